@@ -1,0 +1,182 @@
+/*
+ * smesh.h -- C ABI of the MI355X-native project-and-fuse hot path of semantic-meshes.
+ *
+ * This is the drop-in boundary: every entry point below is what a
+ * binding for the reference's Python modules `semantic_meshes.render` / `semantic_meshes.fusion`
+ * would call instead of the Boost.Python + template-tensors code.  Plain pointers and sizes
+ * only; no torch / numpy / C++ types cross this boundary.
+ *
+ * Two shared libraries export this same ABI:
+ *   semantic_meshes_amd/csrc/libsmesh_hip.so  -- the product: HIP kernels for gfx950 (MI355X)
+ *   oracle/libsmesh_oracle.so                 -- TEST INFRASTRUCTURE ONLY: scalar CPU restatement
+ *
+ * Conventions (reference citations are relative to /root/reference):
+ *   - images are (W,H[,C]) row-major with y fastest: element (x,y) lives at x*H + y
+ *     (python/semantic_meshes/include/Renderer.h:29,32)
+ *   - primitive index images are uint32, background 0xFFFFFFFF; depth float32, background +inf
+ *     (include/semantic_meshes/render/TriangleRenderer.h:75-78; Renderer.h:19-23)
+ *   - every function returns an int status; 0 = ok.  SMESH_ERR_INVALID maps to Python ValueError
+ *     (std::invalid_argument in the reference: include/semantic_meshes/fusion/Mesh.h:68-74,
+ *     python/semantic_meshes/src/Fusion.cu:122-125), everything else to RuntimeError.
+ *   - strides are in ELEMENTS, not bytes, and must be >= 0.
+ */
+#ifndef SMESH_H
+#define SMESH_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes ------------------------------------------------------------------------ */
+#define SMESH_OK            0
+#define SMESH_ERR_INVALID   1   /* bad argument / shape / dtype  -> ValueError            */
+#define SMESH_ERR_RUNTIME   2   /* HIP / RCCL / allocation failure -> RuntimeError         */
+#define SMESH_ERR_NODEVICE  3   /* no usable GPU                 -> RuntimeError           */
+
+/* ---- enums -------------------------------------------------------------------------------- */
+/* index dtypes accepted by add(): python/semantic_meshes/include/Common.h:5-12 */
+#define SMESH_IDX_U32 0
+#define SMESH_IDX_I32 1
+#define SMESH_IDX_U64 2
+#define SMESH_IDX_I64 3
+
+/* where a caller buffer lives: Common.h:10,19,28 (mem::HOST, mem::DEVICE) */
+#define SMESH_MEM_HOST   0
+#define SMESH_MEM_DEVICE 1
+
+/* aggregator kinds: python/semantic_meshes/src/Fusion.cu:46-64 (Summax), :66-76 (Sum), :78-92 (Mul) */
+#define SMESH_AGG_SUM    0
+#define SMESH_AGG_SUMMAX 1
+#define SMESH_AGG_MUL    2
+
+/* ---- camera POD ---------------------------------------------------------------------------- */
+/* Replaces semantic_meshes::Camera (include/semantic_meshes/render/Camera.h:7-15) as filled by the
+ * Python ctor (python/semantic_meshes/include/Camera.h:16-57): float32 rigid world->camera
+ * transform Xc = R*X + t, double per-axis focal lengths / principal point, resolution (W,H). */
+typedef struct smesh_camera {
+  float    rotation[9];      /* row-major 3x3 */
+  float    translation[3];
+  double   focal[2];         /* fx, fy (a scalar-f PinholeFC is passed as fx == fy) */
+  double   principal[2];     /* cx, cy */
+  uint64_t width;            /* resolution(0) */
+  uint64_t height;           /* resolution(1) */
+} smesh_camera_t;
+
+typedef struct smesh_renderer   smesh_renderer_t;
+typedef struct smesh_aggregator smesh_aggregator_t;
+
+/* ---- library / device ---------------------------------------------------------------------- */
+/* Returns a static string naming the backend: "hip-gfx950" or "oracle-cpu". */
+const char* smesh_backend(void);
+/* Thread-local message describing the last non-zero status returned on this thread. */
+const char* smesh_last_error(void);
+/* Number of visible GPUs (oracle: 0). */
+int smesh_device_count(int* count);
+/* Block until all work queued on `device` by this library has finished. */
+int smesh_synchronize(int device);
+
+/* ---- triangle renderer --------------------------------------------------------------------- */
+/* Replaces TriangleRenderer::TriangleRenderer (include/semantic_meshes/render/TriangleRenderer.h:30-39):
+ * uploads float32[V,3] vertices and int32[F,3] faces; primitive id == face ordinal (:57-60). */
+int smesh_renderer_create_triangles(const float* vertices, uint64_t num_vertices,
+                                    const int32_t* faces, uint64_t num_faces,
+                                    int device, smesh_renderer_t** out);
+/* Replaces TexturedTriangleRenderer::TexturedTriangleRenderer
+ * (include/semantic_meshes/render/TexturedTriangleRenderer.h:87-182): texel primitives whose
+ * per-triangle resolution comes from the max projected area over `cameras`. */
+int smesh_renderer_create_texels(const float* vertices, uint64_t num_vertices,
+                                 const int32_t* faces, uint64_t num_faces,
+                                 const smesh_camera_t* cameras, uint64_t num_cameras,
+                                 float texels_per_pixel, int device, smesh_renderer_t** out);
+int smesh_renderer_destroy(smesh_renderer_t* r);
+/* Replaces getPrimitivesNum() (TriangleRenderer.h:41-44, TexturedTriangleRenderer.h:184-187). */
+int smesh_renderer_num_primitives(const smesh_renderer_t* r, uint64_t* out);
+/* Texel renderers only: copies the (possibly re-ordered, TexturedTriangleRenderer.h:129-146) faces,
+ * per-triangle texture resolution and first texel index to host arrays of F*3 / F / F entries.
+ * Any pointer may be NULL. */
+int smesh_renderer_texel_layout(const smesh_renderer_t* r, int32_t* faces_out,
+                                uint32_t* resolution_out, uint32_t* first_texel_out);
+
+/* Replaces Renderer<T>::render (python/semantic_meshes/include/Renderer.h:25-43) =
+ * clear (TriangleRenderer.h:75-78) + rasterize (:81-88) + AoS->SoA split (Renderer.h:32-35).
+ * Writes uint32[W,H] indices and float32[W,H] depth to HOST memory; depth_out may be NULL. */
+int smesh_renderer_render(smesh_renderer_t* r, const smesh_camera_t* camera,
+                          uint32_t* indices_out, float* depth_out);
+/* Same, but the two planes stay in DEVICE memory owned by the renderer (the DLPack capsules of
+ * Renderer.h:37-38).  The returned pointers stay valid until smesh_renderer_release_image() is
+ * called on them or the renderer is destroyed; they can be passed straight to
+ * smesh_aggregator_add(..., SMESH_MEM_DEVICE). */
+int smesh_renderer_render_device(smesh_renderer_t* r, const smesh_camera_t* camera,
+                                 uint32_t** indices_dev, float** depth_dev);
+int smesh_renderer_release_image(smesh_renderer_t* r, void* indices_dev, void* depth_dev);
+
+/* ---- mesh aggregator ----------------------------------------------------------------------- */
+/* Replaces construct1/2/3 + ModelAggregator ctor (python/semantic_meshes/src/Fusion.cu:120-138;
+ * include/semantic_meshes/fusion/Mesh.h:57-63).  num_classes is a run-time value here. */
+int smesh_aggregator_create(uint64_t num_primitives, uint32_t num_classes, int kind,
+                            float images_equal_weight, int device, smesh_aggregator_t** out);
+int smesh_aggregator_destroy(smesh_aggregator_t* a);
+/* Replaces ModelAggregator::reset (Mesh.h:119-122). */
+int smesh_aggregator_reset(smesh_aggregator_t* a);
+
+/* Replaces ModelAggregator::add1/add2 (python/semantic_meshes/include/Fusion.h:42-64) and
+ * ModelAggregator::add (Mesh.h:65-107,109-117).
+ *   indices: (W,H) image of `idx_dtype`, element strides idx_strides[2]
+ *   probs:   (W,H,C) float32, element strides probs_strides[3]
+ *   weights: (W,H) float32 or NULL (== all ones, Mesh.h:109-117), element strides weights_strides[2]
+ * All three must have the same (W,H) -- the caller passes one (W,H); the Python layer raises
+ * ValueError on mismatching shapes like Mesh.h:68-74.  Each buffer has its own memkind: the usual
+ * call (python/scripts/colorize_cityscapes_mesh.py:65-67) passes render()'s DEVICE indices with
+ * HOST network output. */
+int smesh_aggregator_add(smesh_aggregator_t* a,
+                         const void* indices, int idx_dtype, const int64_t idx_strides[2], int idx_memkind,
+                         const float* probs, const int64_t probs_strides[3], int probs_memkind,
+                         const float* weights, const int64_t weights_strides[2], int weights_memkind,
+                         uint64_t width, uint64_t height);
+
+/* Replaces ModelAggregator::get (Fusion.h:72-76; Mesh.h:131-132) with the output functor chain of
+ * the chosen aggregator (Fusion.cu:47-49 / 67-69 / 79-82; Fusion.h:79-104): writes float32[P,C]. */
+int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind);
+
+/* Un-normalised accumulator state float32[P,C] (Sum/Summax: weighted sums; Mul: log-domain sums).
+ * New functionality: this is what is summed across GPUs before get(). */
+int smesh_aggregator_get_raw(smesh_aggregator_t* a, float* out, int memkind);
+int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind);
+/* Device pointer of the raw accumulator (for an in-place RCCL all-reduce); oracle: host pointer. */
+int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* num_floats);
+
+/* ---- fused view: render(camera) -> add(indices, probs) without leaving the device ----------- */
+/* One iteration of the loop at python/scripts/colorize_cityscapes_mesh.py:54-67. probs/weights as
+ * in smesh_aggregator_add with contiguous (W,H,C)/(W,H) layout. */
+int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* camera,
+                    const float* probs, const float* weights, int memkind);
+
+/* ---- timing hooks (tracing) -------------------------------------------- */
+/* When enabled, the library brackets its dominant kernels with HIP events on its own stream.
+ * smesh_profile_read returns accumulated device milliseconds and launch counts per slot. */
+#define SMESH_PROF_FUSE_SCATTER 0   /* the scatter-add fusion kernel          */
+#define SMESH_PROF_FUSE_HIST    1   /* per-view histogram (Mesh.h:90-93)       */
+#define SMESH_PROF_RASTER       2   /* all rasterizer kernels of one render    */
+#define SMESH_PROF_FINALIZE     3   /* get() normalisation                     */
+#define SMESH_PROF_SLOTS        8
+int smesh_profile_enable(int device, int enabled);
+int smesh_profile_read(int device, int slot, double* total_ms, uint64_t* launches);
+int smesh_profile_reset(int device);
+
+/* ---- synthetic workload generators (benchmark utility) ------------------------ */
+/* Fills float32[N,C] class probabilities (softmax of hashed logits; `zero_fraction` of the pixels
+ * get an all-zero don't-care row) directly in device (or host) memory. */
+int smesh_synth_probs(float* out, uint64_t num_pixels, uint32_t num_classes, uint64_t seed,
+                      float zero_fraction, int device, int memkind);
+/* Raw device memory for benchmark inputs that must be resident in HBM before timing starts. */
+int smesh_device_malloc(int device, uint64_t bytes, void** out);
+int smesh_device_free(int device, void* ptr);
+int smesh_memcpy(void* dst, const void* src, uint64_t bytes, int dst_memkind, int src_memkind, int device);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMESH_H */

@@ -1,0 +1,593 @@
+// smesh_oracle.cpp -- CPU restatement of the semantic-meshes project-and-fuse hot path.
+//
+// *** TEST INFRASTRUCTURE -- NOT PART OF THE PRODUCT. ***
+// Only tests/, __graft_entry__.smoke() and bench.py's `cpu_baseline` leg may load this library.
+// The product (semantic_meshes_amd/) never links, imports or falls back to anything in oracle/.
+//
+// PARITY STATUS: "parity unpinned" for the rasteriser.  The reference has no tests, golden vectors
+// or fixtures, cannot be compiled here (needs nvcc + the absent template-tensors,
+// tinyply, dlpack submodules + Boost.Python), and the rasteriser arithmetic lives
+// in the un-vendored, un-pinned submodule extern/template-tensors (.gitmodules:7-9).  The fusion
+// arithmetic (Sum/Summax) IS fully determined by in-tree reference lines and is restated 1:1 below.
+// Behaviours the reference leaves to template-tensors are decided in DESIGN.md ("Raster spec") and
+// implemented here and, independently, in semantic_meshes_amd/csrc/raster.hip.
+//
+// Citations are relative to /root/reference.
+//
+// Build: see oracle/Makefile (g++ -O2 -fopenmp -ffp-contract=off).  -ffp-contract=off matters: the
+// GPU kernels must execute the same IEEE-754 operation sequence to be bit-exact on indices.
+
+#include "../include/smesh.h"
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+#include <omp.h>
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) { g_err = msg; return code; }
+
+int g_threads = 1;            // deterministic by default; bench raises it for the CPU baseline
+bool g_accum_double = false;  // float64 accumulators for tolerance tests (reference uses float32)
+
+// ---------------------------------------------------------------------------------------------
+// Raster spec (DESIGN.md "Raster spec"); protocol from TriangleRenderer.h:30-39,46-61,63-89.
+// ---------------------------------------------------------------------------------------------
+constexpr float kNear = 1e-6f;  // triangles with a vertex at z_c <= kNear are dropped whole (B-3)
+
+struct ScreenVertex {
+  double u, v;  // pixel coordinates: f * (Xc.xy / Xc.z) + c  (render/Camera.h:10-11 -- double intrinsics)
+  double iz;    // 1 / z_c ; 0 marks an unusable vertex
+};
+
+inline ScreenVertex project_vertex(const smesh_camera_t& cam, const float* p) {
+  const float* R = cam.rotation;
+  const float* t = cam.translation;
+  // Rigid<float,3>::transformPoint: float32 (render/Camera.h:13), fixed left-to-right order
+  const float xc = ((R[0] * p[0] + R[1] * p[1]) + R[2] * p[2]) + t[0];
+  const float yc = ((R[3] * p[0] + R[4] * p[1]) + R[5] * p[2]) + t[1];
+  const float zc = ((R[6] * p[0] + R[7] * p[1]) + R[8] * p[2]) + t[2];
+  ScreenVertex s;
+  s.u = 0.0; s.v = 0.0; s.iz = 0.0;
+  if (!(zc > kNear) || !std::isfinite(xc) || !std::isfinite(yc) || !std::isfinite(zc)) return s;
+  const double zd = (double)zc;
+  const double u = cam.focal[0] * ((double)xc / zd) + cam.principal[0];
+  const double v = cam.focal[1] * ((double)yc / zd) + cam.principal[1];
+  if (!std::isfinite(u) || !std::isfinite(v)) return s;
+  s.u = u; s.v = v; s.iz = 1.0 / zd;
+  return s;
+}
+
+// Edge function through two screen points, evaluated with the endpoints in a canonical order so
+// that the two triangles sharing an edge compute bit-identical magnitudes (watertightness, B-2).
+struct Edge {
+  double lx, ly, dx, dy;
+  double sign;  // -1 if the endpoints were swapped into canonical order
+  inline void setup(double ax, double ay, double bx, double by) {
+    const bool sw = (bx < ax) || (bx == ax && by < ay);
+    lx = sw ? bx : ax; ly = sw ? by : ay;
+    const double hx = sw ? ax : bx, hy = sw ? ay : by;
+    dx = hx - lx; dy = hy - ly;
+    sign = sw ? -1.0 : 1.0;
+  }
+  inline double eval(double px, double py) const {
+    const double e = dx * (py - ly) - dy * (px - lx);
+    return sign * e;
+  }
+  // d(eval)/dpx and d(eval)/dpy
+  inline double gx() const { return sign * (-dy); }
+  inline double gy() const { return sign * dx; }
+};
+
+struct TriSetup {
+  Edge e[3];        // e[i] is the edge opposite vertex i
+  double s;         // orientation sign so that interior weights are positive
+  bool own[3];      // tie-break: does a sample exactly on edge i belong to this triangle?
+  double iz[3];
+  int x0, x1, y0, y1;
+  bool ok;
+};
+
+inline TriSetup setup_triangle(const ScreenVertex& a, const ScreenVertex& b, const ScreenVertex& c,
+                               uint64_t W, uint64_t H) {
+  TriSetup t;
+  t.ok = false;
+  if (a.iz == 0.0 || b.iz == 0.0 || c.iz == 0.0) return t;
+  const double minu = std::min(a.u, std::min(b.u, c.u)), maxu = std::max(a.u, std::max(b.u, c.u));
+  const double minv = std::min(a.v, std::min(b.v, c.v)), maxv = std::max(a.v, std::max(b.v, c.v));
+  // samples sit at pixel centres (x + 0.5, y + 0.5)  (B-1)
+  double fx0 = std::ceil(minu - 0.5), fx1 = std::floor(maxu - 0.5);
+  double fy0 = std::ceil(minv - 0.5), fy1 = std::floor(maxv - 0.5);
+  if (fx0 < 0.0) fx0 = 0.0;
+  if (fy0 < 0.0) fy0 = 0.0;
+  if (fx1 > (double)(W - 1)) fx1 = (double)(W - 1);
+  if (fy1 > (double)(H - 1)) fy1 = (double)(H - 1);
+  if (!(fx0 <= fx1) || !(fy0 <= fy1)) return t;
+  t.x0 = (int)fx0; t.x1 = (int)fx1; t.y0 = (int)fy0; t.y1 = (int)fy1;
+  t.e[0].setup(b.u, b.v, c.u, c.v);
+  t.e[1].setup(c.u, c.v, a.u, a.v);
+  t.e[2].setup(a.u, a.v, b.u, b.v);
+  const double area2 = t.e[2].eval(c.u, c.v);
+  if (!(area2 != 0.0) || !std::isfinite(area2)) return t;  // degenerate; no back-face culling (a3)
+  t.s = area2 > 0.0 ? 1.0 : -1.0;
+  for (int i = 0; i < 3; i++) {
+    const double A = t.s * t.e[i].gx(), B = t.s * t.e[i].gy();
+    t.own[i] = (A > 0.0) || (A == 0.0 && B > 0.0);
+  }
+  t.iz[0] = a.iz; t.iz[1] = b.iz; t.iz[2] = c.iz;
+  t.ok = true;
+  return t;
+}
+
+// Returns true and the weights if sample (px,py) is covered.
+inline bool cover(const TriSetup& t, double px, double py, double w[3]) {
+  for (int i = 0; i < 3; i++) {
+    w[i] = t.s * t.e[i].eval(px, py);
+    if (!(w[i] > 0.0 || (w[i] == 0.0 && t.own[i]))) return false;
+  }
+  return true;
+}
+
+// perspective-correct camera-space depth (B-3)
+inline bool depth_at(const TriSetup& t, const double w[3], float* z) {
+  const double num = (w[0] + w[1]) + w[2];
+  const double den = (w[0] * t.iz[0] + w[1] * t.iz[1]) + w[2] * t.iz[2];
+  const float zf = (float)(num / den);
+  if (!(zf > 0.0f) || !std::isfinite(zf)) return false;
+  *z = zf;
+  return true;
+}
+
+inline uint32_t float_bits(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline float bits_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+
+constexpr uint64_t kBackgroundKey = ((uint64_t)0x7F800000u << 32) | 0xFFFFFFFFull;  // {+inf, -1}
+
+inline void key_min(uint64_t* slot, uint64_t key, bool parallel) {
+  if (!parallel) { if (key < *slot) *slot = key; return; }
+  uint64_t cur = __atomic_load_n(slot, __ATOMIC_RELAXED);
+  while (key < cur && !__atomic_compare_exchange_n(slot, &cur, key, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
+
+// SymmetricMatrixLowerTriangleRowMajor::toIndex is out of tree (B-5); decided bijection:
+// row = tu + tv, col = tu  ->  row*(row+1)/2 + col, with (tu,tv) clamped into the triangle.
+inline uint32_t texel_index(uint32_t res, double b1, double b2) {
+  // TexturedTriangleRenderer.h:34-38: uv = b1*(1,0) + b2*(0,1) in float; t = (int)((uv - 1e-6) * res)
+  const float u = (float)b1, v = (float)b2;
+  const float fu = (u - 1e-6f) * (float)res, fv = (v - 1e-6f) * (float)res;
+  int tu = (int)fu, tv = (int)fv;
+  if (tu < 0) tu = 0;
+  if (tv < 0) tv = 0;
+  const int r1 = (int)res - 1;
+  if (tu > r1) tu = r1;
+  if (tv > r1 - tu) tv = r1 - tu;
+  const int row = tu + tv;
+  return (uint32_t)(row * (row + 1) / 2 + tu);
+}
+
+}  // namespace
+
+struct smesh_renderer {
+  std::vector<float> verts;
+  std::vector<int32_t> faces;
+  uint64_t V = 0, F = 0;
+  bool texels = false;
+  std::vector<uint32_t> tex_res, tex_first;
+  uint64_t num_primitives = 0;
+  std::vector<uint64_t> keys;
+  std::vector<ScreenVertex> sv;
+};
+
+struct smesh_aggregator {
+  uint64_t P = 0;
+  uint32_t C = 0;
+  int kind = 0;
+  float iew = 0.5f;
+  std::vector<float> acc;    // float32 state, as the reference (Fusion.cu:58,71,85)
+  std::vector<double> accd;  // used instead when g_accum_double
+  std::vector<std::mutex> locks;  // atomic::op::Lock<std::mutex> per primitive (Fusion.cu:58,71,85)
+  smesh_aggregator(uint64_t P_, uint32_t C_) : P(P_), C(C_), locks(P_) {}
+};
+
+extern "C" {
+
+const char* smesh_backend(void) { return "oracle-cpu"; }
+const char* smesh_last_error(void) { return g_err.c_str(); }
+int smesh_device_count(int* count) { if (count) *count = 0; return SMESH_OK; }
+int smesh_synchronize(int) { return SMESH_OK; }
+
+// oracle-only knobs (not part of smesh.h)
+int smesh_oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; return SMESH_OK; }
+int smesh_oracle_get_threads(void) { return g_threads; }
+int smesh_oracle_set_accum_double(int on) { g_accum_double = on != 0; return SMESH_OK; }
+
+// --------------------------------------------------------------------------------------------
+// renderer
+// --------------------------------------------------------------------------------------------
+static int make_renderer(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F,
+                         smesh_renderer_t** out) {
+  if (!out) return fail(SMESH_ERR_INVALID, "out is NULL");
+  if ((V && !vertices) || (F && !faces)) return fail(SMESH_ERR_INVALID, "NULL mesh arrays");
+  auto* r = new (std::nothrow) smesh_renderer();
+  if (!r) return fail(SMESH_ERR_RUNTIME, "out of memory");
+  r->V = V; r->F = F;
+  r->verts.assign(vertices, vertices + 3 * V);   // TriangleRenderer.h:36
+  r->faces.assign(faces, faces + 3 * F);         // TriangleRenderer.h:37-38
+  r->num_primitives = F;                         // TriangleRenderer.h:41-44
+  *out = r;
+  return SMESH_OK;
+}
+
+int smesh_renderer_create_triangles(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F,
+                                    int, smesh_renderer_t** out) {
+  return make_renderer(vertices, V, faces, F, out);
+}
+
+// TexturedTriangleRenderer.h:87-182
+int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F,
+                                 const smesh_camera_t* cameras, uint64_t K, float tpp, int,
+                                 smesh_renderer_t** out) {
+  if (K && !cameras) return fail(SMESH_ERR_INVALID, "NULL cameras");
+  int st = make_renderer(vertices, V, faces, F, out);
+  if (st) return st;
+  smesh_renderer* r = *out;
+  r->texels = true;
+  r->tex_res.assign(F, 0);
+  r->tex_first.assign(F, 0);
+  for (uint64_t f = 0; f < F; f++) {
+    int32_t* face = &r->faces[3 * f];
+    bool valid = true;
+    for (int k = 0; k < 3; k++) if (face[k] < 0 || (uint64_t)face[k] >= V) valid = false;
+    if (!valid) continue;
+    auto vert = [&](int k) { return &r->verts[3 * (size_t)face[k % 3]]; };
+    float best = 0.0f;  // aggregator::max<float>(0)  (:92)
+    for (uint64_t ci = 0; ci < K; ci++) {
+      const smesh_camera_t& cam = cameras[ci];
+      float pu[3], pv[3];
+      bool in_front = false;
+      for (int k = 0; k < 3; k++) {
+        const float* p = vert(k);
+        const float* R = cam.rotation; const float* t = cam.translation;
+        const float xc = ((R[0] * p[0] + R[1] * p[1]) + R[2] * p[2]) + t[0];
+        const float yc = ((R[3] * p[0] + R[4] * p[1]) + R[5] * p[2]) + t[1];
+        const float zc = ((R[6] * p[0] + R[7] * p[1]) + R[8] * p[2]) + t[2];
+        in_front |= zc > 0.0f;  // :108
+        // Project -> Vector2f (:73-82,109)
+        pu[k] = (float)(cam.focal[0] * ((double)xc / (double)zc) + cam.principal[0]);
+        pv[k] = (float)(cam.focal[1] * ((double)yc / (double)zc) + cam.principal[1]);
+      }
+      const float border = 0.5f;  // :114
+      const float rw = (float)(int)cam.width, rh = (float)(int)cam.height;
+      bool inside = in_front;
+      for (int k = 0; k < 3 && inside; k++) {
+        inside = (-border * rw <= pu[k]) && (pu[k] < (1 + border) * rw) &&
+                 (-border * rh <= pv[k]) && (pv[k] < (1 + border) * rh);  // :115-119
+      }
+      if (inside) {
+        const float area = 0.5f * std::fabs(pu[0] * (pv[1] - pv[2]) + pu[1] * (pv[2] - pv[0]) + pu[2] * (pv[0] - pv[1]));  // :121-123
+        if (area > best) best = area;
+      }
+    }
+    r->tex_res[f] = (uint32_t)std::ceil(tpp * std::sqrt(best));  // :127
+
+    // "Optimally order face indices" (:129-146): vertex 0 gets the angle closest to 90 degrees
+    float diffs[3];
+    for (int k = 0; k < 3; k++) {
+      const float* p0 = vert(k); const float* p1 = vert(k + 1); const float* p2 = vert(k + 2);
+      const float ax = p1[0] - p0[0], ay = p1[1] - p0[1], az = p1[2] - p0[2];
+      const float bx = p2[0] - p0[0], by = p2[1] - p0[1], bz = p2[2] - p0[2];
+      const float dot = ax * bx + ay * by + az * bz;
+      const float la = std::sqrt(ax * ax + ay * ay + az * az), lb = std::sqrt(bx * bx + by * by + bz * bz);
+      float cosv = dot / (la * lb);
+      if (cosv > 1.0f) cosv = 1.0f;
+      if (cosv < -1.0f) cosv = -1.0f;
+      const float angle = std::acos(cosv);
+      diffs[k] = std::fabs(angle - 1.57079632679489661923f);
+    }
+    int best_k = 0;
+    for (int k = 1; k < 3; k++) if (diffs[k] < diffs[best_k]) best_k = k;
+    if (best_k != 0) { std::swap(face[0], face[best_k]); std::swap(diffs[0], diffs[best_k]); }
+    if (diffs[1] >= diffs[2]) std::swap(face[1], face[2]);
+  }
+  // prefix sum (:149-162); getTexelNum = r(r+1)/2 (:43-47)
+  uint64_t total = 0;
+  for (uint64_t f = 0; f < F; f++) {
+    r->tex_first[f] = (uint32_t)total;
+    const uint64_t res = r->tex_res[f];
+    total += res * (res + 1) / 2;
+  }
+  if (total >= 0xFFFFFFFFull) { delete r; *out = nullptr; return fail(SMESH_ERR_INVALID, "texel count overflows uint32"); }
+  r->num_primitives = total;
+  return SMESH_OK;
+}
+
+int smesh_renderer_destroy(smesh_renderer_t* r) { delete r; return SMESH_OK; }
+
+int smesh_renderer_num_primitives(const smesh_renderer_t* r, uint64_t* out) {
+  if (!r || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
+  *out = r->num_primitives;
+  return SMESH_OK;
+}
+
+int smesh_renderer_texel_layout(const smesh_renderer_t* r, int32_t* faces_out, uint32_t* res_out, uint32_t* first_out) {
+  if (!r) return fail(SMESH_ERR_INVALID, "NULL renderer");
+  if (!r->texels) return fail(SMESH_ERR_INVALID, "not a texel renderer");
+  if (faces_out) std::memcpy(faces_out, r->faces.data(), r->faces.size() * sizeof(int32_t));
+  if (res_out) std::memcpy(res_out, r->tex_res.data(), r->tex_res.size() * sizeof(uint32_t));
+  if (first_out) std::memcpy(first_out, r->tex_first.data(), r->tex_first.size() * sizeof(uint32_t));
+  return SMESH_OK;
+}
+
+// Renderer<T>::render (Renderer.h:25-43) = clear (TriangleRenderer.h:75-78) + raster (:81-88) + split (Renderer.h:32-35)
+int smesh_renderer_render(smesh_renderer_t* r, const smesh_camera_t* cam, uint32_t* idx_out, float* depth_out) {
+  if (!r || !cam || !idx_out) return fail(SMESH_ERR_INVALID, "NULL argument");
+  const uint64_t W = cam->width, H = cam->height;
+  if (W == 0 || H == 0 || W > 65536 || H > 65536) return fail(SMESH_ERR_INVALID, "bad resolution");
+  const uint64_t N = W * H;
+  r->keys.assign(N, kBackgroundKey);  // {z=+inf, primitive_index=-1}
+  r->sv.resize(r->V);
+  const bool par = g_threads > 1;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (par)
+  for (int64_t v = 0; v < (int64_t)r->V; v++) r->sv[v] = project_vertex(*cam, &r->verts[3 * v]);
+#pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1024) if (par)
+  for (int64_t f = 0; f < (int64_t)r->F; f++) {
+    const int32_t* face = &r->faces[3 * f];
+    if (face[0] < 0 || face[1] < 0 || face[2] < 0) continue;
+    if ((uint64_t)face[0] >= r->V || (uint64_t)face[1] >= r->V || (uint64_t)face[2] >= r->V) continue;
+    const TriSetup t = setup_triangle(r->sv[face[0]], r->sv[face[1]], r->sv[face[2]], W, H);
+    if (!t.ok) continue;
+    if (r->texels && r->tex_res[f] == 0) continue;  // a triangle without texels has no primitive to write
+    for (int x = t.x0; x <= t.x1; x++) {
+      for (int y = t.y0; y <= t.y1; y++) {
+        double w[3];
+        if (!cover(t, (double)x + 0.5, (double)y + 0.5, w)) continue;
+        float z;
+        if (!depth_at(t, w, &z)) continue;
+        uint32_t prim = (uint32_t)f;  // Shader: primitive ordinal (TriangleRenderer.h:57-60)
+        if (r->texels) {
+          const double num = (w[0] + w[1]) + w[2];
+          prim = r->tex_first[f] + texel_index(r->tex_res[f], w[1] / num, w[2] / num);  // TexturedTriangleRenderer.h:193-196
+        }
+        const uint64_t key = ((uint64_t)float_bits(z) << 32) | prim;
+        key_min(&r->keys[(uint64_t)x * H + y], key, par);  // nearest z wins; ties -> lower id (B-4)
+      }
+    }
+  }
+  for (uint64_t i = 0; i < N; i++) {
+    idx_out[i] = (uint32_t)(r->keys[i] & 0xFFFFFFFFull);
+    if (depth_out) depth_out[i] = bits_float((uint32_t)(r->keys[i] >> 32));
+  }
+  return SMESH_OK;
+}
+
+int smesh_renderer_render_device(smesh_renderer_t*, const smesh_camera_t*, uint32_t**, float**) {
+  return fail(SMESH_ERR_NODEVICE, "oracle has no device memory");
+}
+int smesh_renderer_release_image(smesh_renderer_t*, void*, void*) { return SMESH_OK; }
+
+// --------------------------------------------------------------------------------------------
+// aggregator
+// --------------------------------------------------------------------------------------------
+static void agg_fill_zero(smesh_aggregator* a) {
+  // Sum/Summax start at the 0-vector; Mul at LogProb of 1 == log-domain 0 (Mesh.h:57-63; A.2)
+  std::fill(a->acc.begin(), a->acc.end(), 0.0f);
+  std::fill(a->accd.begin(), a->accd.end(), 0.0);
+}
+
+int smesh_aggregator_create(uint64_t P, uint32_t C, int kind, float iew, int, smesh_aggregator_t** out) {
+  if (!out) return fail(SMESH_ERR_INVALID, "out is NULL");
+  if (C == 0) return fail(SMESH_ERR_INVALID, "classes must be > 0");
+  if (kind < 0 || kind > 2) return fail(SMESH_ERR_INVALID, "unknown aggregator kind");
+  if (P >= 0xFFFFFFFFull) return fail(SMESH_ERR_INVALID, "too many primitives for uint32 indices");
+  auto* a = new (std::nothrow) smesh_aggregator(P, C);
+  if (!a) return fail(SMESH_ERR_RUNTIME, "out of memory");
+  a->kind = kind; a->iew = iew;
+  if (g_accum_double) a->accd.assign(P * C, 0.0); else a->acc.assign(P * C, 0.0f);
+  *out = a;
+  return SMESH_OK;
+}
+
+int smesh_aggregator_destroy(smesh_aggregator_t* a) { delete a; return SMESH_OK; }
+
+int smesh_aggregator_reset(smesh_aggregator_t* a) {  // Mesh.h:119-122
+  if (!a) return fail(SMESH_ERR_INVALID, "NULL aggregator");
+  agg_fill_zero(a);
+  return SMESH_OK;
+}
+
+static inline uint32_t load_idx(const void* base, int dtype, int64_t off) {
+  // FromPrimitiveImage accepts u32/i32/u64/i64 (Common.h:5-12); TensorConstructor casts to uint32 (Fusion.h:45)
+  switch (dtype) {
+    case SMESH_IDX_U32: return ((const uint32_t*)base)[off];
+    case SMESH_IDX_I32: return (uint32_t)((const int32_t*)base)[off];
+    case SMESH_IDX_U64: return (uint32_t)((const uint64_t*)base)[off];
+    default:            return (uint32_t)((const int64_t*)base)[off];
+  }
+}
+
+// ModelAggregator::add1/add2 (Fusion.h:42-64) -> ModelAggregator::add (Mesh.h:65-107)
+int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dtype, const int64_t is[2], int imem,
+                         const float* probs, const int64_t ps[3], int pmem,
+                         const float* weights, const int64_t ws[2], int wmem,
+                         uint64_t W, uint64_t H) {
+  if (!a || !indices || !probs || !is || !ps) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (imem != SMESH_MEM_HOST || pmem != SMESH_MEM_HOST || (weights && wmem != SMESH_MEM_HOST))
+    return fail(SMESH_ERR_INVALID, "oracle only reads host memory");
+  if (idx_dtype < 0 || idx_dtype > 3) return fail(SMESH_ERR_INVALID, "bad index dtype");
+  if (weights && !ws) return fail(SMESH_ERR_INVALID, "weights without strides");
+  const uint64_t N = W * H;
+  const uint32_t C = a->C;
+  const uint64_t P = a->P;
+  const bool par = g_threads > 1;
+
+  // Fusion.h:45-47 -- TensorConstructor: OpenMP element copy (+cast) into fresh row-major host tensors
+  std::vector<uint32_t> idx(N);
+  std::vector<float> pr(N * C);
+  std::vector<float> wt(weights ? N : 0);
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (par)
+  for (int64_t x = 0; x < (int64_t)W; x++)
+    for (uint64_t y = 0; y < H; y++) {
+      const uint64_t i = (uint64_t)x * H + y;
+      idx[i] = load_idx(indices, idx_dtype, x * is[0] + (int64_t)y * is[1]);
+      for (uint32_t c = 0; c < C; c++) pr[i * C + c] = probs[x * ps[0] + (int64_t)y * ps[1] + (int64_t)c * ps[2]];
+      if (weights) wt[i] = weights[x * ws[0] + (int64_t)y * ws[1]];
+    }
+
+  // Mesh.h:90-93 -- serial std::map histogram over ALL pixels of this image
+  std::map<size_t, size_t> pixels_per_face;
+  for (uint64_t i = 0; i < N; i++) pixels_per_face.insert({(size_t)idx[i], 0}).first->second += 1;
+
+  // Mesh.h:94-106 -- OpenMP 2-D loop, one lock per primitive
+  const float iew = a->iew;
+  const int kind = a->kind;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (par)
+  for (int64_t i = 0; i < (int64_t)N; i++) {
+    const size_t primitive_index = idx[i];
+    if (!(primitive_index < P)) continue;                       // Mesh.h:95
+    const float* next = &pr[(uint64_t)i * C];
+    float sum = 0.0f;
+    for (uint32_t c = 0; c < C; c++) sum = sum + next[c];        // tt::sum, sequential float32
+    if (!(sum > 0.5f)) continue;                                // Mesh.h:98 "Not the don't-care class"
+    const float image_weight = 1.0f / ((float)pixels_per_face.find(primitive_index)->second);  // :100
+    const float pixel_weight = 1.0f;                                                        // :101
+    const float image_pixel_weight = iew * image_weight + (1 - iew) * pixel_weight;           // :102
+    const float w = image_pixel_weight * (weights ? wt[i] : 1.0f);                           // :103
+    std::unique_lock<std::mutex> guard(a->locks[primitive_index], std::defer_lock);
+    if (par) guard.lock();
+    if (kind == SMESH_AGG_SUM) {
+      // aggregator::weighted::sum (Fusion.cu:70-73): s += p * w
+      if (g_accum_double) { double* s = &a->accd[primitive_index * C]; for (uint32_t c = 0; c < C; c++) s[c] += (double)(next[c] * w); }
+      else { float* s = &a->acc[primitive_index * C]; for (uint32_t c = 0; c < C; c++) s[c] = s[c] + next[c] * w; }
+    } else if (kind == SMESH_AGG_SUMMAX) {
+      // Fusion.cu:51-56: only the (first) arg-max class contributes prob*weight
+      uint32_t m = 0;
+      for (uint32_t c = 1; c < C; c++) if (next[c] > next[m]) m = c;
+      if (g_accum_double) a->accd[primitive_index * C + m] += (double)(next[m] * w);
+      else a->acc[primitive_index * C + m] = a->acc[primitive_index * C + m] + next[m] * w;
+    } else {
+      // Fusion.cu:83-87: map_input(pow) -> prod of LogProb<float>: L += log(p^w)   (B-6)
+      for (uint32_t c = 0; c < C; c++) {
+        const float l = std::log(std::pow(next[c], w));
+        if (g_accum_double) a->accd[primitive_index * C + c] += (double)l;
+        else a->acc[primitive_index * C + c] = a->acc[primitive_index * C + c] + l;
+      }
+    }
+  }
+  return SMESH_OK;
+}
+
+static inline float nan_inf_to_zero(float v) { return (std::isnan(v) || std::isinf(v)) ? 0.0f : v; }  // Fusion.h:79-95
+
+// ModelAggregator::get (Fusion.h:72-76, Mesh.h:131-132) + functor chains (Fusion.cu:47-49,67-69,79-82)
+int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind) {
+  if (!a || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (memkind != SMESH_MEM_HOST) return fail(SMESH_ERR_INVALID, "oracle only writes host memory");
+  const uint32_t C = a->C;
+  std::vector<float> row(C);
+  for (uint64_t p = 0; p < a->P; p++) {
+    for (uint32_t c = 0; c < C; c++) row[c] = g_accum_double ? (float)a->accd[p * C + c] : a->acc[p * C + c];
+    if (a->kind == SMESH_AGG_MUL) {
+      // logprob_normalize (Fusion.h:97-104): p / max_el(p) in the log domain, then cast to float
+      float m = row[0];
+      for (uint32_t c = 1; c < C; c++) if (row[c] > m) m = row[c];
+      for (uint32_t c = 0; c < C; c++) row[c] = std::exp(row[c] - m);
+    }
+    float n = 0.0f;  // normalize<l1_norm> (Fusion.cu:48,68,80)
+    for (uint32_t c = 0; c < C; c++) n = n + std::fabs(row[c]);
+    for (uint32_t c = 0; c < C; c++) out[p * C + c] = nan_inf_to_zero(row[c] / n);
+  }
+  return SMESH_OK;
+}
+
+int smesh_aggregator_get_raw(smesh_aggregator_t* a, float* out, int memkind) {
+  if (!a || !out || memkind != SMESH_MEM_HOST) return fail(SMESH_ERR_INVALID, "bad argument");
+  const uint64_t n = a->P * a->C;
+  if (g_accum_double) for (uint64_t i = 0; i < n; i++) out[i] = (float)a->accd[i];
+  else std::memcpy(out, a->acc.data(), n * sizeof(float));
+  return SMESH_OK;
+}
+
+int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind) {
+  if (!a || !in || memkind != SMESH_MEM_HOST) return fail(SMESH_ERR_INVALID, "bad argument");
+  const uint64_t n = a->P * a->C;
+  if (g_accum_double) for (uint64_t i = 0; i < n; i++) a->accd[i] = in[i];
+  else std::memcpy(a->acc.data(), in, n * sizeof(float));
+  return SMESH_OK;
+}
+
+int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* n) {
+  if (!a || !ptr) return fail(SMESH_ERR_INVALID, "bad argument");
+  if (g_accum_double) return fail(SMESH_ERR_INVALID, "raw pointer unavailable with float64 accumulators");
+  *ptr = a->acc.data();
+  if (n) *n = a->P * a->C;
+  return SMESH_OK;
+}
+
+int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cam,
+                    const float* probs, const float* weights, int memkind) {
+  if (!r || !a || !cam || !probs) return fail(SMESH_ERR_INVALID, "NULL argument");
+  const uint64_t W = cam->width, H = cam->height;
+  std::vector<uint32_t> idx(W * H);
+  int st = smesh_renderer_render(r, cam, idx.data(), nullptr);
+  if (st) return st;
+  const int64_t is[2] = {(int64_t)H, 1};
+  const int64_t ps[3] = {(int64_t)H * a->C, (int64_t)a->C, 1};
+  return smesh_aggregator_add(a, idx.data(), SMESH_IDX_U32, is, SMESH_MEM_HOST, probs, ps, memkind,
+                              weights, is, memkind, W, H);
+}
+
+// --------------------------------------------------------------------------------------------
+int smesh_profile_enable(int, int) { return SMESH_OK; }
+int smesh_profile_read(int, int, double* ms, uint64_t* n) { if (ms) *ms = 0; if (n) *n = 0; return SMESH_OK; }
+int smesh_profile_reset(int) { return SMESH_OK; }
+
+// Synthetic probabilities.  Arithmetic is chosen so that CPU and GPU produce the same
+// bits: hashed uniforms u in [0,1) -> q = u^4 (peaky, softmax-like) -> p = q / sum(q).
+static inline uint64_t splitmix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+
+int smesh_synth_probs(float* out, uint64_t N, uint32_t C, uint64_t seed, float zero_fraction, int, int memkind) {
+  if (!out || memkind != SMESH_MEM_HOST) return fail(SMESH_ERR_INVALID, "bad argument");
+  const uint32_t zthr = (uint32_t)(zero_fraction * 16777216.0f);
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
+  for (int64_t i = 0; i < (int64_t)N; i++) {
+    float* row = out + (uint64_t)i * C;
+    const uint64_t hz = splitmix64(seed ^ (0xD1B54A32D192ED03ull * ((uint64_t)i + 1)));
+    if ((uint32_t)(hz >> 40) < zthr) { for (uint32_t c = 0; c < C; c++) row[c] = 0.0f; continue; }
+    float s = 0.0f;
+    for (uint32_t c = 0; c < C; c++) {
+      const uint64_t h = splitmix64(seed + 0x632BE59BD9B4E019ull * ((uint64_t)i * C + c + 1));
+      const float u = (float)(uint32_t)(h >> 40) * (1.0f / 16777216.0f);
+      const float u2 = u * u;
+      const float q = u2 * u2 + 1e-4f;
+      row[c] = q;
+      s = s + q;
+    }
+    for (uint32_t c = 0; c < C; c++) row[c] = row[c] / s;
+  }
+  return SMESH_OK;
+}
+
+int smesh_device_malloc(int, uint64_t, void**) { return fail(SMESH_ERR_NODEVICE, "oracle has no device memory"); }
+int smesh_device_free(int, void*) { return SMESH_OK; }
+int smesh_memcpy(void* dst, const void* src, uint64_t bytes, int dk, int sk, int) {
+  if (dk != SMESH_MEM_HOST || sk != SMESH_MEM_HOST) return fail(SMESH_ERR_NODEVICE, "oracle has no device memory");
+  std::memmove(dst, src, bytes);
+  return SMESH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,109 @@
+"""ctypes loader for the HIP library (semantic_meshes_amd/csrc/libsmesh_hip.so).
+
+The C ABI is declared in include/smesh.h.  There is deliberately NO CPU fallback here: if the
+HIP library is missing or no GPU is usable, calls raise -- the product never routes through oracle/.
+"""
+import ctypes
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsmesh_hip.so")
+
+OK, ERR_INVALID, ERR_RUNTIME, ERR_NODEVICE = 0, 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+IDX_U32, IDX_I32, IDX_U64, IDX_I64 = 0, 1, 2, 3
+AGG_KINDS = {"Sum": 0, "Summax": 1, "Mul": 2}
+PROF_FUSE_SCATTER, PROF_FUSE_HIST, PROF_RASTER, PROF_FINALIZE = 0, 1, 2, 3
+
+c_void_p, c_int, c_u64, c_u32, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_float
+P = ctypes.POINTER
+
+
+class CameraPOD(ctypes.Structure):
+    """smesh_camera_t (include/smesh.h)."""
+    _fields_ = [
+        ("rotation", ctypes.c_float * 9),
+        ("translation", ctypes.c_float * 3),
+        ("focal", ctypes.c_double * 2),
+        ("principal", ctypes.c_double * 2),
+        ("width", ctypes.c_uint64),
+        ("height", ctypes.c_uint64),
+    ]
+
+
+# name -> (restype, argtypes); one entry per symbol declared in include/smesh.h
+SIGNATURES = {
+    "smesh_backend": (ctypes.c_char_p, []),
+    "smesh_last_error": (ctypes.c_char_p, []),
+    "smesh_device_count": (c_int, [P(c_int)]),
+    "smesh_synchronize": (c_int, [c_int]),
+    "smesh_renderer_create_triangles": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_int, P(c_void_p)]),
+    "smesh_renderer_create_texels": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64, c_float, c_int, P(c_void_p)]),
+    "smesh_renderer_destroy": (c_int, [c_void_p]),
+    "smesh_renderer_num_primitives": (c_int, [c_void_p, P(c_u64)]),
+    "smesh_renderer_texel_layout": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "smesh_renderer_render": (c_int, [c_void_p, P(CameraPOD), c_void_p, c_void_p]),
+    "smesh_renderer_render_device": (c_int, [c_void_p, P(CameraPOD), P(c_void_p), P(c_void_p)]),
+    "smesh_renderer_release_image": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "smesh_aggregator_create": (c_int, [c_u64, c_u32, c_int, c_float, c_int, P(c_void_p)]),
+    "smesh_aggregator_destroy": (c_int, [c_void_p]),
+    "smesh_aggregator_reset": (c_int, [c_void_p]),
+    "smesh_aggregator_add": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int,
+                                     c_void_p, P(ctypes.c_int64), c_int,
+                                     c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64]),
+    "smesh_aggregator_get": (c_int, [c_void_p, c_void_p, c_int]),
+    "smesh_aggregator_get_raw": (c_int, [c_void_p, c_void_p, c_int]),
+    "smesh_aggregator_set_raw": (c_int, [c_void_p, c_void_p, c_int]),
+    "smesh_aggregator_raw_pointer": (c_int, [c_void_p, P(c_void_p), P(c_u64)]),
+    "smesh_fuse_view": (c_int, [c_void_p, c_void_p, P(CameraPOD), c_void_p, c_void_p, c_int]),
+    "smesh_profile_enable": (c_int, [c_int, c_int]),
+    "smesh_profile_read": (c_int, [c_int, c_int, P(ctypes.c_double), P(c_u64)]),
+    "smesh_profile_reset": (c_int, [c_int]),
+    "smesh_synth_probs": (c_int, [c_void_p, c_u64, c_u32, c_u64, c_float, c_int, c_int]),
+    "smesh_device_malloc": (c_int, [c_int, c_u64, P(c_void_p)]),
+    "smesh_device_free": (c_int, [c_int, c_void_p]),
+    "smesh_memcpy": (c_int, [c_void_p, c_void_p, c_u64, c_int, c_int, c_int]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load libsmesh_hip.so (once).  Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        "semantic_meshes_amd: %s not found -- build it with `make -C semantic_meshes_amd/csrc` "
+                        "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+                L = ctypes.CDLL(LIB_PATH)
+                for name, (res, args) in SIGNATURES.items():
+                    fn = getattr(L, name)  # AttributeError if the library does not export the ABI
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = L
+    return _lib
+
+
+def check(status):
+    """Map a C status to the reference's exception types (ValueError <- std::invalid_argument)."""
+    if status == OK:
+        return
+    msg = lib().smesh_last_error().decode(errors="replace")
+    if status == ERR_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(msg)
+
+
+def device_count():
+    n = c_int(0)
+    check(lib().smesh_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def synchronize(device=0):
+    check(lib().smesh_synchronize(device))

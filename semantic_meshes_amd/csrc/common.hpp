@@ -1,0 +1,70 @@
+// common.hpp -- shared host-side plumbing of libsmesh_hip.so (device contexts, errors, timing).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/smesh.h"
+
+namespace smesh {
+
+int fail(int code, const std::string& msg);
+int fail_hip(hipError_t e, const char* what, const char* file, int line);
+
+#define SMESH_HIP(expr)                                                         \
+  do {                                                                          \
+    hipError_t _e = (expr);                                                     \
+    if (_e != hipSuccess) return ::smesh::fail_hip(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define SMESH_TRY(expr)              \
+  do {                               \
+    int _s = (expr);                 \
+    if (_s != SMESH_OK) return _s;   \
+  } while (0)
+
+struct ProfSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // recorded, not yet read
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;     // free event pairs
+  double total_ms = 0.0;
+  uint64_t launches = 0;
+};
+
+// One per GPU: a compute stream all of this library's kernels and copies are ordered on.
+struct DeviceCtx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  int num_cus = 256;
+  bool profiling = false;
+  ProfSlot slots[SMESH_PROF_SLOTS];
+  std::recursive_mutex mu;
+};
+
+// Returns the context of `device`, creating it (and its stream) on first use.
+int get_ctx(int device, DeviceCtx** out);
+
+// RAII: brackets a region of the context's stream with HIP events when profiling is enabled.
+struct ProfScope {
+  DeviceCtx* ctx;
+  int slot;
+  hipEvent_t start = nullptr, stop = nullptr;
+  ProfScope(DeviceCtx* c, int s);
+  ~ProfScope();
+};
+
+// Grow-only device scratch buffer.
+struct Scratch {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int reserve(size_t need);
+  void release();
+};
+
+inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
+
+}  // namespace smesh

@@ -1,0 +1,206 @@
+// context.cpp -- device contexts, error strings, memory helpers and the timing hooks of the C ABI.
+#include "common.hpp"
+
+#include <cstring>
+#include <memory>
+
+namespace smesh {
+
+static thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+
+int fail_hip(hipError_t e, const char* what, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  g_err = buf;
+  // clear the sticky error so that later calls report their own failures
+  (void)hipGetLastError();
+  return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? SMESH_ERR_NODEVICE : SMESH_ERR_RUNTIME;
+}
+
+static std::mutex g_ctx_mu;
+static std::vector<std::unique_ptr<DeviceCtx>> g_ctx;
+
+int get_ctx(int device, DeviceCtx** out) {
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(SMESH_ERR_NODEVICE, "no HIP device available (libsmesh_hip has no CPU fallback)");
+  }
+  if (device < 0 || device >= n) return fail(SMESH_ERR_INVALID, "device index out of range");
+  if ((int)g_ctx.size() < n) g_ctx.resize(n);
+  if (!g_ctx[device]) {
+    SMESH_HIP(hipSetDevice(device));
+    auto ctx = std::make_unique<DeviceCtx>();
+    ctx->device = device;
+    SMESH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    hipDeviceProp_t prop;
+    SMESH_HIP(hipGetDeviceProperties(&prop, device));
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    g_ctx[device] = std::move(ctx);
+  }
+  *out = g_ctx[device].get();
+  return SMESH_OK;
+}
+
+ProfScope::ProfScope(DeviceCtx* c, int s) : ctx(c), slot(s) {
+  if (!ctx->profiling) return;
+  ProfSlot& ps = ctx->slots[slot];
+  if (!ps.pool.empty()) {
+    start = ps.pool.back().first;
+    stop = ps.pool.back().second;
+    ps.pool.pop_back();
+  } else {
+    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) {
+      start = stop = nullptr;
+      return;
+    }
+  }
+  (void)hipEventRecord(start, ctx->stream);
+}
+
+ProfScope::~ProfScope() {
+  if (!start) return;
+  (void)hipEventRecord(stop, ctx->stream);
+  ctx->slots[slot].pending.emplace_back(start, stop);
+}
+
+int Scratch::reserve(size_t need) {
+  if (need <= bytes) return SMESH_OK;
+  if (ptr) SMESH_HIP(hipFree(ptr));
+  ptr = nullptr;
+  bytes = 0;
+  size_t want = need + need / 8 + 256;  // slack so that slowly growing images do not reallocate every call
+  SMESH_HIP(hipMalloc(&ptr, want));
+  bytes = want;
+  return SMESH_OK;
+}
+
+void Scratch::release() {
+  if (ptr) (void)hipFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+}  // namespace smesh
+
+using namespace smesh;
+
+extern "C" {
+
+const char* smesh_backend(void) { return "hip-gfx950"; }
+
+const char* smesh_last_error(void) { return g_err.c_str(); }
+
+int smesh_device_count(int* count) {
+  if (!count) return fail(SMESH_ERR_INVALID, "count is NULL");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  *count = n;
+  return SMESH_OK;
+}
+
+int smesh_synchronize(int device) {
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  SMESH_HIP(hipSetDevice(device));
+  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  return SMESH_OK;
+}
+
+int smesh_profile_enable(int device, int enabled) {
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  ctx->profiling = enabled != 0;
+  return SMESH_OK;
+}
+
+static int drain(DeviceCtx* ctx) {
+  SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto& ps : ctx->slots) {
+    for (auto& ev : ps.pending) {
+      float ms = 0.f;
+      if (hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+        ps.total_ms += ms;
+        ps.launches += 1;
+      }
+      ps.pool.push_back(ev);
+    }
+    ps.pending.clear();
+  }
+  return SMESH_OK;
+}
+
+int smesh_profile_read(int device, int slot, double* total_ms, uint64_t* launches) {
+  if (slot < 0 || slot >= SMESH_PROF_SLOTS) return fail(SMESH_ERR_INVALID, "bad profile slot");
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_TRY(drain(ctx));
+  if (total_ms) *total_ms = ctx->slots[slot].total_ms;
+  if (launches) *launches = ctx->slots[slot].launches;
+  return SMESH_OK;
+}
+
+int smesh_profile_reset(int device) {
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_TRY(drain(ctx));
+  for (auto& ps : ctx->slots) {
+    ps.total_ms = 0.0;
+    ps.launches = 0;
+  }
+  return SMESH_OK;
+}
+
+int smesh_device_malloc(int device, uint64_t bytes, void** out) {
+  if (!out) return fail(SMESH_ERR_INVALID, "out is NULL");
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  SMESH_HIP(hipSetDevice(device));
+  SMESH_HIP(hipMalloc(out, bytes ? bytes : 1));
+  return SMESH_OK;
+}
+
+int smesh_device_free(int device, void* ptr) {
+  if (!ptr) return SMESH_OK;
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  SMESH_HIP(hipSetDevice(device));
+  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  SMESH_HIP(hipFree(ptr));
+  return SMESH_OK;
+}
+
+int smesh_memcpy(void* dst, const void* src, uint64_t bytes, int dst_memkind, int src_memkind, int device) {
+  if (bytes == 0) return SMESH_OK;
+  if (!dst || !src) return fail(SMESH_ERR_INVALID, "NULL pointer");
+  if (dst_memkind == SMESH_MEM_HOST && src_memkind == SMESH_MEM_HOST) {
+    memmove(dst, src, bytes);
+    return SMESH_OK;
+  }
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(device));
+  hipMemcpyKind kind = dst_memkind == SMESH_MEM_HOST ? hipMemcpyDeviceToHost
+                       : (src_memkind == SMESH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice);
+  // ordered after everything already queued on the library stream
+  SMESH_HIP(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  return SMESH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,177 @@
+"""Device-resident arrays handed between render() and add().
+
+The reference returns DLPack capsules over CUDA memory from render() and accepts them (or numpy
+arrays, or framework tensors) in add() (/root/reference/python/semantic_meshes/include/Renderer.h:37-38,
+Common.h:5-30).  Here the hand-off object is a DeviceArray: a typed, strided view of HIP device
+memory that exposes `__cuda_array_interface__` (the protocol ROCm builds of torch/cupy consume)
+and converts to numpy on request.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+class DeviceArray:
+    """A (possibly strided) view of device memory owned by some handle of this library."""
+
+    def __init__(self, ptr, shape, dtype, device=0, strides=None, owner=None, on_release=None):
+        self.ptr = int(ptr)
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.device = int(device)
+        if strides is None:  # C-contiguous, in elements
+            strides, acc = [], 1
+            for s in reversed(self.shape):
+                strides.append(acc)
+                acc *= s
+            strides = tuple(reversed(strides))
+        self.strides = tuple(int(s) for s in strides)  # in ELEMENTS
+        self._owner = owner            # keeps the owning handle alive
+        self._on_release = on_release  # returns the buffer to its pool
+
+    def __del__(self):
+        cb, self._on_release = getattr(self, "_on_release", None), None
+        if cb is not None:
+            try:
+                cb(self.ptr)
+            except Exception:
+                pass
+
+    @property
+    def ndim(self):
+        return len(self.shape)
+
+    @property
+    def size(self):
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def nbytes(self):
+        return self.size * self.dtype.itemsize
+
+    @property
+    def __cuda_array_interface__(self):
+        return {
+            "shape": self.shape,
+            "typestr": self.dtype.str,
+            "data": (self.ptr, False),
+            "version": 2,
+            "strides": tuple(s * self.dtype.itemsize for s in self.strides),
+        }
+
+    def transpose(self, *axes):
+        """Stride permutation without a copy (callers transpose (H,W,C) network output to (W,H,C))."""
+        if len(axes) == 1 and hasattr(axes[0], "__len__"):
+            axes = tuple(axes[0])
+        if not axes:
+            axes = tuple(reversed(range(self.ndim)))
+        return DeviceArray(self.ptr, [self.shape[a] for a in axes], self.dtype, self.device,
+                           [self.strides[a] for a in axes], owner=self)
+
+    @property
+    def T(self):
+        return self.transpose()
+
+    def _is_contiguous(self):
+        acc = 1
+        for s, st in zip(reversed(self.shape), reversed(self.strides)):
+            if s != 1 and st != acc:
+                return False
+            acc *= s
+        return True
+
+    def numpy(self):
+        """Copy to a fresh host array (synchronises with the producing stream)."""
+        if not self._is_contiguous():
+            # copy the dense span, then re-stride on the host
+            span = 1 + sum((s - 1) * st for s, st in zip(self.shape, self.strides))
+            flat = np.empty(span, self.dtype)
+            _lib.check(_lib.lib().smesh_memcpy(flat.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.ptr),
+                                                flat.nbytes, _lib.MEM_HOST, _lib.MEM_DEVICE, self.device))
+            return np.lib.stride_tricks.as_strided(flat, self.shape, [st * self.dtype.itemsize for st in self.strides]).copy()
+        out = np.empty(self.shape, self.dtype)
+        if out.nbytes:
+            _lib.check(_lib.lib().smesh_memcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.ptr),
+                                                out.nbytes, _lib.MEM_HOST, _lib.MEM_DEVICE, self.device))
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        a = self.numpy()
+        return a if dtype is None else a.astype(dtype, copy=False)
+
+    def __repr__(self):
+        return "DeviceArray(shape=%s, dtype=%s, device=%d, ptr=0x%x)" % (self.shape, self.dtype, self.device, self.ptr)
+
+
+class DeviceBuffer:
+    """Raw HBM allocation (benchmark inputs that must be resident before timing starts)."""
+
+    def __init__(self, nbytes, device=0):
+        self.nbytes, self.device = int(nbytes), int(device)
+        p = ctypes.c_void_p()
+        _lib.check(_lib.lib().smesh_device_malloc(self.device, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            _lib.lib().smesh_device_free(self.device, ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def view(self, shape, dtype, offset_bytes=0):
+        return DeviceArray(self.ptr + offset_bytes, shape, dtype, self.device, owner=self)
+
+
+def to_device(array, device=0):
+    """Copy a host numpy array into a fresh device allocation; returns a DeviceArray owning it."""
+    a = np.ascontiguousarray(array)
+    buf = DeviceBuffer(max(a.nbytes, 1), device)
+    if a.nbytes:
+        _lib.check(_lib.lib().smesh_memcpy(ctypes.c_void_p(buf.ptr), a.ctypes.data_as(ctypes.c_void_p), a.nbytes,
+                                            _lib.MEM_DEVICE, _lib.MEM_HOST, device))
+    return buf.view(a.shape, a.dtype)
+
+
+def describe(obj, want_ndim, what):
+    """Normalise an add()/render() argument to (pointer, memkind, shape, dtype, element strides, keepalive).
+
+    Accepts what the reference's FromTensor accepts in practice: numpy arrays / array-likes
+    on the host, and device arrays via DeviceArray or `__cuda_array_interface__` (torch-ROCm, cupy).
+    """
+    if isinstance(obj, DeviceArray):
+        shape, dtype, strides, ptr, mem, keep = obj.shape, obj.dtype, obj.strides, obj.ptr, _lib.MEM_DEVICE, obj
+    elif hasattr(obj, "__cuda_array_interface__"):
+        cai = obj.__cuda_array_interface__
+        shape, dtype = tuple(cai["shape"]), np.dtype(cai["typestr"])
+        ptr = int(cai["data"][0])
+        bstr = cai.get("strides")
+        if bstr is None:
+            strides, acc = [], 1
+            for s in reversed(shape):
+                strides.append(acc)
+                acc *= s
+            strides = tuple(reversed(strides))
+        else:
+            if any(b % dtype.itemsize for b in bstr):
+                raise ValueError("%s: strides are not a multiple of the item size" % what)
+            strides = tuple(b // dtype.itemsize for b in bstr)
+        mem, keep = _lib.MEM_DEVICE, obj
+    else:
+        a = np.asarray(obj)
+        if a.ndim == want_ndim and a.size:
+            span = 1 + sum((s - 1) * abs(st) // a.itemsize for s, st in zip(a.shape, a.strides))
+            bad = any(st < 0 or st % a.itemsize for st in a.strides) or span > 2 * a.size
+            if bad or not a.flags.aligned:
+                a = np.ascontiguousarray(a)
+        shape, dtype = a.shape, a.dtype
+        strides = tuple(st // a.itemsize for st in a.strides)
+        ptr, mem, keep = a.ctypes.data, _lib.MEM_HOST, a
+    if len(shape) != want_ndim:
+        raise ValueError("%s must have rank %d, got shape %s" % (what, want_ndim, tuple(shape)))
+    if mem == _lib.MEM_DEVICE and any(st < 0 for st in strides):
+        raise ValueError("%s: negative strides are not supported for device arrays" % what)
+    return ptr, mem, tuple(shape), dtype, strides, keep

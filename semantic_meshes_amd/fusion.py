@@ -1,0 +1,146 @@
+"""`semantic_meshes.fusion.MeshAggregator`.
+
+Reference: /root/reference/python/semantic_meshes/src/Fusion.cu:120-150 (factory, defaults "sum", 0.5),
+include/Fusion.h:42-76 (add1/add2/reset/get), /root/reference/include/semantic_meshes/fusion/Mesh.h:65-132.
+The class count is a run-time value here (compile-time CLASSES_NUMS list in the reference).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .device import DeviceArray, describe
+
+_IDX_CODES = {np.dtype(np.uint32): _lib.IDX_U32, np.dtype(np.int32): _lib.IDX_I32,
+              np.dtype(np.uint64): _lib.IDX_U64, np.dtype(np.int64): _lib.IDX_I64}
+
+
+def _c64(vals):
+    return (ctypes.c_int64 * len(vals))(*vals)
+
+
+class _MeshAggregator:
+    def __init__(self, primitives, classes, kind, images_equal_weight, device):
+        self.primitives, self.classes = int(primitives), int(classes)
+        self.kind, self.images_equal_weight, self.device = kind, float(images_equal_weight), int(device)
+        if self.primitives < 0 or self.classes <= 0:
+            raise ValueError("primitives must be >= 0 and classes > 0")
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().smesh_aggregator_create(self.primitives, self.classes, _lib.AGG_KINDS[kind],
+                                                     self.images_equal_weight, self.device, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            try:
+                _lib.lib().smesh_aggregator_destroy(h)
+            except Exception:
+                pass
+
+    def add(self, primitive_image, probs_image, weights_image=None):
+        """Fuse one view: `primitive_image` (W,H) of uint32/int32/uint64/int64, `probs_image` (W,H,C) float32,
+        optional `weights_image` (W,H) float32; host numpy or device arrays, any non-negative strides."""
+        ip, imem, ishape, idt, istr, k0 = describe(primitive_image, 2, "primitive image")
+        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image")
+        if idt not in _IDX_CODES:
+            raise ValueError("primitive image dtype must be one of uint32/int32/uint64/int64, got %s" % idt)
+        if pdt != np.float32:
+            if pmem == _lib.MEM_HOST and pdt.kind == "f":
+                probs_image = np.asarray(probs_image, dtype=np.float32)
+                pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image")
+            else:
+                raise ValueError("probs image must be float32, got %s" % pdt)
+        wp, wmem, wstr, k2, wshape = None, _lib.MEM_HOST, None, None, None
+        if weights_image is not None:
+            wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image")
+            if wdt != np.float32:
+                if wmem == _lib.MEM_HOST and wdt.kind == "f":
+                    weights_image = np.asarray(weights_image, dtype=np.float32)
+                    wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image")
+                else:
+                    raise ValueError("weights image must be float32, got %s" % wdt)
+        if tuple(ishape) != tuple(pshape[:2]) or (wshape is not None and tuple(wshape) != tuple(ishape)):
+            # Mesh.h:68-74 std::invalid_argument
+            raise ValueError("Primitive image %s, probs image %s and weights image %s must have the same width and height"
+                             % (tuple(ishape), tuple(pshape[:2]), None if wshape is None else tuple(wshape)))
+        if pshape[2] != self.classes:
+            raise ValueError("probs image has %d classes, aggregator was built for %d" % (pshape[2], self.classes))
+        W, H = ishape
+        if W == 0 or H == 0:
+            return
+        _lib.check(_lib.lib().smesh_aggregator_add(
+            self._h, ctypes.c_void_p(ip), _IDX_CODES[idt], _c64(istr), imem,
+            ctypes.c_void_p(pp), _c64(pstr), pmem,
+            None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H))
+
+    def reset(self):
+        _lib.check(_lib.lib().smesh_aggregator_reset(self._h))
+
+    def get(self):
+        """Normalised per-primitive class distribution, fresh float32[P,C] numpy array (Fusion.h:72-76)."""
+        out = np.empty((self.primitives, self.classes), np.float32)
+        if out.size:
+            _lib.check(_lib.lib().smesh_aggregator_get(self._h, out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
+        return out
+
+    # ---- new functionality: raw accumulator access for the cross-GPU sum ----------
+    def get_raw(self):
+        out = np.empty((self.primitives, self.classes), np.float32)
+        if out.size:
+            _lib.check(_lib.lib().smesh_aggregator_get_raw(self._h, out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
+        return out
+
+    def set_raw(self, raw):
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        if raw.shape != (self.primitives, self.classes):
+            raise ValueError("raw accumulator must be float32[%d,%d]" % (self.primitives, self.classes))
+        if raw.size:
+            _lib.check(_lib.lib().smesh_aggregator_set_raw(self._h, raw.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
+
+    def raw_device_array(self):
+        """The un-normalised float32[P,C] accumulator in HBM (view, not a copy)."""
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        _lib.check(_lib.lib().smesh_aggregator_raw_pointer(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return DeviceArray(p.value, (self.primitives, self.classes), np.float32, self.device, owner=self)
+
+    def fuse_view(self, renderer, camera, probs_image, weights_image=None):
+        """render(camera) + add(indices, probs) in one call without the indices leaving the device."""
+        W, H = camera.resolution
+        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image")
+        if tuple(pshape) != (W, H, self.classes) or pdt != np.float32:
+            raise ValueError("probs image must be float32 (W,H,C) = %s" % ((W, H, self.classes),))
+        if pstr != (H * self.classes, self.classes, 1):
+            raise ValueError("fuse_view needs a contiguous (W,H,C) probs image")
+        wp = None
+        if weights_image is not None:
+            wp_, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image")
+            if tuple(wshape) != (W, H) or wdt != np.float32 or wstr != (H, 1) or wmem != pmem:
+                raise ValueError("weights image must be contiguous float32 (W,H) in the same memory as probs")
+            wp = ctypes.c_void_p(wp_)
+        _lib.check(_lib.lib().smesh_fuse_view(renderer._h, self._h, ctypes.byref(camera._pod), ctypes.c_void_p(pp), wp, pmem))
+
+
+class MeshAggregatorSum(_MeshAggregator):
+    pass
+
+
+class MeshAggregatorSummax(_MeshAggregator):
+    pass
+
+
+class MeshAggregatorMul(_MeshAggregator):
+    pass
+
+
+_CLASSES = {"Sum": MeshAggregatorSum, "Summax": MeshAggregatorSummax, "Mul": MeshAggregatorMul}
+
+
+def MeshAggregator(primitives, classes, aggregator="sum", images_equal_weight=0.5, device=0):
+    """`semantic_meshes.fusion.MeshAggregator(primitives, classes[, aggregator[, images_equal_weight]])`
+    (Fusion.cu:120-138,148-150): aggregator name is matched after capitalising its first letter."""
+    name = str(aggregator)
+    name = name[:1].upper() + name[1:]
+    if name not in _CLASSES:
+        raise ValueError("unknown aggregator %r (expected one of sum, summax, mul)" % (aggregator,))
+    return _CLASSES[name](primitives, classes, name, images_equal_weight, device)

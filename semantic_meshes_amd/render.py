@@ -1,0 +1,123 @@
+"""`semantic_meshes.render`: `triangles(mesh)` / `texels(mesh, cameras[, texels_per_pixel])`.
+
+Reference: /root/reference/python/semantic_meshes/src/Render.cu:4-24 (module), include/Renderer.h:25-43
+(`render(camera) -> (indices, depth)`), include/Ply.h:56-124 (factories).  The returned planes are
+device-resident `DeviceArray`s in the reference's (W,H) y-fastest layout and can be passed straight
+to `MeshAggregator.add` like the reference's DLPack capsules (python/scripts/colorize_cityscapes_mesh.py:65-67).
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .data import Camera
+from .device import DeviceArray
+
+
+def _mesh_arrays(mesh):
+    v = np.ascontiguousarray(getattr(mesh, "vertices"), dtype=np.float32)
+    f = np.ascontiguousarray(getattr(mesh, "faces"), dtype=np.int32)
+    if v.ndim != 2 or v.shape[1] != 3 or f.ndim != 2 or f.shape[1] != 3:
+        raise ValueError("mesh must provide vertices[V,3] and faces[F,3]")
+    return v, f
+
+
+class _Renderer:
+    """Common part of PlyRendererTriangles / PlyRendererTexels (Renderer.h:12-43)."""
+
+    def __init__(self, handle, device):
+        self._h = handle
+        self.device = device
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            try:
+                _lib.lib().smesh_renderer_destroy(h)
+            except Exception:
+                pass
+
+    def getPrimitivesNum(self):
+        n = ctypes.c_uint64()
+        _lib.check(_lib.lib().smesh_renderer_num_primitives(self._h, ctypes.byref(n)))
+        return int(n.value)
+
+    def render(self, camera):
+        """Rasterise the mesh for `camera`; returns `(primitive_indices, depth)`:
+        uint32 (W,H) with background 0xFFFFFFFF and float32 (W,H) with background +inf."""
+        if not isinstance(camera, Camera):
+            raise TypeError("render() expects a semantic_meshes data.Camera")
+        W, H = camera.resolution
+        pi, pd = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(_lib.lib().smesh_renderer_render_device(self._h, ctypes.byref(camera._pod), ctypes.byref(pi), ctypes.byref(pd)))
+        h = self._h
+
+        def rel_i(ptr, h=h):
+            if h.value:
+                _lib.lib().smesh_renderer_release_image(h, ctypes.c_void_p(ptr), None)
+
+        def rel_d(ptr, h=h):
+            if h.value:
+                _lib.lib().smesh_renderer_release_image(h, None, ctypes.c_void_p(ptr))
+
+        indices = DeviceArray(pi.value, (W, H), np.uint32, self.device, owner=self, on_release=rel_i)
+        depth = DeviceArray(pd.value, (W, H), np.float32, self.device, owner=self, on_release=rel_d)
+        return indices, depth
+
+    def render_numpy(self, camera):
+        """Host variant: one call, results copied into fresh numpy arrays."""
+        W, H = camera.resolution
+        idx = np.empty((W, H), np.uint32)
+        depth = np.empty((W, H), np.float32)
+        _lib.check(_lib.lib().smesh_renderer_render(self._h, ctypes.byref(camera._pod),
+                                                   idx.ctypes.data_as(ctypes.c_void_p), depth.ctypes.data_as(ctypes.c_void_p)))
+        return idx, depth
+
+
+class PlyRendererTriangles(_Renderer):
+    """Triangle primitives: id == ordinal of the face in the mesh (TriangleRenderer.h:41-44,57-60)."""
+
+    def __init__(self, mesh, device=0):
+        v, f = _mesh_arrays(mesh)
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().smesh_renderer_create_triangles(v.ctypes.data_as(ctypes.c_void_p), len(v),
+                                                             f.ctypes.data_as(ctypes.c_void_p), len(f), device, ctypes.byref(h)))
+        super().__init__(h, device)
+
+
+class PlyRendererTexels(_Renderer):
+    """Texel primitives (TexturedTriangleRenderer.h:87-182)."""
+
+    def __init__(self, mesh, cameras, texels_per_pixel=0.1, device=0):
+        v, f = _mesh_arrays(mesh)
+        cams = list(cameras.getCameras()) if hasattr(cameras, "getCameras") else list(cameras)
+        for c in cams:
+            if not isinstance(c, Camera):
+                raise TypeError("texels() expects a list of data.Camera")
+        pods = (_lib.CameraPOD * max(len(cams), 1))(*[c._pod for c in cams])
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().smesh_renderer_create_texels(v.ctypes.data_as(ctypes.c_void_p), len(v),
+                                                          f.ctypes.data_as(ctypes.c_void_p), len(f),
+                                                          ctypes.cast(pods, ctypes.c_void_p), len(cams),
+                                                          float(texels_per_pixel), device, ctypes.byref(h)))
+        super().__init__(h, device)
+        self._num_faces = len(f)
+
+    def texel_layout(self):
+        """(faces after the reference's vertex re-ordering, per-triangle resolution, first texel id)."""
+        F = self._num_faces
+        faces, res, first = np.empty((F, 3), np.int32), np.empty(F, np.uint32), np.empty(F, np.uint32)
+        _lib.check(_lib.lib().smesh_renderer_texel_layout(self._h, faces.ctypes.data_as(ctypes.c_void_p),
+                                                         res.ctypes.data_as(ctypes.c_void_p), first.ctypes.data_as(ctypes.c_void_p)))
+        return faces, res, first
+
+
+def triangles(mesh, device=0):
+    """`semantic_meshes.render.triangles(mesh)` (Render.cu:24)."""
+    return PlyRendererTriangles(mesh, device=device)
+
+
+def texels(mesh, cameras, texels_per_pixel=0.1, device=0):
+    """`semantic_meshes.render.texels(mesh, colmap|[cameras][, texels_per_pixel])` (Render.cu:20-23);
+    default texels_per_pixel 0.1 (TexturedTriangleRenderer.h:87)."""
+    return PlyRendererTexels(mesh, cameras, texels_per_pixel, device=device)

@@ -1,0 +1,250 @@
+"""GPU parity tests: HIP path (through the C ABI via ctypes) vs the CPU oracle on the same inputs.
+
+Bar (BASELINE.json north_star): primitive indices bit-exact, fused float32 distributions within 1e-5 relative.
+"""
+import numpy as np
+import pytest
+
+from helpers import BG, assert_fused_close, random_probs, small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _render_both(sm, oracle, mesh, cam):
+    r = sm.render.triangles(mesh)
+    idx, depth = r.render(cam)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    oidx, odepth = o.render(cam)
+    return np.asarray(idx), np.asarray(depth), oidx, odepth
+
+
+def test_backend_is_hip(sm):
+    from semantic_meshes_amd import _lib
+    assert _lib.lib().smesh_backend() == b"hip-gfx950"
+
+
+@pytest.mark.parametrize("view", [0, 1, 2])
+def test_render_small_scene_bit_exact(sm, oracle, view):
+    mesh, cams = small_scene()
+    idx, depth, oidx, odepth = _render_both(sm, oracle, mesh, cams[view])
+    assert idx.dtype == np.uint32 and idx.shape == cams[view].resolution
+    assert (idx != BG).mean() > 0.3
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(depth.view(np.uint32), odepth.view(np.uint32))
+
+
+def test_render_cfg1_bit_exact(sm, oracle):
+    from semantic_meshes_amd import synth
+    mesh, cams, _ = synth.scene("cfg1")
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    assert r.getPrimitivesNum() == len(mesh.faces) == 10000
+    for cam in cams:
+        idx, depth = r.render(cam)
+        oidx, odepth = o.render(cam)
+        np.testing.assert_array_equal(np.asarray(idx), oidx)
+        np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+
+
+def test_render_cfg2_full_size_bit_exact(sm, oracle):
+    """BASELINE cfg2: 1M triangles at 1920x1080 -- the oracle renders a view in ~0.2 s."""
+    from semantic_meshes_amd import synth
+    mesh, cams, _ = synth.scene("cfg2")
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    for k in (0, 66, 133):
+        idx, depth = r.render(cams[k])
+        oidx, odepth = o.render(cams[k])
+        idx = np.asarray(idx)
+        assert (idx != BG).mean() > 0.5
+        np.testing.assert_array_equal(idx, oidx)
+        np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+
+
+def test_render_is_deterministic(sm):
+    mesh, cams = small_scene(60, 30, 320, 240)
+    r = sm.render.triangles(mesh)
+    a = np.asarray(r.render(cams[0])[0])
+    for _ in range(3):
+        np.testing.assert_array_equal(np.asarray(r.render(cams[0])[0]), a)
+
+
+def test_render_empty_scene_is_background(sm):
+    # KA1: TriangleRenderer.h:75-78
+    mesh = sm.data.Mesh(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32))
+    from semantic_meshes_amd import synth
+    cam = synth.ring_camera(0, 1, 64, 48)
+    idx, depth = sm.render.triangles(mesh).render(cam)
+    assert (np.asarray(idx) == BG).all() and np.isposinf(np.asarray(depth)).all()
+
+
+def test_render_overlap_nearest_wins_and_big_triangles(sm, oracle):
+    # KA2/KA3: two large camera-facing triangles at different depths (cooperative big-triangle path)
+    from semantic_meshes_amd import synth
+    v = np.array([[-4, -3, 0], [4, -3, 0], [0, 4, 0], [-4, -3, 1], [4, -3, 1], [0, 4, 1]], np.float32)
+    f = np.array([[0, 1, 2], [3, 5, 4]], np.int32)
+    mesh = sm.data.Mesh(v, f)
+    R, t = synth.look_at((0.5, 0.2, 8.0), (0, 0, 0), up=(0, 1, 0))
+    cam = sm.data.Camera(R, t, np.array([200, 150]), np.array([160.0, 160.0]), np.array([100.0, 75.0]))
+    idx, depth, oidx, odepth = _render_both(sm, oracle, mesh, cam)
+    np.testing.assert_array_equal(idx, oidx)
+    np.testing.assert_array_equal(depth.view(np.uint32), odepth.view(np.uint32))
+    covered = idx[idx != BG]
+    assert covered.size > 2000 and set(np.unique(covered)) == {0, 1}
+    assert (idx[100, 75] == 1)  # the nearer triangle (z=1 is closer to the camera at z=8)
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("iew", [0.5, 0.0, 1.0])
+def test_fusion_small_matches_oracle(sm, oracle, kind, iew):
+    mesh, cams = small_scene()
+    C = 7
+    rng = np.random.default_rng(5)
+    P = len(mesh.faces)
+    r = sm.render.triangles(mesh)
+    agg = sm.fusion.MeshAggregator(primitives=P, classes=C, aggregator=kind, images_equal_weight=iew)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, iew)
+        for cam in cams:
+            idx, _ = r.render(cam)
+            probs = random_probs(rng, *cam.resolution, C)
+            if kind == "mul":
+                probs = np.maximum(probs, 1e-3).astype(np.float32)  # keep log p finite for a meaningful comparison
+            agg.add(idx, probs)
+            oagg.add(np.asarray(idx), probs)
+        got, want = agg.get(), oagg.get()
+    finally:
+        oracle.set_accum_double(False)
+    assert got.dtype == np.float32 and got.shape == (P, C)
+    assert_fused_close(got, want, rtol=1e-5 if kind != "mul" else 5e-5)
+    touched = want.sum(axis=1) > 0.5
+    assert touched.sum() > P // 4
+    np.testing.assert_allclose(got[touched].sum(axis=1), 1.0, rtol=1e-5)   # KA8
+    if kind != "mul":
+        assert (got[~touched] == 0).all()                                    # KA7
+
+
+@pytest.mark.parametrize("C", [1, 5, 19, 40, 64, 150, 256])
+def test_fusion_class_counts(sm, oracle, C):
+    rng = np.random.default_rng(C)
+    W, H, P = 96, 70, 500
+    idx = rng.integers(0, P + 40, size=(W, H)).astype(np.uint32)
+    idx[rng.random((W, H)) < 0.2] = BG
+    idx = np.sort(idx.reshape(-1)).reshape(W, H)  # long runs and short runs
+    idx[::7] = rng.integers(0, P, size=idx[::7].shape)
+    probs = random_probs(rng, W, H, C)
+    weights = rng.random((W, H), dtype=np.float32)
+    agg = sm.fusion.MeshAggregator(P, C)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C)
+        for _ in range(2):
+            agg.add(idx, probs, weights)
+            oagg.add(idx, probs, weights)
+        assert_fused_close(agg.get(), oagg.get())
+        assert_fused_close(agg.get_raw(), oagg.get_raw(), rtol=1e-5, atol=1e-7)
+    finally:
+        oracle.set_accum_double(False)
+
+
+def test_fusion_dtypes_strides_and_device_inputs(sm, oracle):
+    from semantic_meshes_amd.device import to_device
+    rng = np.random.default_rng(11)
+    W, H, C, P = 64, 48, 19, 300
+    idx = rng.integers(0, P, size=(W, H)).astype(np.int64)
+    idx[rng.random((W, H)) < 0.1] = -1                       # KA4: -1 of any int type is background
+    hwc = random_probs(rng, H, W, C)                          # network layout (H,W,C)
+    probs = hwc.transpose(1, 0, 2)                            # callers transpose without copying
+    want_agg = oracle.OracleAggregator(P, C)
+    want_agg.add(idx, np.ascontiguousarray(probs))
+    want = want_agg.get()
+    for dt in (np.int64, np.uint64, np.int32, np.uint32):
+        agg = sm.fusion.MeshAggregator(P, C)
+        agg.add(idx.astype(dt), probs)
+        assert_fused_close(agg.get(), want)
+    # device-resident inputs, transposed view on the device, Fortran-ordered index image
+    agg = sm.fusion.MeshAggregator(P, C)
+    d_hwc = to_device(hwc)
+    d_idx = to_device(np.ascontiguousarray(idx.astype(np.int32).T))   # stored (H,W)
+    agg.add(d_idx.transpose(1, 0), d_hwc.transpose(1, 0, 2))
+    assert_fused_close(agg.get(), want)
+
+
+def test_fusion_dont_care_pixels_still_counted(sm, oracle):
+    # KA5 (Mesh.h:90-93 counts every pixel; :98 filters later) and KA6 (iew = 1: each image weighs 1 per primitive)
+    W, H, C, P = 8, 8, 3, 2
+    idx = np.zeros((W, H), np.uint32)
+    probs = np.zeros((W, H, C), np.float32)
+    probs[:4, :, 0] = 1.0                                     # half of the pixels are don't-care (sum 0)
+    agg = sm.fusion.MeshAggregator(P, C, "sum", 1.0)
+    agg.add(idx, probs)
+    raw = agg.get_raw()
+    np.testing.assert_allclose(raw[0], [0.5, 0, 0], rtol=1e-6)  # 32 valid pixels * (1/64)
+    assert (raw[1] == 0).all()
+    oagg = oracle.OracleAggregator(P, C, "sum", 1.0)
+    oagg.add(idx, probs)
+    np.testing.assert_allclose(oagg.get_raw(), raw, rtol=1e-6)
+
+
+def test_fusion_reset_and_raw_roundtrip(sm):
+    rng = np.random.default_rng(3)
+    W, H, C, P = 32, 32, 5, 50
+    idx = rng.integers(0, P, size=(W, H)).astype(np.uint32)
+    probs = random_probs(rng, W, H, C, 0.0)
+    agg = sm.fusion.MeshAggregator(P, C)
+    agg.add(idx, probs)
+    raw = agg.get_raw()
+    first = agg.get()
+    agg.reset()
+    assert (agg.get_raw() == 0).all() and (agg.get() == 0).all()
+    agg.set_raw(raw)
+    np.testing.assert_array_equal(agg.get(), first)
+    # sharding equivalence on one GPU: sum of two half-jobs' raw buffers == the whole job
+    a1, a2 = sm.fusion.MeshAggregator(P, C), sm.fusion.MeshAggregator(P, C)
+    a1.add(idx, probs)
+    a2.add(idx[::-1].copy(), probs)
+    whole = sm.fusion.MeshAggregator(P, C)
+    whole.add(idx, probs)
+    whole.add(idx[::-1].copy(), probs)
+    a1.set_raw(a1.get_raw() + a2.get_raw())
+    assert_fused_close(a1.get(), whole.get())
+
+
+def test_fusion_errors(sm):
+    agg = sm.fusion.MeshAggregator(10, 4)
+    idx = np.zeros((8, 6), np.uint32)
+    with pytest.raises(ValueError):
+        agg.add(idx, np.zeros((8, 7, 4), np.float32))          # KA9: Mesh.h:68-74
+    with pytest.raises(ValueError):
+        agg.add(idx, np.zeros((8, 6, 5), np.float32))          # wrong class count
+    with pytest.raises(ValueError):
+        agg.add(idx.astype(np.float32), np.zeros((8, 6, 4), np.float32))
+    with pytest.raises(ValueError):
+        agg.add(idx, np.zeros((8, 6, 4), np.float32), np.zeros((6, 8), np.float32))
+    with pytest.raises(ValueError):
+        sm.fusion.MeshAggregator(10, 4, aggregator="median")
+
+
+def test_fuse_view_cfg2_full_size(sm, oracle):
+    """One full-size BASELINE cfg2 view through the fused entry point with probs generated in HBM;
+    the oracle consumes the very same bytes (downloaded)."""
+    from semantic_meshes_amd import synth
+    mesh, cams, C = synth.scene("cfg2")
+    P = len(mesh.faces)
+    r = sm.render.triangles(mesh)
+    agg = sm.fusion.MeshAggregator(P, C)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C)
+        for k in (3, 120):
+            W, H = cams[k].resolution
+            d_probs = synth.device_probs(W, H, C, synth.probs_seed(1, k), zero_fraction=0.05)
+            agg.fuse_view(r, cams[k], d_probs)
+            h_probs = np.asarray(d_probs)
+            np.testing.assert_array_equal(h_probs.reshape(-1, C), oracle.synth_probs(W * H, C, synth.probs_seed(1, k), 0.05))
+            oagg.add(o.render(cams[k])[0], h_probs)
+        assert_fused_close(agg.get(), oagg.get())
+    finally:
+        oracle.set_accum_double(False)
