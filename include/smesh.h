@@ -145,8 +145,11 @@ int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind);
  * New functionality: this is what is summed across GPUs before get(). */
 int smesh_aggregator_get_raw(smesh_aggregator_t* a, float* out, int memkind);
 int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind);
-/* Device pointer of the raw accumulator (for an in-place RCCL all-reduce); oracle: host pointer. */
+/* In-place access for the RCCL all-reduce: the accumulator as it lives in device memory, P rows of
+ * `row_stride` floats (row_stride >= C, padding is zero and stays zero under a sum), num_floats =
+ * P * row_stride.  Oracle: host pointer, row_stride == C. */
 int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* num_floats);
+int smesh_aggregator_row_stride(smesh_aggregator_t* a, uint32_t* row_stride);
 
 /* ---- fused view: render(camera) -> add(indices, probs) without leaving the device ----------- */
 /* One iteration of the loop at python/scripts/colorize_cityscapes_mesh.py:54-67. probs/weights as
@@ -155,14 +158,15 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
                     const float* probs, const float* weights, int memkind);
 
 /* ---- timing hooks (tracing) -------------------------------------------- */
-/* When enabled, the library brackets its dominant kernels with HIP events on its own stream.
+/* `slot_mask` is a bitmask of SMESH_PROF_* slots (bit s = slot s; 0 = off, 0xFF = all).
+ * For every enabled slot the library brackets the kernels with HIP events on its own stream.
  * smesh_profile_read returns accumulated device milliseconds and launch counts per slot. */
 #define SMESH_PROF_FUSE_SCATTER 0   /* the scatter-add fusion kernel          */
 #define SMESH_PROF_FUSE_HIST    1   /* per-view histogram (Mesh.h:90-93)       */
 #define SMESH_PROF_RASTER       2   /* all rasterizer kernels of one render    */
 #define SMESH_PROF_FINALIZE     3   /* get() normalisation                     */
 #define SMESH_PROF_SLOTS        8
-int smesh_profile_enable(int device, int enabled);
+int smesh_profile_enable(int device, int slot_mask);
 int smesh_profile_read(int device, int slot, double* total_ms, uint64_t* launches);
 int smesh_profile_reset(int device);
 

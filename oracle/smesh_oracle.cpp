@@ -533,6 +533,12 @@ int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* n)
   return SMESH_OK;
 }
 
+int smesh_aggregator_row_stride(smesh_aggregator_t* a, uint32_t* stride) {
+  if (!a || !stride) return fail(SMESH_ERR_INVALID, "bad argument");
+  *stride = a->C;
+  return SMESH_OK;
+}
+
 int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cam,
                     const float* probs, const float* weights, int memkind) {
   if (!r || !a || !cam || !probs) return fail(SMESH_ERR_INVALID, "NULL argument");

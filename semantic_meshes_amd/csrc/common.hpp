@@ -40,7 +40,7 @@ struct DeviceCtx {
   int device = -1;
   hipStream_t stream = nullptr;
   int num_cus = 256;
-  bool profiling = false;
+  unsigned profiling = 0;   // bit s set = bracket slot s with HIP events
   ProfSlot slots[SMESH_PROF_SLOTS];
   std::recursive_mutex mu;
 };

@@ -50,7 +50,7 @@ int get_ctx(int device, DeviceCtx** out) {
 }
 
 ProfScope::ProfScope(DeviceCtx* c, int s) : ctx(c), slot(s) {
-  if (!ctx->profiling) return;
+  if (!(ctx->profiling & (1u << slot))) return;
   ProfSlot& ps = ctx->slots[slot];
   if (!ps.pool.empty()) {
     start = ps.pool.back().first;
@@ -121,7 +121,7 @@ int smesh_profile_enable(int device, int enabled) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-  ctx->profiling = enabled != 0;
+  ctx->profiling = enabled < 0 ? 0xFFu : (unsigned)enabled;
   return SMESH_OK;
 }
 

@@ -1,28 +1,36 @@
 // fusion.hip -- MeshAggregator on MI355X (gfx950): per-view histogram, segmented scatter-add, finalize.
 //
 // Replaces the reference's host-side fusion (citations relative to /root/reference):
-//   include/semantic_meshes/fusion/Mesh.h:90-93   serial std::map histogram      -> k_hist
-//   include/semantic_meshes/fusion/Mesh.h:94-106  OpenMP loop + per-primitive mutex -> k_scatter_tile
-//   python/semantic_meshes/src/Fusion.cu:46-92    Summax / Sum / Mul aggregators  -> KIND template
-//   python/semantic_meshes/include/Fusion.h:26-40 TensorConstructor copy+cast      -> k_gather_* (only
+//   include/semantic_meshes/fusion/Mesh.h:90-93   serial std::map histogram        -> k_hist_strip
+//   include/semantic_meshes/fusion/Mesh.h:94-106  OpenMP loop + per-primitive mutex -> k_scatter_strip
+//   python/semantic_meshes/src/Fusion.cu:46-92    Summax / Sum / Mul aggregators    -> KIND template
+//   python/semantic_meshes/include/Fusion.h:26-40 TensorConstructor copy+cast       -> k_gather_* (only
 //                                                  when the caller's layout is not already contiguous)
-//   Fusion.h:79-104 + Fusion.cu:47-49,67-69,79-82 get() functor chain             -> k_finalize_tile
+//   Fusion.h:79-104 + Fusion.cu:47-49,67-69,79-82 get() functor chain               -> k_finalize_tile
 //
-// Data layout in HBM: accumulator float32[P][C] dense row-major (what get() returns and what the
-// cross-GPU all-reduce sums); per-view histogram uint32[P] kept zero between add() calls.
+// Data layout in HBM: accumulator float32[P][S] with the row stride S = C rounded up to 16 floats, so that
+// every primitive's row starts on a 64-byte boundary (C = 19 -> one 128-byte line per row); the padding
+// stays zero.  get()/get_raw() return dense [P][C].  Per-view histogram uint32[P], zero between add() calls.
 //
-// The scatter-add is HBM-bound (no MFMA): per view it must read 4*N (indices) + 4*N*C (probs) bytes
-// and read-modify-write 2*4*C*T accumulator bytes (T = distinct primitives touched).  Design:
-//   * one workgroup = one tile of TP consecutive pixels (images are y-fastest, so a tile is a run of
-//     pixels down a column); the tile's probs (TP*C floats, contiguous in memory) are streamed with
-//     16-byte coalesced loads into LDS,
-//   * a wave ballot over "index differs from the previous pixel" splits the tile into same-primitive
-//     runs (a triangle projects to vertically adjacent pixels); each run is reduced out of LDS by the
-//     lanes that own its (run, class) elements,
-//   * one global float atomic per (run, class), issued by consecutive lanes on consecutive addresses.
+// The scatter-add is HBM-bound (no MFMA): per view it must read 4*N (indices) + 4*N*C (probs) bytes and
+// read-modify-write 2*4*C*T accumulator bytes (T = distinct primitives touched).  Measured on MI355X
+// (tools/atomic_bench.hip, tools/flush_replay.hip): float atomics execute memory-side and cost
+// roughly 30 ps per request + 0.5 ps per byte, LDS float atomics are an order of magnitude too slow, and
+// workgroup barriers / dependent LDS round trips dominate a tile-per-workgroup design.  Hence:
+//   * one WAVE = one strip of 4 columns x 16 rows (images are y-fastest: 4 column segments of 16
+//     consecutive pixels); no workgroup barriers, every wave is independent,
+//   * the strip's probs (4 x 16*C contiguous floats) are streamed with 16-byte coalesced loads into LDS and
+//     read back one pixel row per lane; the don't-care test and the weight are applied in registers,
+//   * a wave ballot splits each column into same-primitive runs; a segmented suffix scan over the 16-lane
+//     rows folds each run into its head lane; runs of the same primitive in neighbouring columns are
+//     linked (mutual first match, 8-connectivity) into chains = groups,
+//   * lanes then own (group, class) elements, add up the <= 4 run totals of the chain out of LDS and issue
+//     ONE float atomic each: 19 consecutive lanes cover one 128-byte accumulator row = one request.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 using namespace smesh;
@@ -62,36 +70,6 @@ __global__ void k_gather_probs(const float* __restrict__ in, int64_t s0, int64_t
 }
 
 // ------------------------------------------------------------------------------------------------
-// F1: per-view histogram count[v] = #pixels with index v (Mesh.h:90-93).  Same-index runs inside a
-// wave are collapsed to one atomic by the run's first lane.
-// ------------------------------------------------------------------------------------------------
-__global__ void k_hist(const uint32_t* __restrict__ idx, uint32_t* __restrict__ count, uint64_t N, uint32_t P) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int lane = threadIdx.x & (kWave - 1);
-  const bool in = i < N;
-  const uint32_t v = in ? idx[i] : 0xFFFFFFFFu;
-  uint32_t prev = __shfl_up(v, 1);
-  const bool head = in && (lane == 0 || v != prev);
-  const unsigned long long heads = __ballot(head);
-  const unsigned long long active = __ballot(in);
-  if (head && v < P) {
-    // run length = distance to the next head (or to the end of the active lanes)
-    const unsigned long long later = lane == 63 ? 0ull : (heads >> (lane + 1));
-    const int nactive = __popcll(active);  // active lanes are a prefix of the wave
-    const int len = later ? (__ffsll((long long)later)) : (nactive - lane);
-    atomicAdd(&count[v], (uint32_t)len);
-  }
-}
-
-// Zero only the touched histogram entries (cheaper than a memset when P >> N).
-__global__ void k_hist_clear(const uint32_t* __restrict__ idx, uint32_t* __restrict__ count, uint64_t N, uint32_t P) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const uint32_t v = idx[i];
-  if (v < P) count[v] = 0u;
-}
-
-// ------------------------------------------------------------------------------------------------
 // aggregator input maps (Fusion.cu:51-56 Summax, :70-73 Sum, :83-87 Mul)
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
@@ -101,7 +79,7 @@ __device__ __forceinline__ float contribution(float p, float w) {
 }
 
 // Opaque to the optimiser: the value must sit in VGPRs here, so the load that produced it cannot be sunk
-// into a later conditional block (which would serialise the tile's loads one s_waitcnt at a time).
+// into a later conditional block (which would serialise the strip's loads one s_waitcnt at a time).
 __device__ __forceinline__ void pin(float4& v) {
   asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w));
 }
@@ -110,11 +88,20 @@ struct ScatterArgs {
   const uint32_t* idx;
   const float* probs;
   const float* weights;   // may be null
-  const uint32_t* count;  // null when images_equal_weight == 0 (weight does not depend on the histogram)
-  float* acc;
+  const float* pw;        // per-pixel weight image from k_pixel_weights; null = every weight is 1
+  uint32_t* count;        // per-view histogram; null when images_equal_weight == 0
+  float* acc;             // [P][S]
   uint64_t N;
   uint32_t P;
   uint32_t C;
+  uint32_t S;             // accumulator row stride in floats
+  uint32_t W, H;
+  uint32_t strips_y;      // strips per image column
+  uint32_t nstrips;
+  uint32_t strips_per_xcd;  // ceil(nstrips / 8)
+  uint32_t strips_per_wave; // scatter kernel: contiguous strips walked by one persistent wave
+  int vec_ok;             // every full strip's column segments start 16-byte aligned
+  int dbg;                // development ablation switches (SMESH_DBG): 2 = no global atomics
   float iew;
 };
 
@@ -128,142 +115,409 @@ __device__ __forceinline__ float pixel_weight(const ScatterArgs& a, uint32_t v, 
 }
 
 // ------------------------------------------------------------------------------------------------
-// F2: segmented scatter-add, one tile of TP pixels per workgroup.
+// Strip machinery shared by the histogram and the scatter-add.
+//
+// A strip is 4 columns x 16 rows = one wave; lane l owns pixel (cx = l / 16, ty = l % 16).  Consecutive
+// strip ids walk down an image column (their probs segments abut in memory); ids are dealt to the 8 XCDs
+// in contiguous ranges so that neighbouring strips share an L2.
 // ------------------------------------------------------------------------------------------------
-template <int CT, int KIND, int TP>
-__global__ __launch_bounds__(TP) void k_scatter_tile(ScatterArgs a) {
+constexpr int kSX = 4;
+constexpr int kTY = 16;
+constexpr int kNone = 255;
+
+struct StripGeom {
+  uint32_t x0, y0;
+  int nx, ny;
+  bool valid;
+};
+
+__device__ __forceinline__ StripGeom strip_geom(const ScatterArgs& a) {
+  StripGeom g;
+  // block b runs on XCD b % 8 (observed, MI355X_MICROARCH.md); only speed depends on it
+  const uint32_t b = blockIdx.x;
+  const uint32_t L = (b & 7u) * a.strips_per_xcd + (b >> 3);
+  g.valid = L < a.nstrips;
+  const uint32_t bx = L / a.strips_y, by = L - bx * a.strips_y;
+  g.x0 = bx * kSX;
+  g.y0 = by * kTY;
+  g.nx = g.valid ? min((int)(a.W - g.x0), kSX) : 0;
+  g.ny = g.valid ? min((int)(a.H - g.y0), kTY) : 0;
+  return g;
+}
+
+// Wave-private LDS bookkeeping (no workgroup barrier is ever needed: the workgroup IS one wave).
+struct StripLists {
+  uint32_t sv[kWave];      // primitive of pixel l (0xFFFFFFFF outside the image)
+  uint8_t shead[kWave];    // head lane of the run pixel l belongs to
+  uint8_t lmatch[kWave];   // head lane of the first same-primitive run in the column to the left (or kNone)
+  uint8_t rmatch[kWave];   // ... to the right
+  uint8_t child[kWave];    // head lane -> next run of the chain (mutual match), or kNone
+  uint8_t slen[kWave];     // head lane -> pixels in the run
+  uint8_t groot[kWave];    // group g -> head lane of the chain's first (leftmost) run
+};
+
+struct StripRuns {
+  bool head;       // this lane starts a run
+  int hl;          // head lane of my run
+  int len;         // pixels in my run (valid on head lanes)
+  bool root;       // head lane of the first run of a chain with a valid primitive
+  int G;           // groups in the strip
+};
+
+// Orders this wave's LDS writes before its later LDS reads (LDS executes a wave's instructions in order;
+// this only stops the compiler from reordering them).  No s_barrier: waves never wait for each other here.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Builds runs, links and groups from each lane's primitive id `v` (0xFFFFFFFF outside the image).
+__device__ __forceinline__ StripRuns build_strip(StripLists& L, uint32_t v, uint32_t P, int l) {
+  StripRuns r;
+  const int ty = l & (kTY - 1), cx = l / kTY;
+  // ---- runs: a pixel starts a run when it is the top of a column segment or differs from the pixel above
+  L.sv[l] = v;
+  const uint32_t prev = __shfl_up(v, 1);
+  r.head = (ty == 0) || (v != prev);
+  const unsigned long long heads = __ballot(r.head);
+  const unsigned long long upto = (2ull << l) - 1ull;   // bits 0..l (l = 63: wraps to all ones)
+  r.hl = 63 - __clzll((long long)(heads & upto));      // lane 0 is always a head
+  const unsigned long long later = heads & ~upto;
+  const int next = later ? (__ffsll((long long)later) - 1) : kWave;
+  r.len = next - l;
+  L.shead[l] = (uint8_t)r.hl;
+  L.slen[l] = (uint8_t)r.len;
+  wave_sync();
+  // ---- first same-primitive run in the neighbouring columns (8-connectivity)
+  const bool valid = v < P;
+  int lp = kNone, rc = kNone;
+  if (r.head && valid) {
+    const int lo = max(ty - 1, 0), hi = min(ty + r.len, kTY - 1);
+    if (cx < kSX - 1) {
+      const int q0 = (cx + 1) * kTY;
+      for (int y = lo; y <= hi; y++)
+        if (L.sv[q0 + y] == v) { rc = L.shead[q0 + y]; break; }
+    }
+    if (cx > 0) {
+      const int q0 = (cx - 1) * kTY;
+      for (int y = lo; y <= hi; y++)
+        if (L.sv[q0 + y] == v) { lp = L.shead[q0 + y]; break; }
+    }
+  }
+  L.lmatch[l] = (uint8_t)lp;
+  L.rmatch[l] = (uint8_t)rc;
+  wave_sync();
+  // ---- a link exists only when both runs chose each other, so chains never fork
+  int child = kNone;
+  r.root = false;
+  if (r.head && valid) {
+    if (rc != kNone && L.lmatch[rc] == l) child = rc;
+    r.root = !(lp != kNone && L.rmatch[lp] == l);
+  }
+  L.child[l] = (uint8_t)child;
+  const unsigned long long roots = __ballot(r.root);
+  r.G = __popcll(roots);
+  if (r.root) L.groot[__popcll(roots & ((1ull << l) - 1ull))] = (uint8_t)l;
+  wave_sync();
+  return r;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F1: per-view histogram count[v] = #pixels with index v (Mesh.h:90-93): one atomic per group.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWave) void k_hist_strip(ScatterArgs a) {
+  __shared__ StripLists L;
+  const StripGeom g = strip_geom(a);
+  if (!g.valid) return;
+  const int l = threadIdx.x;
+  const int cx = l / kTY, ty = l - cx * kTY;
+  const bool in = cx < g.nx && ty < g.ny;
+  const uint32_t v = in ? a.idx[(uint64_t)(g.x0 + cx) * a.H + g.y0 + ty] : 0xFFFFFFFFu;
+  const StripRuns r = build_strip(L, v, a.P, l);
+  if (r.root) {
+    uint32_t n = 0;
+    int q = l;
+    for (int hop = 0; hop < kSX && q != kNone; hop++) {
+      n += L.slen[q];
+      q = L.child[q];
+    }
+    if (!(a.dbg & 2)) atomicAdd(&a.count[v], n);
+  }
+}
+
+// Per-pixel weight image (Mesh.h:100-103) in pixel order: w = (iew / count[idx] + (1 - iew)) * weight.
+// Doing this gather in its own pass lets the scatter kernel prefetch a strip with independent loads only.
+__global__ void k_pixel_weights(ScatterArgs a, float* __restrict__ pw) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.N) return;
+  const uint32_t v = a.idx[i];
+  float w = 0.0f;
+  if (v < a.P) w = pixel_weight(a, v, a.weights ? a.weights[i] : 1.0f);
+  pw[i] = w;
+}
+
+// Zero only the touched histogram entries (cheaper than a memset when P >> N).
+__global__ void k_hist_clear(const uint32_t* __restrict__ idx, uint32_t* __restrict__ count, uint64_t N, uint32_t P) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const uint32_t v = idx[i];
+  if (v < P) count[v] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F2: segmented scatter-add (Mesh.h:94-106).  Persistent waves: each wave walks a contiguous range of
+// 4 x 16 strips.  The float atomics are acknowledged memory-side microseconds after they are issued, and
+// a wave that ends (or waits on a later load) right after issuing them holds its slot for that whole
+// drain -- measured, that made the atomics' time ADD to the streaming time instead of hiding under it.
+// So the loop is software-pipelined around the in-order vmcnt counter:
+//     park strip s (prefetched registers -> LDS) | issue loads for strip s+1 | compute strip s |
+//     wait for the s+1 loads (long since landed)  | issue the atomics of strip s, do not wait
+// Nothing issued after the atomics is waited on before the next iteration has done a full strip of
+// LDS/VALU work, so the drain overlaps compute.
+// ------------------------------------------------------------------------------------------------
+template <int CT>
+struct Chunk {  // classes held in registers at a time
+  static constexpr int value = (CT > 0 && CT <= 32) ? CT : 16;
+};
+
+template <int CT>
+struct PrefetchVecs {  // float4 registers holding the next strip's probs (0 = no register prefetch)
+  static constexpr int value = (CT > 0 && CT <= 40) ? (CT * 4 * kSX + kWave - 1) / kWave : 0;
+};
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void pin(f4& v) { asm volatile("" : "+v"(v)); }
+template <bool NT>
+__device__ __forceinline__ f4 load_stream(const f4* p) {
+  // NT: streamed-once data should not displace the accumulator rows from the memory-side cache
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(uint32_t& v) { asm volatile("" : "+v"(v)); }
+
+__device__ __forceinline__ StripGeom strip_at(const ScatterArgs& a, uint32_t s) {
+  StripGeom g;
+  g.valid = s < a.nstrips;
+  const uint32_t bx = s / a.strips_y, by = s - bx * a.strips_y;
+  g.x0 = bx * kSX;
+  g.y0 = by * kTY;
+  g.nx = g.valid ? min((int)(a.W - g.x0), kSX) : 0;
+  g.ny = g.valid ? min((int)(a.H - g.y0), kTY) : 0;
+  return g;
+}
+
+template <int CT, int KIND, bool NT>
+__global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
+  constexpr int CH = Chunk<CT>::value;
+  constexpr int KV = PrefetchVecs<CT>::value;
   const int C = CT > 0 ? CT : (int)a.C;
-  constexpr int NW = TP / kWave;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int pfloats = (TP * C + 3) & ~3;
-  float* sp = reinterpret_cast<float*>(smem);               // [TP*C] probs tile, flat copy of global
-  float* sw = sp + pfloats;                                 // [TP]   per-pixel weight (0 = skip)
-  uint32_t* sprim = reinterpret_cast<uint32_t*>(sw + TP);   // [TP]   primitive of run r
-  int* sstart = reinterpret_cast<int*>(sprim + TP);         // [TP+1] first pixel of run r
-  int* swave = sstart + TP + 1;                             // [NW]   heads per wave
-  uint16_t* samax = reinterpret_cast<uint16_t*>(swave + NW + 1);  // [TP] arg-max class (Summax only)
+  const int pfloats = (kWave * C + 3) & ~3;
+  float* sp = reinterpret_cast<float*>(smem);  // [64*C] probs strip: pixel l at sp[l*C ..)
+  StripLists& L = *reinterpret_cast<StripLists*>(smem + (size_t)pfloats * 4);
 
-  const int t = threadIdx.x;
-  const int lane = t & (kWave - 1), wave = t / kWave;
-  const uint64_t b0 = (uint64_t)blockIdx.x * TP;
-  const int npx = (int)((a.N - b0) < (uint64_t)TP ? (a.N - b0) : (uint64_t)TP);
-  const int nfl = npx * C;
-  const float* __restrict__ src = a.probs + b0 * (uint64_t)C;
+  // contiguous strip range of this wave; ranges are dealt to the XCDs in contiguous blocks
+  // (block b runs on XCD b % 8 -- observed, MI355X_MICROARCH.md; only speed depends on it)
+  const uint32_t b = blockIdx.x;
+  const uint32_t chunk = (b & 7u) * (gridDim.x >> 3) + (b >> 3);
+  const uint32_t s_begin = chunk * a.strips_per_wave;
+  const uint32_t s_end = min(s_begin + a.strips_per_wave, a.nstrips);
+  if (s_begin >= s_end) return;
 
-  // ---- stage 1: stream the tile's probs into LDS (16 B per lane, coalesced) -----------------
-  if (npx == TP) {
-    const float4* __restrict__ src4 = reinterpret_cast<const float4*>(src);
-    float4* sp4 = reinterpret_cast<float4*>(sp);
-    const int nvec = (TP * C) >> 2;  // TP is a multiple of 4
-    if constexpr (CT > 0) {
-      constexpr int KV = (CT + 3) / 4;  // vectors per thread
-      float4 r[KV];
+  const int l = threadIdx.x;
+  const int cx = l / kTY, ty = l - cx * kTY;
+  const int seg_vecs = 4 * C;           // float4 per column segment (16 pixels)
+  const int nvec = kSX * seg_vecs;
+  const f4* __restrict__ base4 = reinterpret_cast<const f4*>(a.probs);
+
+  auto is_fast = [&](const StripGeom& g) { return g.nx == kSX && g.ny == kTY && a.vec_ok; };
+  auto src_index = [&](const StripGeom& g, int q) -> uint64_t {
+    const int seg = q / seg_vecs;
+    const int within = q - seg * seg_vecs;
+    return (((uint64_t)(g.x0 + seg) * a.H + g.y0) * (uint64_t)C) / 4 + within;
+  };
+  // this lane's pixel, clamped into the image so that the per-pixel loads are unconditional
+  auto pixel_of = [&](const StripGeom& g) -> uint64_t {
+    return (uint64_t)(g.x0 + min(cx, g.nx - 1)) * a.H + g.y0 + min(ty, g.ny - 1);
+  };
+
+  // ---- prologue: load the first strip -----------------------------------------------------------
+  // All prefetch loads are unconditional and land directly in the loop-carried registers: a load inside
+  // a branch gets copied at the join, and that copy would wait for it (and for every older atomic).
+  f4 r[KV > 0 ? KV : 1];
+  {
+    const StripGeom g0 = strip_at(a, s_begin);
+    if constexpr (KV > 0) {
+      // a partial (edge) strip is parked with dword loads instead; prefetch a harmless in-bounds address
 #pragma unroll
       for (int k = 0; k < KV; k++) {
-        const int e = t + k * TP;
-        r[k] = src4[e < nvec ? e : nvec - 1];  // clamped, unconditional: all KV loads are in flight together
+        const int q = l + k * kWave;
+        r[k] = load_stream<NT>(base4 + (is_fast(g0) ? src_index(g0, q < nvec ? q : nvec - 1) : 0));
       }
+    }
+  }
+  uint32_t v_next = a.idx[pixel_of(strip_at(a, s_begin))];
+  float pw_next = a.pw ? a.pw[pixel_of(strip_at(a, s_begin))] : 1.0f;
+  // wait for the prologue loads here, so that inside the loop the only pending memory operations at the
+  // loop head are the previous strip's atomics (which no register depends on)
+  if constexpr (KV > 0) {
 #pragma unroll
-      for (int k = 0; k < KV; k++) pin(r[k]);  // keep the loads above the (conditional) LDS stores
+    for (int k = 0; k < KV; k++) pin(r[k]);
+  }
+  pin(v_next);
+  pin(pw_next);
+
+  for (uint32_t s = s_begin; s < s_end; s++) {
+    const StripGeom g = strip_at(a, s);
+    const uint32_t v_raw = v_next;
+    const float pw_raw = pw_next;
+
+    // ---- 1. park this strip's probs in LDS ------------------------------------------------------
+    if (KV > 0 && is_fast(g)) {
+      f4* sp4 = reinterpret_cast<f4*>(sp);
 #pragma unroll
-      for (int k = 0; k < KV; k++) {
-        const int e = t + k * TP;
-        if (e < nvec) sp4[e] = r[k];
+      for (int k = 0; k < (KV > 0 ? KV : 1); k++) {
+        const int q = l + k * kWave;
+        if (q < nvec) sp4[q] = r[k];
+      }
+    } else if (is_fast(g)) {
+      f4* sp4 = reinterpret_cast<f4*>(sp);
+      for (int base = 0; base < nvec; base += 8 * kWave) {
+        f4 t8[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int q = base + l + k * kWave;
+          t8[k] = load_stream<NT>(base4 + src_index(g, q < nvec ? q : nvec - 1));
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) pin(t8[k]);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int q = base + l + k * kWave;
+          if (q < nvec) sp4[q] = t8[k];
+        }
       }
     } else {
-      for (int base = 0; base < nvec; base += 4 * TP) {
-        float4 r[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int e = base + t + k * TP;
-          r[k] = src4[e < nvec ? e : nvec - 1];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) pin(r[k]);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int e = base + t + k * TP;
-          if (e < nvec) sp4[e] = r[k];
-        }
+      // edge strips / unaligned images: dword loads, zero fill outside the image
+      for (int q = l; q < kWave * C; q += kWave) {
+        const int px = q / C, c = q - px * C;
+        const int pcx = px / kTY, pty = px - pcx * kTY;
+        float val = 0.0f;
+        if (pcx < g.nx && pty < g.ny) val = a.probs[((uint64_t)(g.x0 + pcx) * a.H + g.y0 + pty) * C + c];
+        sp[q] = val;
       }
     }
-  } else {
-    for (int e = t; e < nfl; e += TP) sp[e] = src[e];
-  }
 
-  // ---- per-pixel scalars ---------------------------------------------------------------------
-  const bool in = t < npx;
-  const uint32_t v = in ? a.idx[b0 + t] : 0xFFFFFFFFu;
-  const float wt = (in && a.weights) ? a.weights[b0 + t] : 1.0f;
-  const bool prim_ok = in && v < a.P;                 // Mesh.h:95
-  float w = prim_ok ? pixel_weight(a, v, wt) : 0.0f;
-
-  // run heads: a pixel starts a run when its primitive differs from the previous pixel's
-  uint32_t prev = __shfl_up(v, 1);
-  if (lane == 0 && t > 0 && in) prev = a.idx[b0 + t - 1];
-  const bool head = in && (t == 0 || v != prev);
-  const unsigned long long heads = __ballot(head);
-  if (lane == 0) swave[wave] = __popcll(heads);
-  __syncthreads();
-
-  int run_base = 0, nruns = 0;
+    // ---- 2. issue the loads of the next strip (consumed one iteration later) --------------------
+    {
+      const StripGeom g1 = strip_at(a, min(s + 1, s_end - 1));
+      if constexpr (KV > 0) {
+        const bool f1 = is_fast(g1);
 #pragma unroll
-  for (int k = 0; k < NW; k++) {
-    const int c = swave[k];
-    if (k < wave) run_base += c;
-    nruns += c;
-  }
-  if (head) {
-    const int r = run_base + __popcll(heads & ((1ull << lane) - 1ull));
-    sstart[r] = t;
-    sprim[r] = v;
-  }
-  if (t == 0) sstart[nruns] = npx;
-
-  // ---- stage 2: don't-care test on the float32 sequential class sum (Mesh.h:98) ---------------
-  if (in) {
-    const float* row = sp + t * C;
-    float s = 0.0f;
-    float best = row[0];
-    int m = 0;
-    for (int c = 0; c < C; c++) {
-      const float p = row[c];
-      s = s + p;
-      if (KIND == SMESH_AGG_SUMMAX && p > best) { best = p; m = c; }  // first max (Fusion.cu:53)
-    }
-    if (!(s > 0.5f)) w = 0.0f;
-    if (KIND == SMESH_AGG_SUMMAX) samax[t] = (uint16_t)m;
-  }
-  sw[t] = w;
-  __syncthreads();
-
-  // ---- stage 3: each lane owns (run, class) elements; reduce the run out of LDS, one atomic ----
-  const int total = nruns * C;
-  for (int e = t; e < total; e += TP) {
-    const int r = e / C;
-    const int c = e - r * C;
-    const uint32_t prim = sprim[r];
-    if (prim >= a.P) continue;
-    const int j0 = sstart[r], j1 = sstart[r + 1];
-    float sum = 0.0f;
-    bool touched = false;
-    for (int j = j0; j < j1; j++) {
-      const float wj = sw[j];
-      if (wj != 0.0f) {
-        if (KIND == SMESH_AGG_SUMMAX) {
-          if ((int)samax[j] == c) { sum += sp[j * C + c] * wj; touched = true; }
-        } else {
-          sum += contribution<KIND>(sp[j * C + c], wj);
-          touched = true;
+        for (int k = 0; k < KV; k++) {
+          const int q = l + k * kWave;
+          r[k] = load_stream<NT>(base4 + (f1 ? src_index(g1, q < nvec ? q : nvec - 1) : 0));
         }
       }
+      v_next = a.idx[pixel_of(g1)];
+      pw_next = a.pw ? a.pw[pixel_of(g1)] : 1.0f;
     }
-    if (touched) unsafeAtomicAdd(&a.acc[(uint64_t)prim * C + c], sum);
+
+    // ---- 3. compute: runs, links, groups (LDS + VALU only) ---------------------------------------
+    const bool in = cx < g.nx && ty < g.ny;
+    const uint32_t v = in ? v_raw : 0xFFFFFFFFu;
+    float w = (in && v < a.P) ? pw_raw : 0.0f;          // Mesh.h:95,100-103 (k_pixel_weights)
+    const StripRuns rr = build_strip(L, v, a.P, l);     // wave syncs inside: the probs strip is complete in LDS
+
+    // don't-care test on the float32 sequential class sum (Mesh.h:98)
+    float* row = sp + l * C;
+    int amax = 0;
+    {
+      float sum = 0.0f;
+      float best = row[0];
+      for (int c = 0; c < C; c++) {
+        const float p = row[c];
+        sum = sum + p;
+        if (KIND == SMESH_AGG_SUMMAX && p > best) { best = p; amax = c; }  // first max (Fusion.cu:53)
+      }
+      if (!(sum > 0.5f)) w = 0.0f;
+    }
+
+    // contributions in registers, folded into the run's head lane by a segmented suffix scan over the
+    // 16-lane column (distance 1, 2, 4, 8), then parked in the head pixel's LDS row
+    const int hid = rr.hl + 1;  // 0 is reserved for "no lane"
+    bool same[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int d = 1 << k;
+      const int other = __shfl_down(hid, d, kTY);
+      same[k] = (ty + d < kTY) && (other == hid);
+    }
+    for (int c0 = 0; c0 < C; c0 += CH) {
+      float val[CH];
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        const int c = c0 + k;
+        float x = 0.0f;
+        if (c < C && w != 0.0f) {
+          const float p = row[c];
+          if (KIND == SMESH_AGG_SUMMAX) x = (c == amax) ? p * w : 0.0f;
+          else x = contribution<KIND>(p, w);
+        }
+        val[k] = x;
+      }
+#pragma unroll
+      for (int st = 0; st < 4; st++) {
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const float o = __shfl_down(val[k], 1 << st, kTY);
+          val[k] += same[st] ? o : 0.0f;
+        }
+      }
+      if (rr.head) {
+#pragma unroll
+        for (int k = 0; k < CH; k++)
+          if (c0 + k < C) row[c0 + k] = val[k];
+      }
+    }
+    wave_sync();
+
+    // ---- 4. the next strip's loads have had a whole compute phase to land: wait for them NOW, before
+    // the atomics go out, so that nothing younger than the atomics is ever waited on
+    if constexpr (KV > 0) {
+#pragma unroll
+      for (int k = 0; k < KV; k++) pin(r[k]);
+    }
+    pin(v_next);
+    pin(pw_next);
+
+    // ---- 5. lanes own (group, class) elements: add the chain's run totals, one global atomic each ----
+    const int total = rr.G * C;
+    for (int e = l; e < total; e += kWave) {
+      const int gi = e / C;
+      const int c = e - gi * C;
+      int q = L.groot[gi];
+      const uint32_t prim = L.sv[q];
+      float sum = 0.0f;
+      for (int hop = 0; hop < kSX && q != kNone; hop++) {
+        sum += sp[q * C + c];
+        q = L.child[q];
+      }
+      if (sum != 0.0f && !(a.dbg & 2)) {
+        float* dst = &a.acc[(uint64_t)prim * a.S + c];
+        if (a.dbg & 8) *dst = sum;                 // ablation: plain store
+        else if (a.dbg & 16) *dst = *dst + sum;    // ablation: plain read-modify-write
+        else unsafeAtomicAdd(dst, sum);
+      }
+    }
+    wave_sync();  // the next iteration overwrites the LDS strip
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Fallback for class counts whose tile does not fit LDS: per-pixel weights, then a flat scatter.
+// Fallback for class counts whose strip does not fit LDS: per-pixel weights, then a flat scatter.
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
 __global__ void k_pixel_weight(ScatterArgs a, float* __restrict__ wpix, uint32_t* __restrict__ amax) {
@@ -295,11 +549,12 @@ __global__ void k_scatter_flat(ScatterArgs a, const float* __restrict__ wpix, co
   const float w = wpix[i];
   if (w == 0.0f) return;
   if (KIND == SMESH_AGG_SUMMAX && amax[i] != c) return;
-  unsafeAtomicAdd(&a.acc[(uint64_t)a.idx[i] * a.C + c], contribution<KIND>(a.probs[e], w));
+  unsafeAtomicAdd(&a.acc[(uint64_t)a.idx[i] * a.S + c], contribution<KIND>(a.probs[e], w));
 }
 
 // ------------------------------------------------------------------------------------------------
 // get(): load -> [Mul: / max element] -> L1 normalise -> NaN/Inf -> 0   (Fusion.h:79-104)
+// Reads padded rows [P][S], writes dense [P][C].
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float nan_inf_to_zero(float v) { return (isnan(v) || isinf(v)) ? 0.0f : v; }
 
@@ -317,27 +572,23 @@ __device__ __forceinline__ void finalize_row(float* row, int C) {
 
 template <int KIND, int TP>
 __global__ __launch_bounds__(TP) void k_finalize_tile(const float* __restrict__ acc, float* __restrict__ out,
-                                                      uint64_t P, int C) {
+                                                      uint64_t P, int C, int S) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sp = reinterpret_cast<float*>(smem);
   const int t = threadIdx.x;
   const uint64_t r0 = (uint64_t)blockIdx.x * TP;
   const int nrows = (int)((P - r0) < (uint64_t)TP ? (P - r0) : (uint64_t)TP);
   const int nfl = nrows * C;
-  const float* __restrict__ src = acc + r0 * (uint64_t)C;
+  const float* __restrict__ src = acc + r0 * (uint64_t)S;
   float* __restrict__ dst = out + r0 * (uint64_t)C;
-  const bool vec = (nrows == TP);
-  if (vec) {
-    const float4* src4 = reinterpret_cast<const float4*>(src);
-    float4* sp4 = reinterpret_cast<float4*>(sp);
-    for (int e = t; e < (nfl >> 2); e += TP) sp4[e] = src4[e];
-  } else {
-    for (int e = t; e < nfl; e += TP) sp[e] = src[e];
+  for (int e = t; e < nfl; e += TP) {
+    const int rr = e / C, c = e - rr * C;
+    sp[e] = src[(uint64_t)rr * S + c];
   }
   __syncthreads();
   if (t < nrows) finalize_row<KIND>(sp + t * C, C);
   __syncthreads();
-  if (vec) {
+  if (nrows == TP && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
     const float4* sp4 = reinterpret_cast<const float4*>(sp);
     float4* dst4 = reinterpret_cast<float4*>(dst);
     for (int e = t; e < (nfl >> 2); e += TP) dst4[e] = sp4[e];
@@ -347,10 +598,10 @@ __global__ __launch_bounds__(TP) void k_finalize_tile(const float* __restrict__ 
 }
 
 template <int KIND>
-__global__ void k_finalize_rows(const float* __restrict__ acc, float* __restrict__ out, uint64_t P, int C) {
+__global__ void k_finalize_rows(const float* __restrict__ acc, float* __restrict__ out, uint64_t P, int C, int S) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  const float* src = acc + p * C;
+  const float* src = acc + p * S;
   float* dst = out + p * C;
   for (int c = 0; c < C; c++) dst[c] = src[c];
   finalize_row<KIND>(dst, C);
@@ -359,42 +610,76 @@ __global__ void k_finalize_rows(const float* __restrict__ acc, float* __restrict
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
+// Dense rows: padding rows to whole cache lines was measured SLOWER (tools/flush_replay.hip: memory-side
+// atomics cost per line touched, and dense neighbours share lines), so the stride is C.
+inline uint32_t row_stride(uint32_t C) { return C; }
+
+// the strip path keeps 64 pixel rows of C floats in LDS (<= 64 KiB without opting into more: C <= 250)
+
+inline size_t strip_lds_bytes(uint32_t C) {
+  const size_t pfloats = ((size_t)kWave * C + 3) & ~(size_t)3;
+  return pfloats * 4 + sizeof(StripLists) + 16;
+}
+
+inline bool strip_path(uint32_t C) { return strip_lds_bytes(C) <= 64 * 1024; }
+
+// rows per finalize tile
 inline int tile_pixels(uint32_t C) {
   if (C <= 48) return 256;
   if (C <= 100) return 128;
   if (C <= 220) return 64;
-  return 0;  // fallback path
+  return 0;
 }
 
-inline size_t tile_lds_bytes(int TP, uint32_t C) {
-  const size_t pfloats = ((size_t)TP * C + 3) & ~(size_t)3;
-  return pfloats * 4 + (size_t)TP * 4 /*sw*/ + (size_t)TP * 4 /*sprim*/ + (size_t)(TP + 1) * 4 /*sstart*/ +
-         (size_t)(TP / kWave + 1) * 4 /*swave*/ + (size_t)TP * 2 /*samax*/ + 16;
+void set_tiling(ScatterArgs& a) {
+  const uint32_t strips_x = (uint32_t)div_up(a.W, kSX);
+  a.strips_y = (uint32_t)div_up(a.H, kTY);
+  a.nstrips = strips_x * a.strips_y;
+  a.strips_per_xcd = (uint32_t)div_up(a.nstrips, 8);
+  a.strips_per_wave = 1;
+  // a full strip's column segment starts at float offset ((x0+seg)*H + y0)*C with y0 a multiple of 16:
+  // 16-byte aligned for every column iff H*C is a multiple of 4 and the base pointer is aligned
+  a.vec_ok = ((uint64_t)a.H * a.C) % 4 == 0 && (reinterpret_cast<uintptr_t>(a.probs) & 15) == 0;
 }
 
-template <int CT, int KIND>
-int launch_tile_tp(const ScatterArgs& a, int TP, hipStream_t st) {
-  const uint32_t grid = (uint32_t)div_up(a.N, TP);
-  const size_t lds = tile_lds_bytes(TP, a.C);
-  switch (TP) {
-    case 256: hipLaunchKernelGGL((k_scatter_tile<CT, KIND, 256>), dim3(grid), dim3(256), lds, st, a); break;
-    case 128: hipLaunchKernelGGL((k_scatter_tile<CT, KIND, 128>), dim3(grid), dim3(128), lds, st, a); break;
-    default:  hipLaunchKernelGGL((k_scatter_tile<CT, KIND, 64>), dim3(grid), dim3(64), lds, st, a); break;
+template <int KIND>
+int launch_strip(const ScatterArgs& a0, int num_cus, hipStream_t st) {
+  ScatterArgs a = a0;
+  const size_t lds = strip_lds_bytes(a.C);
+  // persistent waves: as many as the LDS lets a CU hold (at most 32), each walking a contiguous strip range
+  static const int env_wpc = getenv("SMESH_WAVES_PER_CU") ? atoi(getenv("SMESH_WAVES_PER_CU")) : 0;
+  int waves_per_cu = (int)std::min<size_t>(28, (160 * 1024) / lds);
+  if (env_wpc > 0) waves_per_cu = env_wpc;
+  if (waves_per_cu < 1) waves_per_cu = 1;
+  uint32_t waves = (uint32_t)num_cus * (uint32_t)waves_per_cu;
+  waves = (waves + 7u) & ~7u;
+  a.strips_per_wave = (uint32_t)div_up(a.nstrips, waves);
+  if (a.strips_per_wave < 1) a.strips_per_wave = 1;
+  waves = ((uint32_t)div_up(a.nstrips, a.strips_per_wave) + 7u) & ~7u;
+  const dim3 grid(waves), block(kWave);
+  // class counts of the benchmark configs get compile-time loops; everything else runs the same
+  // kernel with a run-time C (the reference needs a rebuild with -DCLASSES_NUMS for each count)
+  if (a.dbg & 32) {
+    switch (a.C) {
+      case 19: hipLaunchKernelGGL((k_scatter_strip<19, KIND, true>), grid, block, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_scatter_strip<0, KIND, true>), grid, block, lds, st, a); break;
+    }
+  } else {
+    switch (a.C) {
+      case 5:  hipLaunchKernelGGL((k_scatter_strip<5, KIND, false>), grid, block, lds, st, a); break;
+      case 19: hipLaunchKernelGGL((k_scatter_strip<19, KIND, false>), grid, block, lds, st, a); break;
+      case 40: hipLaunchKernelGGL((k_scatter_strip<40, KIND, false>), grid, block, lds, st, a); break;
+      default: hipLaunchKernelGGL((k_scatter_strip<0, KIND, false>), grid, block, lds, st, a); break;
+    }
   }
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
 
-template <int KIND>
-int launch_tile(const ScatterArgs& a, int TP, hipStream_t st) {
-  // class counts of the benchmark configs get compile-time loops; everything else runs the same
-  // kernel with a run-time C (the reference needs a rebuild with -DCLASSES_NUMS for each count)
-  switch (a.C) {
-    case 5:   return launch_tile_tp<5, KIND>(a, TP, st);
-    case 19:  return launch_tile_tp<19, KIND>(a, TP, st);
-    case 40:  return launch_tile_tp<40, KIND>(a, TP, st);
-    default:  return launch_tile_tp<0, KIND>(a, TP, st);
-  }
+int launch_hist(const ScatterArgs& a, hipStream_t st) {
+  hipLaunchKernelGGL(k_hist_strip, dim3(a.strips_per_xcd * 8), dim3(kWave), 0, st, a);
+  SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
 }
 
 }  // namespace
@@ -405,11 +690,13 @@ struct smesh_aggregator {
   uint32_t C = 0;
   int kind = 0;
   float iew = 0.5f;
-  float* acc = nullptr;       // float32[P*C]
+  uint32_t S = 0;             // accumulator row stride in floats (C rounded up to 16)
+  float* acc = nullptr;       // float32[P*S]
   uint32_t* count = nullptr;  // uint32[P], all zero between add() calls
   Scratch st_idx, st_probs, st_w;        // host->device staging
   Scratch nm_idx, nm_probs, nm_w;        // normalised (contiguous) copies
   Scratch fb_w, fb_amax;                 // fallback path scratch
+  Scratch pw;                            // per-pixel weight image of the current view
   Scratch out_tmp;                       // get(): normalised result before the D2H copy
   std::mutex mu;
 };
@@ -471,26 +758,36 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
     weights = static_cast<const float*>(a->nm_w.ptr);
   }
 
-  // ---- F1 histogram (skipped when the weight does not depend on it) -------------------------
+  ScatterArgs args;
+  args.idx = idx; args.probs = probs; args.weights = weights; args.pw = nullptr;
   const bool need_hist = a->iew != 0.0f;
+  args.count = need_hist ? a->count : nullptr;
+  args.acc = a->acc; args.N = N; args.P = (uint32_t)a->P; args.C = C; args.S = a->S; args.iew = a->iew;
+  args.W = (uint32_t)W; args.H = (uint32_t)H;
+  { const char* d = getenv("SMESH_DBG"); args.dbg = d ? atoi(d) : 0; }
+  set_tiling(args);
+
+  // ---- F1 histogram (skipped when the weight does not depend on it) -------------------------
   if (need_hist) {
     ProfScope prof(ctx, SMESH_PROF_FUSE_HIST);
-    hipLaunchKernelGGL(k_hist, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, idx, a->count, N, (uint32_t)a->P);
-    SMESH_HIP(hipGetLastError());
+    SMESH_TRY(launch_hist(args, st));
   }
 
   // ---- F2 scatter-add -------------------------------------------------------------------------
-  ScatterArgs args;
-  args.idx = idx; args.probs = probs; args.weights = weights;
-  args.count = need_hist ? a->count : nullptr;
-  args.acc = a->acc; args.N = N; args.P = (uint32_t)a->P; args.C = C; args.iew = a->iew;
-  const int TP = tile_pixels(C);
-  if (TP) {
+  if (strip_path(C)) {
+    args.pw = nullptr;
+    if (need_hist || weights) {
+      SMESH_TRY(a->pw.reserve(N * 4));
+      ProfScope prof(ctx, SMESH_PROF_FUSE_HIST);
+      hipLaunchKernelGGL(k_pixel_weights, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, args, static_cast<float*>(a->pw.ptr));
+      SMESH_HIP(hipGetLastError());
+      args.pw = static_cast<const float*>(a->pw.ptr);
+    }
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
     switch (a->kind) {
-      case SMESH_AGG_SUM:    SMESH_TRY(launch_tile<SMESH_AGG_SUM>(args, TP, st)); break;
-      case SMESH_AGG_SUMMAX: SMESH_TRY(launch_tile<SMESH_AGG_SUMMAX>(args, TP, st)); break;
-      default:               SMESH_TRY(launch_tile<SMESH_AGG_MUL>(args, TP, st)); break;
+      case SMESH_AGG_SUM:    SMESH_TRY(launch_strip<SMESH_AGG_SUM>(args, ctx->num_cus, st)); break;
+      case SMESH_AGG_SUMMAX: SMESH_TRY(launch_strip<SMESH_AGG_SUMMAX>(args, ctx->num_cus, st)); break;
+      default:               SMESH_TRY(launch_strip<SMESH_AGG_MUL>(args, ctx->num_cus, st)); break;
     }
   } else {
     SMESH_TRY(a->fb_w.reserve(N * 4));
@@ -566,8 +863,8 @@ int smesh_aggregator_create(uint64_t P, uint32_t C, int kind, float iew, int dev
   SMESH_HIP(hipSetDevice(device));
   auto* a = new (std::nothrow) smesh_aggregator();
   if (!a) return fail(SMESH_ERR_RUNTIME, "out of memory");
-  a->ctx = ctx; a->P = P; a->C = C; a->kind = kind; a->iew = iew;
-  const size_t acc_bytes = (size_t)P * C * 4;
+  a->ctx = ctx; a->P = P; a->C = C; a->S = row_stride(C); a->kind = kind; a->iew = iew;
+  const size_t acc_bytes = (size_t)P * a->S * 4;
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&a->acc), acc_bytes ? acc_bytes : 16);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&a->count), P ? P * 4 : 16);
   if (e == hipSuccess) e = hipMemsetAsync(a->acc, 0, acc_bytes, ctx->stream);   // Sum/Summax: 0; Mul: log 1 = 0
@@ -588,7 +885,7 @@ int smesh_aggregator_destroy(smesh_aggregator_t* a) {
   (void)hipStreamSynchronize(a->ctx->stream);
   (void)hipFree(a->acc);
   (void)hipFree(a->count);
-  for (Scratch* s : {&a->st_idx, &a->st_probs, &a->st_w, &a->nm_idx, &a->nm_probs, &a->nm_w, &a->fb_w, &a->fb_amax, &a->out_tmp})
+  for (Scratch* s : {&a->st_idx, &a->st_probs, &a->st_w, &a->nm_idx, &a->nm_probs, &a->nm_w, &a->fb_w, &a->fb_amax, &a->pw, &a->out_tmp})
     s->release();
   delete a;
   return SMESH_OK;
@@ -599,7 +896,7 @@ int smesh_aggregator_reset(smesh_aggregator_t* a) {
   std::lock_guard<std::mutex> g(a->mu);
   std::lock_guard<std::recursive_mutex> lock(a->ctx->mu);
   SMESH_HIP(hipSetDevice(a->ctx->device));
-  SMESH_HIP(hipMemsetAsync(a->acc, 0, (size_t)a->P * a->C * 4, a->ctx->stream));
+  SMESH_HIP(hipMemsetAsync(a->acc, 0, (size_t)a->P * a->S * 4, a->ctx->stream));
   return SMESH_OK;
 }
 
@@ -658,9 +955,9 @@ static int finalize_into(smesh_aggregator* a, float* d_out) {
     const dim3 g((uint32_t)div_up(a->P, TP));
 #define SMESH_FIN(K)                                                                                          \
     switch (TP) {                                                                                             \
-      case 256: hipLaunchKernelGGL((k_finalize_tile<K, 256>), g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C); break; \
-      case 128: hipLaunchKernelGGL((k_finalize_tile<K, 128>), g, dim3(128), lds, ctx->stream, a->acc, d_out, a->P, C); break; \
-      default:  hipLaunchKernelGGL((k_finalize_tile<K, 64>), g, dim3(64), lds, ctx->stream, a->acc, d_out, a->P, C); break;  \
+      case 256: hipLaunchKernelGGL((k_finalize_tile<K, 256>), g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break; \
+      case 128: hipLaunchKernelGGL((k_finalize_tile<K, 128>), g, dim3(128), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break; \
+      default:  hipLaunchKernelGGL((k_finalize_tile<K, 64>), g, dim3(64), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break;  \
     }
     switch (a->kind) {
       case SMESH_AGG_SUM: SMESH_FIN(SMESH_AGG_SUM); break;
@@ -671,9 +968,9 @@ static int finalize_into(smesh_aggregator* a, float* d_out) {
   } else {
     const dim3 g((uint32_t)div_up(a->P, 256)), b(256);
     switch (a->kind) {
-      case SMESH_AGG_SUM: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_SUM>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C); break;
-      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_SUMMAX>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C); break;
-      default: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_MUL>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C); break;
+      case SMESH_AGG_SUM: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_SUM>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break;
+      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_SUMMAX>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break;
+      default: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_MUL>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break;
     }
   }
   SMESH_HIP(hipGetLastError());
@@ -708,7 +1005,9 @@ int smesh_aggregator_get_raw(smesh_aggregator_t* a, float* out, int memkind) {
   SMESH_HIP(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)a->P * a->C * 4;
   if (!bytes) return SMESH_OK;
-  SMESH_HIP(hipMemcpyAsync(out, a->acc, bytes, memkind == SMESH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+  // padded rows [P][S] -> dense [P][C]
+  SMESH_HIP(hipMemcpy2DAsync(out, (size_t)a->C * 4, a->acc, (size_t)a->S * 4, (size_t)a->C * 4, a->P,
+                             memkind == SMESH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
   return SMESH_OK;
 }
@@ -721,7 +1020,9 @@ int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind
   SMESH_HIP(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)a->P * a->C * 4;
   if (!bytes) return SMESH_OK;
-  SMESH_HIP(hipMemcpyAsync(a->acc, in, bytes, memkind == SMESH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+  // dense [P][C] -> padded rows [P][S]; the padding stays zero
+  SMESH_HIP(hipMemcpy2DAsync(a->acc, (size_t)a->S * 4, in, (size_t)a->C * 4, (size_t)a->C * 4, a->P,
+                             memkind == SMESH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
   return SMESH_OK;
 }
@@ -732,7 +1033,13 @@ int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* n)
   SMESH_HIP(hipSetDevice(a->ctx->device));
   SMESH_HIP(hipStreamSynchronize(a->ctx->stream));
   *ptr = a->acc;
-  if (n) *n = a->P * a->C;
+  if (n) *n = a->P * a->S;
+  return SMESH_OK;
+}
+
+int smesh_aggregator_row_stride(smesh_aggregator_t* a, uint32_t* stride) {
+  if (!a || !stride) return fail(SMESH_ERR_INVALID, "NULL argument");
+  *stride = a->S;
   return SMESH_OK;
 }
 

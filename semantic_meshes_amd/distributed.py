@@ -1,0 +1,67 @@
+"""Data-parallel fusion over the GPUs of one node (new functionality).
+
+Views are independent and every aggregator is a sum in some domain (Sum/Summax: weighted sums, Mul:
+log-domain sums; /root/reference/python/semantic_meshes/src/Fusion.cu:46-92), so the path shards with no
+data-path collective: each rank fuses its own views into a private accumulator and ONE sum all-reduce of
+the raw float32[P, row_stride] buffer precedes get().  One process per GPU, `torch.distributed`
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" on CPU-only test machines) is used as plumbing only.
+"""
+import numpy as np
+
+
+def shard_views(num_views, rank, world_size, contiguous=True):
+    """Indices of the views rank `rank` fuses.  `contiguous` gives each rank one block (BASELINE cfg3:
+    200 views per GPU); otherwise views are dealt round-robin (view k -> rank k % world_size)."""
+    if world_size <= 0 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    if not contiguous:
+        return list(range(rank, num_views, world_size))
+    base, extra = divmod(num_views, world_size)
+    start = rank * base + min(rank, extra)
+    return list(range(start, start + base + (1 if rank < extra else 0)))
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def allreduce_raw(aggregator, group=None):
+    """Sum the un-normalised accumulators of all ranks in place; afterwards every rank's get() returns the
+    fusion of ALL views.  Works for any object with get_raw()/set_raw(); a HIP aggregator under the nccl
+    backend is reduced in place in HBM (no host round trip)."""
+    dist = _dist()
+    import os
+    if not dist.is_available() or not dist.is_initialized():
+        return aggregator
+    if dist.get_world_size(group) == 1 and not os.environ.get("SMESH_FORCE_ALLREDUCE"):
+        return aggregator
+    import torch
+    backend = dist.get_backend(group)
+    if backend == "nccl" and hasattr(aggregator, "raw_device_array"):
+        flat = aggregator.raw_device_array(padded=True)         # float32[P * row_stride] view of HBM
+        t = torch.as_tensor(flat, device="cuda:%d" % flat.device)  # zero-copy via __cuda_array_interface__
+        if t.data_ptr() != flat.ptr:
+            raise RuntimeError("torch copied the accumulator instead of aliasing it")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        torch.cuda.synchronize(flat.device)
+        return aggregator
+    raw = np.ascontiguousarray(aggregator.get_raw(), dtype=np.float32)
+    t = torch.from_numpy(raw)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    aggregator.set_raw(raw)
+    return aggregator
+
+
+def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None, contiguous=True):
+    """Fuse this rank's share of `cameras` and all-reduce.  `probs_of_view(k)` returns the (W,H,C)
+    class-probability image of view k (host or device)."""
+    dist = _dist()
+    if dist.is_available() and dist.is_initialized():
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    else:
+        rank, world = 0, 1
+    for k in shard_views(len(cameras), rank, world, contiguous):
+        idx, _ = renderer.render(cameras[k])
+        aggregator.add(idx, probs_of_view(k))
+    return allreduce_raw(aggregator, group)

@@ -98,11 +98,17 @@ class _MeshAggregator:
         if raw.size:
             _lib.check(_lib.lib().smesh_aggregator_set_raw(self._h, raw.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
 
-    def raw_device_array(self):
-        """The un-normalised float32[P,C] accumulator in HBM (view, not a copy)."""
-        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+    def raw_device_array(self, padded=False):
+        """The un-normalised accumulator in HBM (a view, not a copy).  Rows are padded to `row_stride`
+        floats in device memory: by default a strided (P,C) view is returned; `padded=True` gives the flat
+        float32[P*row_stride] buffer (padding is zero), which is what an in-place all-reduce sums."""
+        p, n, s = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32()
         _lib.check(_lib.lib().smesh_aggregator_raw_pointer(self._h, ctypes.byref(p), ctypes.byref(n)))
-        return DeviceArray(p.value, (self.primitives, self.classes), np.float32, self.device, owner=self)
+        _lib.check(_lib.lib().smesh_aggregator_row_stride(self._h, ctypes.byref(s)))
+        if padded:
+            return DeviceArray(p.value, (int(n.value),), np.float32, self.device, owner=self)
+        return DeviceArray(p.value, (self.primitives, self.classes), np.float32, self.device,
+                           strides=(int(s.value), 1), owner=self)
 
     def fuse_view(self, renderer, camera, probs_image, weights_image=None):
         """render(camera) + add(indices, probs) in one call without the indices leaving the device."""

@@ -81,7 +81,7 @@ def test_render_empty_scene_is_background(sm):
 def test_render_overlap_nearest_wins_and_big_triangles(sm, oracle):
     # KA2/KA3: two large camera-facing triangles at different depths (cooperative big-triangle path)
     from semantic_meshes_amd import synth
-    v = np.array([[-4, -3, 0], [4, -3, 0], [0, 4, 0], [-4, -3, 1], [4, -3, 1], [0, 4, 1]], np.float32)
+    v = np.array([[-4, -3, 0], [4, -3, 0], [0, 4, 0], [-2, -3, 1], [6, -3, 1], [2, 4, 1]], np.float32)
     f = np.array([[0, 1, 2], [3, 5, 4]], np.int32)
     mesh = sm.data.Mesh(v, f)
     R, t = synth.look_at((0.5, 0.2, 8.0), (0, 0, 0), up=(0, 1, 0))
@@ -91,7 +91,10 @@ def test_render_overlap_nearest_wins_and_big_triangles(sm, oracle):
     np.testing.assert_array_equal(depth.view(np.uint32), odepth.view(np.uint32))
     covered = idx[idx != BG]
     assert covered.size > 2000 and set(np.unique(covered)) == {0, 1}
-    assert (idx[100, 75] == 1)  # the nearer triangle (z=1 is closer to the camera at z=8)
+    both = (oidx == 1).sum()
+    assert both > 1000 and (oidx == 0).sum() > 1000
+    # where the two overlap the nearer one (world z = 1, camera at z = 8) wins: KA3
+    assert idx[110, 80] == 1 and np.isclose(depth[110, 80], 7.0, atol=0.2)
 
 
 @pytest.mark.parametrize("kind", ["sum", "summax", "mul"])

@@ -32,7 +32,7 @@ def main():
     _lib.synchronize(0)
     for mode in ("plain", "profiled"):
         _lib.check(_lib.lib().smesh_profile_reset(0))
-        _lib.check(_lib.lib().smesh_profile_enable(0, 1 if mode == "profiled" else 0))
+        _lib.check(_lib.lib().smesh_profile_enable(0, 0xFF if mode == "profiled" else 0))
         t0 = time.perf_counter()
         for k in range(views):
             agg.fuse_view(r, cams[k % len(cams)], bufs[k % nbuf])
