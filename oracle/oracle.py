@@ -115,9 +115,12 @@ class OracleRenderer:
         self.is_texels = cameras is not None
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().smesh_renderer_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().smesh_renderer_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:  # interpreter shutdown
+            pass
 
     def getPrimitivesNum(self):
         n = ctypes.c_uint64()
@@ -155,9 +158,12 @@ class OracleAggregator:
                                              ctypes.c_float(images_equal_weight), 0, ctypes.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None) and self._h.value:
-            lib().smesh_aggregator_destroy(self._h)
-            self._h = ctypes.c_void_p()
+        try:
+            if getattr(self, "_h", None) and self._h.value:
+                lib().smesh_aggregator_destroy(self._h)
+                self._h = ctypes.c_void_p()
+        except Exception:  # interpreter shutdown
+            pass
 
     def add(self, idx, probs, weights=None):
         idx = np.asarray(idx)

@@ -251,3 +251,93 @@ def test_fuse_view_cfg2_full_size(sm, oracle):
         assert_fused_close(agg.get(), oagg.get())
     finally:
         oracle.set_accum_double(False)
+
+
+def test_golden_fixtures_on_gpu(sm):
+    """The committed oracle fixtures (tests/golden/, generated by make_golden.py) against the HIP path."""
+    import os
+    from semantic_meshes_amd import synth
+    from oracle import oracle as o
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = np.load(os.path.join(gdir, "cfg1_render.npz"))
+    want_fuse = np.load(os.path.join(gdir, "cfg1_fuse.npz"))
+    mesh = sm.data.Mesh(g["vertices"], g["faces"])
+    r = sm.render.triangles(mesh)
+    aggs = {k: sm.fusion.MeshAggregator(10000, 5, k, 0.5) for k in ("sum", "summax", "mul")}
+    for k in range(4):
+        cam = sm.data.Camera(g["cam%d_R" % k], g["cam%d_t" % k], g["cam%d_res" % k], g["cam%d_f" % k], g["cam%d_c" % k])
+        idx, depth = r.render(cam)
+        want = np.repeat(g["idx%d_vals" % k], g["idx%d_lens" % k]).reshape(cam.resolution)
+        np.testing.assert_array_equal(np.asarray(idx), want)
+        assert np.bitwise_xor.reduce(np.asarray(depth).view(np.uint32).reshape(-1)) == g["depth%d_xor" % k]
+        W, H = cam.resolution
+        probs = o.synth_probs(W * H, 5, synth.probs_seed(7, k), 0.05).reshape(W, H, 5)
+        for a in aggs.values():
+            a.add(idx, probs)
+    for kind, a in aggs.items():
+        # the fixture was accumulated in float32 like the reference; tolerance covers the summation order
+        assert_fused_close(a.get(), want_fuse[kind], rtol=2e-5 if kind != "mul" else 2e-4, atol=1e-6)
+
+
+def test_texel_renderer_matches_oracle(sm, oracle):
+    mesh, cams = small_scene(24, 12, 200, 150, views=4)
+    r = sm.render.texels(mesh, cams, 0.4)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces, cams, 0.4)
+    faces, res, first = r.texel_layout()
+    ofaces, ores, ofirst = o.texel_layout()
+    np.testing.assert_array_equal(faces, ofaces)                     # vertex re-ordering (TexturedTriangleRenderer.h:129-146)
+    np.testing.assert_array_equal(res, ores)
+    np.testing.assert_array_equal(first, ofirst)
+    assert r.getPrimitivesNum() == o.getPrimitivesNum() == int((res.astype(np.int64) * (res + 1) // 2).sum())   # KA10
+    assert r.getPrimitivesNum() > len(mesh.faces)
+    for cam in cams:
+        idx, depth = r.render(cam)
+        oidx, odepth = o.render(cam)
+        np.testing.assert_array_equal(np.asarray(idx), oidx)
+        np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+    # texel primitives through the aggregator
+    P, C = r.getPrimitivesNum(), 4
+    rng = np.random.default_rng(2)
+    agg, oagg = sm.fusion.MeshAggregator(P, C), oracle.OracleAggregator(P, C)
+    probs = random_probs(rng, *cams[0].resolution, C)
+    idx, _ = r.render(cams[0])
+    agg.add(idx, probs)
+    oagg.add(np.asarray(idx), probs)
+    assert_fused_close(agg.get(), oagg.get())
+
+
+def test_full_size_properties_cfg2(sm):
+    """Size-independent properties at BASELINE cfg2 scale: idempotent render, linear accumulation,
+    and shard-sum == whole job (the all-reduce identity) on one GPU."""
+    from semantic_meshes_amd import synth
+    mesh, cams, C = synth.scene("cfg2")
+    P = len(mesh.faces)
+    r = sm.render.triangles(mesh)
+    W, H = cams[0].resolution
+    views = [10, 90, 170]
+    probs = [synth.device_probs(W, H, C, synth.probs_seed(2, k), 0.02) for k in views]
+    idx_a = np.asarray(r.render(cams[10])[0])
+    assert np.array_equal(idx_a, np.asarray(r.render(cams[10])[0]))                      # idempotent
+    valid = idx_a[idx_a != BG]
+    assert valid.max() < P and len(np.unique(valid)) > 400_000
+    whole = sm.fusion.MeshAggregator(P, C)
+    parts = [sm.fusion.MeshAggregator(P, C) for _ in views]
+    for v, p, part in zip(views, probs, parts):
+        whole.fuse_view(r, cams[v], p)
+        part.fuse_view(r, cams[v], p)
+    raw_sum = sum(part.get_raw().astype(np.float64) for part in parts)
+    np.testing.assert_allclose(whole.get_raw(), raw_sum, rtol=1e-5, atol=1e-6)           # shard-sum identity
+    twice = sm.fusion.MeshAggregator(P, C)
+    twice.fuse_view(r, cams[10], probs[0])
+    twice.fuse_view(r, cams[10], probs[0])
+    np.testing.assert_allclose(twice.get_raw(), 2.0 * parts[0].get_raw(), rtol=1e-6)      # linearity
+    out = whole.get()
+    touched = out.sum(axis=1) > 0.5
+    np.testing.assert_allclose(out[touched].sum(axis=1), 1.0, rtol=1e-5)
+    assert (out[~touched] == 0).all() and touched.sum() > 600_000
+    # mass conservation: with iew = 0 every valid pixel contributes its whole probability vector
+    plain = sm.fusion.MeshAggregator(P, C, "sum", 0.0)
+    plain.fuse_view(r, cams[10], probs[0])
+    hp = np.asarray(probs[0]).reshape(-1, C)
+    keep = (idx_a.reshape(-1) != BG) & (hp.sum(axis=1) > 0.5)
+    np.testing.assert_allclose(plain.get_raw().astype(np.float64).sum(), hp[keep].astype(np.float64).sum(), rtol=1e-5)

@@ -1,0 +1,108 @@
+"""Host-side logic that needs no GPU: the Camera conversions, argument normalisation, PLY I/O, view sharding."""
+import os
+
+import numpy as np
+import pytest
+
+import semantic_meshes_amd as sm
+from semantic_meshes_amd import _lib, device, distributed, synth
+
+
+def test_camera_conversions_follow_the_reference_ctor():
+    # python/semantic_meshes/include/Camera.h:16-57: rotation/translation -> float32; focal/principal -> float32 -> double
+    R = np.eye(3, dtype=np.float64) * (1 + 1e-12)
+    cam = sm.data.Camera(R, np.array([0.1, 0.2, 0.3]), np.array([640, 480], np.int64), np.array([512.123456789, 500.0]),
+                         np.array([320.5, 240.25], np.float32))
+    assert cam.rotation.dtype == np.float32 and cam.translation.dtype == np.float32
+    assert cam.resolution == (640, 480) and cam.width == 640 and cam.height == 480
+    assert cam.focal_lengths.dtype == np.float64 and cam.focal_lengths[0] == np.float64(np.float32(512.123456789))
+    pod = cam._pod
+    assert pod.width == 640 and pod.height == 480 and pod.focal[0] == float(np.float32(512.123456789))
+    assert list(pod.rotation)[:3] == [1.0, 0.0, 0.0]
+
+
+@pytest.mark.parametrize("bad", [
+    dict(rotation=np.eye(4)), dict(translation=np.zeros(2)), dict(resolution=np.array([640.0, 480.0])),
+    dict(resolution=np.array([0, 480])), dict(focal_lengths=np.zeros(3)), dict(rotation=np.eye(3, dtype=np.complex64)),
+])
+def test_camera_rejects_bad_arguments(bad):
+    args = dict(rotation=np.eye(3), translation=np.zeros(3), resolution=np.array([640, 480]),
+                focal_lengths=np.array([500.0, 500.0]), principal_point=np.array([320.0, 240.0]))
+    args.update(bad)
+    with pytest.raises(ValueError):
+        sm.data.Camera(**args)
+
+
+def test_describe_host_arrays():
+    hwc = np.zeros((48, 64, 5), np.float32)
+    ptr, mem, shape, dt, strides, keep = device.describe(hwc.transpose(1, 0, 2), 3, "probs")
+    assert mem == _lib.MEM_HOST and shape == (64, 48, 5) and strides == (5, 64 * 5, 1) and ptr == hwc.ctypes.data
+    # negative strides and sparse slices are copied
+    ptr2, _, shape2, _, strides2, keep2 = device.describe(hwc[::-1].transpose(1, 0, 2), 3, "probs")
+    assert strides2 == (48 * 5, 5, 1) and keep2.flags.c_contiguous
+    _, _, _, _, strides3, keep3 = device.describe(hwc[::4].transpose(1, 0, 2), 3, "probs")
+    assert keep3.flags.c_contiguous
+    with pytest.raises(ValueError):
+        device.describe(np.zeros((4, 4)), 3, "probs")
+
+
+def test_describe_device_protocol():
+    class Fake:
+        __cuda_array_interface__ = {"shape": (8, 6), "typestr": "<u4", "data": (0x1000, False), "version": 2, "strides": (4, 32)}
+    ptr, mem, shape, dt, strides, keep = device.describe(Fake(), 2, "idx")
+    assert (ptr, mem, shape, dt, strides) == (0x1000, _lib.MEM_DEVICE, (8, 6), np.dtype(np.uint32), (1, 8))
+    d = device.DeviceArray(0x2000, (8, 6, 3), np.float32)
+    t = d.transpose(1, 0, 2)
+    assert t.shape == (6, 8, 3) and t.strides == (3, 18, 1) and t.ptr == d.ptr and d.strides == (18, 3, 1)
+    assert t.__cuda_array_interface__["strides"] == (12, 72, 4)
+
+
+def test_aggregator_factory_names():
+    # Fusion.cu:126: first letter capitalised, rest kept
+    for bad in ("median", "SUM", "sumMax", ""):
+        with pytest.raises((ValueError, RuntimeError)):
+            sm.fusion.MeshAggregator(4, 3, aggregator=bad)
+
+
+def test_ply_roundtrip(tmp_path):
+    mesh = synth.grid_mesh(3, 2)
+    colors = (np.arange(len(mesh.faces) * 3) % 251).astype(np.uint8).reshape(-1, 3)
+    for binary in (True, False):
+        p = os.path.join(tmp_path, "m_%d.ply" % binary)
+        sm.data._write_ply(p, mesh.vertices, mesh.faces, colors, binary)
+        back = sm.data.Ply(p)
+        np.testing.assert_array_equal(back.faces, mesh.faces)
+        np.testing.assert_allclose(back.vertices, mesh.vertices, rtol=1e-6)
+        assert back.faces.dtype == np.int32 and back.vertices.dtype == np.float32
+        with pytest.raises(ValueError):
+            back.save(os.path.join(tmp_path, "x.ply"), colors[:-1])
+        back.save(os.path.join(tmp_path, "y.ply"), colors)
+        again = sm.data.Ply(os.path.join(tmp_path, "y.ply"))
+        np.testing.assert_array_equal(again.faces, mesh.faces)
+
+
+def test_grid_mesh_sizes():
+    for name, tris in (("cfg1", 10_000), ("cfg2", 1_000_000)):
+        cfg = synth.CONFIGS[name]
+        assert 2 * cfg["a"] * cfg["b"] == tris
+    m = synth.grid_mesh(4, 3)
+    assert m.vertices.shape == (20, 3) and m.faces.shape == (24, 3) and m.faces.max() == 19
+
+
+def test_look_at_is_a_rigid_transform():
+    R, t = synth.look_at((3, 2, 5), (0, 0, 0))
+    np.testing.assert_allclose(R @ R.T, np.eye(3), atol=1e-6)
+    assert abs(np.linalg.det(R) - 1) < 1e-5
+    np.testing.assert_allclose(R @ np.array([3, 2, 5], np.float32) + t, 0, atol=1e-5)   # the eye maps to the origin
+    assert (R @ np.zeros(3) + t)[2] > 0                                                   # the target is in front (+z)
+
+
+def test_shard_views():
+    for n, w in ((200, 8), (7, 3), (5, 8), (0, 2)):
+        for contiguous in (True, False):
+            parts = [distributed.shard_views(n, r, w, contiguous) for r in range(w)]
+            assert sorted(sum(parts, [])) == list(range(n))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    assert distributed.shard_views(1600, 3, 8) == list(range(600, 800))
+    with pytest.raises(ValueError):
+        distributed.shard_views(10, 8, 8)

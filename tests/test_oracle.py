@@ -1,0 +1,215 @@
+"""CPU tests of the oracle: analytic known answers derived from the reference's in-tree lines
+ and the committed golden fixtures.  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import BG
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _camera(W=64, H=48, eye=(0, 0, 5.0), target=(0, 0, 0), f=60.0):
+    from semantic_meshes_amd import data, synth
+    R, t = synth.look_at(eye, target, up=(0, 1, 0))
+    return data.Camera(R, t, np.array([W, H]), np.array([f, f]), np.array([W / 2.0, H / 2.0]))
+
+
+def _unrle(vals, lens, shape):
+    return np.repeat(vals, lens).reshape(shape)
+
+
+# ---- rasteriser -----------------------------------------------------------------------------------
+def test_ka1_empty_scene_is_background(oracle):
+    r = oracle.OracleRenderer(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32))
+    idx, depth = r.render(_camera())
+    assert idx.shape == (64, 48) and idx.dtype == np.uint32
+    assert (idx == BG).all() and np.isposinf(depth).all()        # TriangleRenderer.h:75-78
+
+
+def test_ka2_single_triangle_layout_and_depth(oracle):
+    v = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0]], np.float32)
+    r = oracle.OracleRenderer(v, np.array([[0, 1, 2]], np.int32))
+    assert r.getPrimitivesNum() == 1
+    idx, depth = r.render(_camera())
+    cov = idx == 0
+    assert 200 < cov.sum() < 400 and ((idx == 0) | (idx == BG)).all()
+    np.testing.assert_allclose(depth[cov], 5.0, rtol=1e-6)       # camera-space z of the plane z=0 seen from z=5
+    assert np.isposinf(depth[~cov]).all()
+    # (W,H) layout, y fastest: the triangle is wider at the bottom... image y grows downwards (camera +y is down)
+    cols = np.flatnonzero(cov.any(axis=1))
+    rows = np.flatnonzero(cov.any(axis=0))
+    assert cols.min() >= 18 and cols.max() <= 45 and rows.min() >= 10 and rows.max() <= 37
+
+
+def test_ka3_nearest_wins_and_vertex_order_is_irrelevant(oracle):
+    v = np.array([[-1, -1, 0], [1, -1, 0], [0, 1, 0], [-1, -1, 1], [1, -1, 1], [0, 1, 1]], np.float32)
+    a = oracle.OracleRenderer(v, np.array([[0, 1, 2], [3, 4, 5]], np.int32)).render(_camera())[0]
+    b = oracle.OracleRenderer(v, np.array([[0, 2, 1], [5, 3, 4]], np.int32)).render(_camera())[0]   # no back-face culling
+    np.testing.assert_array_equal(a, b)
+    assert (a[32, 24] == 1)                                       # z=1 is nearer to the camera at z=5
+    assert set(np.unique(a)) <= {0, 1, int(BG)}
+
+
+def test_watertight_shared_edges_and_tie_break(oracle):
+    # a fan of triangles around a vertex that projects exactly onto a pixel centre, edges through pixel centres
+    from semantic_meshes_amd import data
+    R = np.eye(3, dtype=np.float32)
+    cam = data.Camera(R, np.zeros(3, np.float32), np.array([32, 32]), np.array([16.0, 16.0]), np.array([16.5, 16.5]))
+    c = np.array([0, 0, 1.0])
+    ring = [np.array([np.cos(a), np.sin(a), 1.0]) for a in np.linspace(0, 2 * np.pi, 9)[:-1]]
+    v = np.array([c] + ring, np.float32)
+    f = np.array([[0, 1 + i, 1 + (i + 1) % 8] for i in range(8)], np.int32)
+    idx, _ = oracle.OracleRenderer(v, f).render(cam)
+    inside = np.zeros((32, 32), bool)
+    for x in range(32):
+        for y in range(32):
+            px, py = (x + 0.5 - 16.5) / 16.0, (y + 0.5 - 16.5) / 16.0
+            inside[x, y] = px * px + py * py < 0.85 ** 2            # well inside the octagon
+    assert (idx[inside] != BG).all()                              # no cracks on shared edges
+    # two coincident triangles: equal depth everywhere -> the lower id wins (B-4)
+    v2 = np.array([[-1, -1, 1], [1, -1, 1], [0, 1, 1]], np.float32)
+    idx2, _ = oracle.OracleRenderer(v2, np.array([[0, 1, 2], [0, 1, 2]], np.int32)).render(cam)
+    assert set(np.unique(idx2)) == {0, int(BG)}
+
+
+def test_behind_camera_triangles_are_dropped(oracle):
+    v = np.array([[-1, -1, 6], [1, -1, 6], [0, 1, 4]], np.float32)    # one vertex in front, two behind the camera at z=5
+    idx, depth = oracle.OracleRenderer(v, np.array([[0, 1, 2]], np.int32)).render(_camera())
+    assert (idx == BG).all()
+
+
+def test_golden_cfg1_render(oracle):
+    from semantic_meshes_amd import data
+    g = np.load(os.path.join(GOLDEN, "cfg1_render.npz"))
+    r = oracle.OracleRenderer(g["vertices"], g["faces"])
+    assert r.getPrimitivesNum() == 10000
+    for k in range(4):
+        cam = data.Camera(g["cam%d_R" % k], g["cam%d_t" % k], g["cam%d_res" % k], g["cam%d_f" % k], g["cam%d_c" % k])
+        idx, depth = r.render(cam)
+        want = _unrle(g["idx%d_vals" % k], g["idx%d_lens" % k], tuple(g["cam%d_res" % k]))
+        np.testing.assert_array_equal(idx, want)
+        assert np.bitwise_xor.reduce(depth.view(np.uint32).reshape(-1)) == g["depth%d_xor" % k]
+
+
+def test_golden_scene_matches_generator():
+    """The committed fixture inputs are what synth.scene('cfg1') produces on this machine."""
+    from semantic_meshes_amd import synth
+    g = np.load(os.path.join(GOLDEN, "cfg1_render.npz"))
+    mesh, cams, C = synth.scene("cfg1")
+    np.testing.assert_array_equal(mesh.vertices, g["vertices"])
+    np.testing.assert_array_equal(mesh.faces, g["faces"])
+    assert C == 5 and len(cams) == 4
+
+
+# ---- fusion ---------------------------------------------------------------------------------------
+def _simple(oracle, kind="sum", iew=0.5, P=4, C=3):
+    return oracle.OracleAggregator(P, C, kind, iew)
+
+
+def test_ka4_out_of_range_indices_ignored(oracle):
+    agg = _simple(oracle)
+    probs = np.full((2, 2, 3), 1 / 3, np.float32)
+    agg.add(np.array([[4, 0xFFFFFFFF], [7, 100]], np.uint32), probs)
+    assert (agg.get_raw() == 0).all()
+    agg.add(np.array([[-1, -1], [-1, 2]], np.int64), probs)         # int64 -1 -> 0xFFFFFFFF (Fusion.h:45)
+    raw = agg.get_raw()
+    assert (raw[:2] == 0).all() and (raw[3] == 0).all() and (raw[2] > 0).all()
+
+
+def test_ka5_ka6_dont_care_counted_and_image_weights(oracle):
+    idx = np.zeros((4, 2), np.uint32)
+    probs = np.zeros((4, 2, 3), np.float32)
+    probs[:2, :, 1] = 1.0                                           # 4 valid pixels, 4 don't-care (sum 0 <= 0.5)
+    for iew, want in ((0.0, 4.0), (1.0, 0.5), (0.5, 2.25)):         # w = iew/8 + (1 - iew): count covers all 8 pixels
+        agg = _simple(oracle, iew=iew)
+        agg.add(idx, probs)
+        np.testing.assert_allclose(agg.get_raw()[0], [0, want, 0], rtol=1e-6)
+    agg = _simple(oracle, iew=0.0)
+    agg.add(idx, probs, np.full((4, 2), 0.25, np.float32))          # per-pixel weights multiply (Mesh.h:103)
+    np.testing.assert_allclose(agg.get_raw()[0], [0, 1.0, 0], rtol=1e-6)
+
+
+def test_ka7_ka8_get_normalises_and_zeroes_untouched(oracle):
+    agg = _simple(oracle)
+    probs = np.zeros((1, 2, 3), np.float32)
+    probs[0, 0] = [0.2, 0.5, 0.3]
+    probs[0, 1] = [0.6, 0.3, 0.1]
+    agg.add(np.array([[1, 1]], np.uint32), probs)
+    out = agg.get()
+    np.testing.assert_allclose(out[1], [0.4, 0.4, 0.2], rtol=1e-6)
+    np.testing.assert_allclose(out[1].sum(), 1.0, rtol=1e-6)
+    assert (out[[0, 2, 3]] == 0).all()                              # 0/0 -> NaN -> 0 (Fusion.h:79-95)
+    agg.reset()
+    assert (agg.get() == 0).all()
+
+
+def test_ka11_summax_only_argmax_contributes(oracle):
+    agg = _simple(oracle, "summax", 0.0)
+    probs = np.zeros((1, 3, 3), np.float32)
+    probs[0, 0] = [0.2, 0.5, 0.3]
+    probs[0, 1] = [0.6, 0.3, 0.1]
+    probs[0, 2] = [0.4, 0.4, 0.2]                                   # tie -> first max (Fusion.cu:53)
+    agg.add(np.zeros((1, 3), np.uint32), probs)
+    np.testing.assert_allclose(agg.get_raw()[0], [1.0, 0.5, 0.0], rtol=1e-6)
+
+
+def test_ka12_mul_aggregator(oracle):
+    agg = _simple(oracle, "mul", 0.0)
+    probs = np.zeros((1, 2, 3), np.float32)
+    probs[0, 0] = [0.2, 0.5, 0.3]
+    probs[0, 1] = [0.5, 0.25, 0.25]
+    agg.add(np.array([[2, 2]], np.uint32), probs)
+    out = agg.get()
+    want = np.array([0.1, 0.125, 0.075])
+    np.testing.assert_allclose(out[2], want / want.sum(), rtol=1e-5)
+    np.testing.assert_allclose(out[0], 1 / 3, rtol=1e-6)           # untouched Mul rows: exp(0) normalised (A.4)
+
+
+def test_ka9_shape_errors(oracle):
+    agg = _simple(oracle)
+    with pytest.raises(ValueError):
+        agg.add(np.zeros((2, 2), np.uint32), np.zeros((2, 3, 3), np.float32))
+    with pytest.raises(ValueError):
+        agg.add(np.zeros((2, 2), np.float32), np.zeros((2, 2, 3), np.float32))
+
+
+def test_golden_cfg1_fuse(oracle):
+    from semantic_meshes_amd import synth
+    g = np.load(os.path.join(GOLDEN, "cfg1_render.npz"))
+    want = np.load(os.path.join(GOLDEN, "cfg1_fuse.npz"))
+    for kind in ("sum", "summax", "mul"):
+        agg = oracle.OracleAggregator(10000, 5, kind, 0.5)
+        for k in range(4):
+            W, H = (int(v) for v in g["cam%d_res" % k])
+            idx = _unrle(g["idx%d_vals" % k], g["idx%d_lens" % k], (W, H))
+            agg.add(idx, oracle.synth_probs(W * H, 5, synth.probs_seed(7, k), 0.05).reshape(W, H, 5))
+        np.testing.assert_array_equal(agg.get(), want[kind])
+
+
+def test_strided_and_threaded_add_agree(oracle):
+    rng = np.random.default_rng(0)
+    W, H, C, P = 40, 30, 4, 60
+    idx = rng.integers(0, P, (W, H)).astype(np.int32)
+    hwc = rng.random((H, W, C), dtype=np.float32)
+    a1, a2 = oracle.OracleAggregator(P, C), oracle.OracleAggregator(P, C)
+    a1.add(idx, np.ascontiguousarray(hwc.transpose(1, 0, 2)))
+    oracle.set_threads(4)
+    try:
+        a2.add(idx, hwc.transpose(1, 0, 2))                         # strided view, OpenMP + per-primitive locks
+    finally:
+        oracle.set_threads(1)
+    np.testing.assert_allclose(a1.get(), a2.get(), rtol=1e-5, atol=1e-7)
+
+
+def test_texel_counts(oracle):
+    # KA10: r(r+1)/2 texels per triangle (TexturedTriangleRenderer.h:43-47)
+    v = np.array([[0.4, 0, 0], [0.5, 1, 0], [0.6, 0, 0]], np.float32)   # debug_render_texels.py:19-23
+    cam = _camera(200, 200, eye=(0.5, 0.5, 2.0), target=(0.5, 0.5, 0), f=180.0)
+    r = oracle.OracleRenderer(v, np.array([[0, 1, 2]], np.int32), [cam], 0.1)
+    faces, res, first = r.texel_layout()
+    assert r.getPrimitivesNum() == int(res[0]) * (int(res[0]) + 1) // 2 and first[0] == 0 and res[0] >= 2
+    idx, _ = r.render(cam)
+    seen = np.unique(idx[idx != BG])
+    assert seen.max() < r.getPrimitivesNum() and len(seen) >= r.getPrimitivesNum() // 2
