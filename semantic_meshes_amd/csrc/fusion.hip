@@ -154,6 +154,8 @@ struct StripLists {
   uint8_t child[kWave];    // head lane -> next run of the chain (mutual match), or kNone
   uint8_t slen[kWave];     // head lane -> pixels in the run
   uint8_t groot[kWave];    // group g -> head lane of the chain's first (leftmost) run
+  uint8_t amax[kWave];     // arg-max class of pixel l (Summax only)
+  float sw[kWave];         // weight of pixel l (0 = contributes nothing)
 };
 
 struct StripRuns {
@@ -161,6 +163,7 @@ struct StripRuns {
   int hl;          // head lane of my run
   int len;         // pixels in my run (valid on head lanes)
   bool root;       // head lane of the first run of a chain with a valid primitive
+  int gidx;        // root lanes: dense index of my group in [0, G)
   int G;           // groups in the strip
 };
 
@@ -218,7 +221,8 @@ __device__ __forceinline__ StripRuns build_strip(StripLists& L, uint32_t v, uint
   L.child[l] = (uint8_t)child;
   const unsigned long long roots = __ballot(r.root);
   r.G = __popcll(roots);
-  if (r.root) L.groot[__popcll(roots & ((1ull << l) - 1ull))] = (uint8_t)l;
+  r.gidx = __popcll(roots & ((1ull << l) - 1ull));
+  if (r.root) L.groot[r.gidx] = (uint8_t)l;
   wave_sync();
   return r;
 }
@@ -276,6 +280,17 @@ __global__ void k_hist_clear(const uint32_t* __restrict__ idx, uint32_t* __restr
 // Nothing issued after the atomics is waited on before the next iteration has done a full strip of
 // LDS/VALU work, so the drain overlaps compute.
 // ------------------------------------------------------------------------------------------------
+// Lane i reads lane i+D of its 16-lane DPP row (0 beyond the row): `row_shl:D`, bound_ctrl.  Columns of a
+// strip are exactly one DPP row, so "the pixel D rows further down" costs a VALU operand modifier, not LDS.
+template <int D>
+__device__ __forceinline__ float row_down(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x100 + D, 0xF, 0xF, true));
+}
+template <int D>
+__device__ __forceinline__ int row_down(int x) {
+  return __builtin_amdgcn_update_dpp(0, x, 0x100 + D, 0xF, 0xF, true);
+}
+
 template <int CT>
 struct Chunk {  // classes held in registers at a time
   static constexpr int value = (CT > 0 && CT <= 32) ? CT : 16;
@@ -308,15 +323,22 @@ __device__ __forceinline__ StripGeom strip_at(const ScatterArgs& a, uint32_t s) 
   return g;
 }
 
+// Flush order of one strip: its groups sorted by primitive id.
+struct FlushLists {
+  uint32_t sprim[kWave];    // primitive at sorted position s
+  uint8_t sorder[kWave];    // root lane (= LDS row holding the group total) at sorted position s
+};
+
 template <int CT, int KIND, bool NT>
 __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
-  constexpr int CH = Chunk<CT>::value;
   constexpr int KV = PrefetchVecs<CT>::value;
+  constexpr int CH = Chunk<CT>::value;
   const int C = CT > 0 ? CT : (int)a.C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int pfloats = (kWave * C + 3) & ~3;
   float* sp = reinterpret_cast<float*>(smem);  // [64*C] probs strip: pixel l at sp[l*C ..)
   StripLists& L = *reinterpret_cast<StripLists*>(smem + (size_t)pfloats * 4);
+  FlushLists& F = *reinterpret_cast<FlushLists*>(smem + (size_t)pfloats * 4 + ((sizeof(StripLists) + 15) & ~(size_t)15));
 
   // contiguous strip range of this wave; ranges are dealt to the XCDs in contiguous blocks
   // (block b runs on XCD b % 8 -- observed, MI355X_MICROARCH.md; only speed depends on it)
@@ -429,7 +451,9 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
     const bool in = cx < g.nx && ty < g.ny;
     const uint32_t v = in ? v_raw : 0xFFFFFFFFu;
     float w = (in && v < a.P) ? pw_raw : 0.0f;          // Mesh.h:95,100-103 (k_pixel_weights)
+    if (a.dbg & 256) { wave_sync(); if (sp[l] == 123.456f) a.acc[0] = 1.0f; continue; }   // ablation: stream + park only
     const StripRuns rr = build_strip(L, v, a.P, l);     // wave syncs inside: the probs strip is complete in LDS
+    if (a.dbg & 512) { if (rr.G == 99) a.acc[0] = 1.0f; continue; }                        // ablation: + runs/links/groups
 
     // don't-care test on the float32 sequential class sum (Mesh.h:98)
     float* row = sp + l * C;
@@ -445,16 +469,21 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
       if (!(sum > 0.5f)) w = 0.0f;
     }
 
-    // contributions in registers, folded into the run's head lane by a segmented suffix scan over the
-    // 16-lane column (distance 1, 2, 4, 8), then parked in the head pixel's LDS row
+    // ---- segmented reduction, all in registers -------------------------------------------------------
+    // (a) down the column: suffix scan over the 16-lane DPP row folds every run into its head lane;
+    // (b) along the chain: two pointer-doubling hops fold the <= 4 linked runs into the chain's root.
     const int hid = rr.hl + 1;  // 0 is reserved for "no lane"
-    bool same[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int d = 1 << k;
-      const int other = __shfl_down(hid, d, kTY);
-      same[k] = (ty + d < kTY) && (other == hid);
-    }
+    float samef[4];
+    samef[0] = (row_down<1>(hid) == hid) ? 1.0f : 0.0f;
+    samef[1] = (row_down<2>(hid) == hid) ? 1.0f : 0.0f;
+    samef[2] = (row_down<4>(hid) == hid) ? 1.0f : 0.0f;
+    samef[3] = (row_down<8>(hid) == hid) ? 1.0f : 0.0f;
+    const bool long_runs = __ballot(samef[2] != 0.0f) != 0ull;    // any run longer than 4 pixels in this strip?
+    const int child1 = rr.head ? (int)L.child[l] : kNone;
+    const bool has1 = child1 != kNone;
+    const int c2 = has1 ? (int)L.child[child1] : kNone;
+    const bool has2 = c2 != kNone;
+    const bool any1 = __ballot(has1) != 0ull, any2 = __ballot(has2) != 0ull;
     for (int c0 = 0; c0 < C; c0 += CH) {
       float val[CH];
 #pragma unroll
@@ -468,21 +497,43 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
         }
         val[k] = x;
       }
+      auto fold = [&](float mine, float other, float sf) -> float {
+        // Mul contributions can be -inf: select instead of multiplying by 0
+        if (KIND == SMESH_AGG_MUL) return mine + (sf != 0.0f ? other : 0.0f);
+        return fmaf(other, sf, mine);
+      };
 #pragma unroll
-      for (int st = 0; st < 4; st++) {
+      for (int k = 0; k < CH; k++) val[k] = fold(val[k], row_down<1>(val[k]), samef[0]);
+#pragma unroll
+      for (int k = 0; k < CH; k++) val[k] = fold(val[k], row_down<2>(val[k]), samef[1]);
+      if (long_runs) {
+#pragma unroll
+        for (int k = 0; k < CH; k++) val[k] = fold(val[k], row_down<4>(val[k]), samef[2]);
+#pragma unroll
+        for (int k = 0; k < CH; k++) val[k] = fold(val[k], row_down<8>(val[k]), samef[3]);
+      }
+      if (any1) {
+        // hop 1: every head adds its child's run total; hop 2: adds its grandchild's (which by then holds
+        // grandchild + great-grandchild), so chains of up to 4 runs end up in their root
 #pragma unroll
         for (int k = 0; k < CH; k++) {
-          const float o = __shfl_down(val[k], 1 << st, kTY);
-          val[k] += same[st] ? o : 0.0f;
+          const float o = __shfl(val[k], has1 ? child1 : l);
+          val[k] += has1 ? o : 0.0f;
+        }
+        if (any2) {
+#pragma unroll
+          for (int k = 0; k < CH; k++) {
+            const float o = __shfl(val[k], has2 ? c2 : l);
+            val[k] += has2 ? o : 0.0f;
+          }
         }
       }
-      if (rr.head) {
+      if (rr.root) {   // park the group total in the root pixel's own LDS row
 #pragma unroll
         for (int k = 0; k < CH; k++)
           if (c0 + k < C) row[c0 + k] = val[k];
       }
     }
-    wave_sync();
 
     // ---- 4. the next strip's loads have had a whole compute phase to land: wait for them NOW, before
     // the atomics go out, so that nothing younger than the atomics is ever waited on
@@ -493,23 +544,35 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
     pin(v_next);
     pin(pw_next);
 
-    // ---- 5. lanes own (group, class) elements: add the chain's run totals, one global atomic each ----
-    const int total = rr.G * C;
-    for (int e = l; e < total; e += kWave) {
-      const int gi = e / C;
-      const int c = e - gi * C;
-      int q = L.groot[gi];
-      const uint32_t prim = L.sv[q];
-      float sum = 0.0f;
-      for (int hop = 0; hop < kSX && q != kNone; hop++) {
-        sum += sp[q * C + c];
-        q = L.child[q];
+    // ---- 5. order the strip's groups by primitive id (bitonic network over the wave, key = prim << 6 | lane):
+    // neighbouring primitives then sit on neighbouring lanes and share cache lines in one atomic instruction
+    {
+      const bool sortable = a.P <= (1u << 26) && !(a.dbg & 1);
+      uint32_t key = rr.root ? ((sortable ? (v << 6) : ((uint32_t)rr.gidx << 6)) | (uint32_t)l) : 0xFFFFFFFFu;
+#pragma unroll
+      for (int k = 2; k <= kWave; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)key, j);
+          const bool up = (l & k) == 0;          // ascending block
+          const bool lower = (l & j) == 0;       // the lower lane of a pair keeps the smaller key when ascending
+          const uint32_t lo = min(key, other), hi = max(key, other);
+          key = (up == lower) ? lo : hi;
+        }
       }
-      if (sum != 0.0f && !(a.dbg & 2)) {
-        float* dst = &a.acc[(uint64_t)prim * a.S + c];
-        if (a.dbg & 8) *dst = sum;                 // ablation: plain store
-        else if (a.dbg & 16) *dst = *dst + sum;    // ablation: plain read-modify-write
-        else unsafeAtomicAdd(dst, sum);
+      if (l < rr.G) {
+        const int lane = (int)(key & 63u);
+        F.sorder[l] = (uint8_t)lane;
+        F.sprim[l] = L.sv[lane];
+      }
+      wave_sync();
+      // lanes own (sorted group, class) elements: ONE global atomic each, 19 consecutive lanes per 76-byte row
+      const int total = (a.dbg & 1024) ? 0 : rr.G * C;
+      for (int e = l; e < total; e += kWave) {
+        const int si = e / C;
+        const int c = e - si * C;
+        const float x = sp[(int)F.sorder[si] * C + c];
+        if (x != 0.0f && !(a.dbg & 2)) unsafeAtomicAdd(&a.acc[(uint64_t)F.sprim[si] * a.S + c], x);
       }
     }
     wave_sync();  // the next iteration overwrites the LDS strip
@@ -612,13 +675,16 @@ __global__ void k_finalize_rows(const float* __restrict__ acc, float* __restrict
 // ------------------------------------------------------------------------------------------------
 // Dense rows: padding rows to whole cache lines was measured SLOWER (tools/flush_replay.hip: memory-side
 // atomics cost per line touched, and dense neighbours share lines), so the stride is C.
-inline uint32_t row_stride(uint32_t C) { return C; }
+inline uint32_t row_stride(uint32_t C) {
+  static const int pad = getenv("SMESH_ROW_PAD") ? atoi(getenv("SMESH_ROW_PAD")) : 0;   // experiment knob
+  return pad > 1 ? (uint32_t)((C + pad - 1) / pad * pad) : C;
+}
 
 // the strip path keeps 64 pixel rows of C floats in LDS (<= 64 KiB without opting into more: C <= 250)
 
 inline size_t strip_lds_bytes(uint32_t C) {
   const size_t pfloats = ((size_t)kWave * C + 3) & ~(size_t)3;
-  return pfloats * 4 + sizeof(StripLists) + 16;
+  return pfloats * 4 + ((sizeof(StripLists) + 15) & ~(size_t)15) + sizeof(FlushLists) + 16;
 }
 
 inline bool strip_path(uint32_t C) { return strip_lds_bytes(C) <= 64 * 1024; }
@@ -648,7 +714,7 @@ int launch_strip(const ScatterArgs& a0, int num_cus, hipStream_t st) {
   const size_t lds = strip_lds_bytes(a.C);
   // persistent waves: as many as the LDS lets a CU hold (at most 32), each walking a contiguous strip range
   static const int env_wpc = getenv("SMESH_WAVES_PER_CU") ? atoi(getenv("SMESH_WAVES_PER_CU")) : 0;
-  int waves_per_cu = (int)std::min<size_t>(28, (160 * 1024) / lds);
+  int waves_per_cu = (int)std::min<size_t>(16, (160 * 1024) / lds);   // measured best on cfg2 (8 strips per wave)
   if (env_wpc > 0) waves_per_cu = env_wpc;
   if (waves_per_cu < 1) waves_per_cu = 1;
   uint32_t waves = (uint32_t)num_cus * (uint32_t)waves_per_cu;
