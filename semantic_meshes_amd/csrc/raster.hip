@@ -18,8 +18,10 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <new>
+#include <string>
 
 #pragma clang fp contract(off)
 
@@ -184,7 +186,15 @@ struct RasterArgs {
   uint32_t* big_count;
   uint32_t big_capacity;
   uint32_t small_limit;       // bbox area up to which a single lane walks the triangle
+  int dbg;                    // development ablation (SMESH_RDBG): 1 = no atomics, 2 = setup only
 };
+
+// Key image layout: 4 x 4 pixel blocks, one 128-byte line each, so that the fragments neighbouring triangles
+// emit (in any screen direction) fall into the same lines and their atomics travel as one request.
+__device__ __forceinline__ uint64_t key_index(uint32_t x, uint32_t y, uint32_t H) {
+  const uint32_t hb = (H + 3u) >> 2;
+  return ((uint64_t)(x >> 2) * hb + (y >> 2)) * 16u + ((x & 3u) << 2) + (y & 3u);
+}
 
 __device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t) {
   const int32_t i0 = a.faces[3 * f + 0], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
@@ -201,7 +211,8 @@ __device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri&
   uint32_t prim = (uint32_t)f;
   if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
   const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | prim;
-  atomicMin(&a.keys[(uint64_t)x * a.H + y], key);
+  if (a.dbg & 1) { if (key == 12345ull) a.keys[0] = key; return; }
+  atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
 }
 
 // One lane per triangle; triangles with a large bounding box are queued for k_raster_big.
@@ -216,6 +227,7 @@ __global__ void k_raster_small(RasterArgs a) {
     if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
     return;
   }
+  if (a.dbg & 2) { if (t.s == 12345.0) a.keys[0] = 0; return; }
   for (int x = t.x0; x <= t.x1; x++)
     for (int y = t.y0; y <= t.y1; y++) emit(a, f, t, x, y);
 }
@@ -242,13 +254,195 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a, uint32_t chunk
   (void)chunks_budget;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tiled path: triangles are binned to screen tiles of 16 columns x 32 rows (a tile column is one 128-byte
+// line of each output plane); one workgroup per tile resolves depth in LDS (4 KiB of 64-bit keys,
+// ds_min_u64) and writes both planes coalesced.  No global atomics per fragment, no clear, no split pass.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTW = 16, kTH = 32, kTilePixels = kTW * kTH;
+constexpr uint32_t kSkipCode = 0xFFFFFFFFu;
+constexpr int kMaxTilesPerTri = 16;   // triangles overlapping more tiles take the cooperative big-triangle path
+
+struct BinArgs {
+  RasterArgs r;
+  uint32_t tiles_x, tiles_y, ntiles;
+  uint32_t* tile_count;    // [ntiles]   triangles per tile; reused as the fill cursor
+  uint32_t* tile_offset;   // [ntiles+1] exclusive scan
+  uint32_t* tri_code;      // [F] packed tile range of each triangle (tx0:12 | ty0:12 | nx-1:4 | ny-1:4)
+  uint32_t* tile_list;     // [<= 16 F] triangle ids grouped by tile
+  uint32_t* idx_out;
+  float* depth_out;
+};
+
+__device__ __forceinline__ bool shade_key(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y,
+                                          unsigned long long* key) {
+  float z;
+  double b1, b2;
+  if (!shade(t, x, y, &z, a.tex_res ? &b1 : nullptr, &b2)) return false;
+  uint32_t prim = (uint32_t)f;
+  if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
+  *key = ((unsigned long long)__float_as_uint(z) << 32) | prim;
+  return true;
+}
+
+// Adds `active ? 1 : 0` to counter[tile] with one atomic per distinct tile in the wave; returns this
+// lane's slot (old value + rank among the lanes of the same tile).  Must be called by the whole wave.
+// The distinct tiles are found with ballots only (no memory traffic); then ALL leaders issue their atomics
+// in one instruction, so a wave pays one atomic round trip, not one per distinct tile.
+__device__ __forceinline__ uint32_t wave_claim(uint32_t* counter, uint32_t tile, bool active, bool want_slot) {
+  const int lane = threadIdx.x & 63;
+  unsigned long long todo = __ballot(active);
+  unsigned long long mine = 0ull;   // lanes holding the same tile as this lane
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const uint32_t t0 = (uint32_t)__shfl((int)tile, first);
+    const unsigned long long same = __ballot(active && tile == t0);
+    if (active && tile == t0) mine = same;
+    todo &= ~same;
+  }
+  if (!active) return 0u;
+  const int leader = __ffsll((long long)mine) - 1;
+  const uint32_t cnt = (uint32_t)__popcll(mine);
+  uint32_t base = 0;
+  if (lane == leader) {
+    if (want_slot) base = atomicAdd(&counter[tile], cnt);
+    else atomicAdd(&counter[tile], cnt);
+  }
+  if (!want_slot) return 0u;
+  base = (uint32_t)__shfl((int)base, leader);
+  return base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+}
+
+// Pass A: one lane per triangle: setup, cull, tile range; count triangles per tile.
+__global__ __launch_bounds__(256) void k_bin_count(BinArgs b) {
+  const RasterArgs& a = b.r;
+  const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t code = kSkipCode;
+  int tx0 = 0, ty0 = 0, nx = 0, n = 0;
+  Tri t;
+  if (f < a.F && load_tri(a, f, t)) {
+    tx0 = t.x0 / kTW; ty0 = t.y0 / kTH;
+    nx = t.x1 / kTW - tx0 + 1;
+    const int ny = t.y1 / kTH - ty0 + 1;
+    if (nx * ny > kMaxTilesPerTri) {
+      const uint32_t slot = atomicAdd(a.big_count, 1u);
+      if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
+    } else {
+      n = nx * ny;
+      code = ((uint32_t)tx0 << 20) | ((uint32_t)ty0 << 8) | ((uint32_t)(nx - 1) << 4) | (uint32_t)(ny - 1);
+    }
+  }
+  if (f < a.F) b.tri_code[f] = code;
+  for (int k = 0; __ballot(k < n) != 0ull; k++) {
+    const bool active = k < n;
+    const uint32_t tile = active ? (uint32_t)(tx0 + k % nx) * b.tiles_y + (uint32_t)(ty0 + k / nx) : 0u;
+    wave_claim(b.tile_count, tile, active, false);
+  }
+}
+
+// Exclusive scan of the tile counts (one workgroup); the counts become zeroed fill cursors.
+__global__ __launch_bounds__(1024) void k_bin_scan(BinArgs b) {
+  __shared__ uint32_t part[1024];
+  const int t = threadIdx.x;
+  const uint32_t per = (b.ntiles + 1023u) / 1024u;
+  const uint32_t lo = min((uint32_t)t * per, b.ntiles), hi = min(lo + per, b.ntiles);
+  uint32_t sum = 0;
+  for (uint32_t i = lo; i < hi; i++) sum += b.tile_count[i];
+  part[t] = sum;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const uint32_t v = t >= d ? part[t - d] : 0u;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  uint32_t run = part[t] - sum;   // exclusive prefix of this thread's chunk
+  for (uint32_t i = lo; i < hi; i++) {
+    const uint32_t c = b.tile_count[i];
+    b.tile_offset[i] = run;
+    b.tile_count[i] = 0;
+    run += c;
+  }
+  if (t == 1023) b.tile_offset[b.ntiles] = part[1023];
+}
+
+// Pass B: write each triangle id into the lists of the tiles it overlaps.
+__global__ __launch_bounds__(256) void k_bin_fill(BinArgs b) {
+  const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t code = f < b.r.F ? b.tri_code[f] : kSkipCode;
+  int tx0 = 0, ty0 = 0, nx = 1, n = 0;
+  if (code != kSkipCode) {
+    tx0 = (int)(code >> 20); ty0 = (int)((code >> 8) & 0xFFFu);
+    nx = (int)((code >> 4) & 0xFu) + 1;
+    n = nx * ((int)(code & 0xFu) + 1);
+  }
+  for (int k = 0; __ballot(k < n) != 0ull; k++) {
+    const bool active = k < n;
+    const uint32_t tile = active ? (uint32_t)(tx0 + k % nx) * b.tiles_y + (uint32_t)(ty0 + k / nx) : 0u;
+    const uint32_t slot = wave_claim(b.tile_count, tile, active, true);
+    if (active) b.tile_list[b.tile_offset[tile] + slot] = (uint32_t)f;
+  }
+}
+
+// One workgroup per tile: depth resolve in LDS, then both planes written once.
+__global__ __launch_bounds__(256) void k_raster_tile(BinArgs b) {
+  const RasterArgs& a = b.r;
+  __shared__ unsigned long long skeys[kTilePixels];
+  const int t = threadIdx.x;
+  const uint32_t tile = blockIdx.x;
+  const uint32_t tx = tile / b.tiles_y, ty = tile - tx * b.tiles_y;
+  const int x0 = (int)tx * kTW, y0 = (int)ty * kTH;
+  const uint32_t off = b.tile_offset[tile];
+  const uint32_t n = b.tile_offset[tile + 1] - off;
+  const bool merge_big = *a.big_count != 0u;   // big triangles went through global atomics into a.keys
+  for (int p = t; p < kTilePixels; p += 256) {
+    const int gx = x0 + (p >> 5), gy = y0 + (p & 31);
+    unsigned long long k = kBackgroundKey;
+    if (merge_big && gx < (int)a.W && gy < (int)a.H) {
+      const uint64_t g = key_index((uint32_t)gx, (uint32_t)gy, a.H);
+      k = a.keys[g];
+      a.keys[g] = kBackgroundKey;   // re-armed for the next render
+    }
+    skeys[p] = k;
+  }
+  __syncthreads();
+  for (uint32_t base = 0; base < n; base += 256) {
+    const uint32_t i = base + t;
+    if (i < n) {
+      const uint64_t f = b.tile_list[off + i];
+      Tri tr;
+      if (load_tri(a, f, tr)) {
+        const int xa = max(tr.x0, x0), xb = min(tr.x1, x0 + kTW - 1);
+        const int ya = max(tr.y0, y0), yb = min(tr.y1, y0 + kTH - 1);
+        for (int x = xa; x <= xb; x++)
+          for (int y = ya; y <= yb; y++) {
+            unsigned long long key;
+            if (shade_key(a, f, tr, x, y, &key)) atomicMin(&skeys[(x - x0) * kTH + (y - y0)], key);
+          }
+      }
+    }
+  }
+  __syncthreads();
+  for (int p = t; p < kTilePixels; p += 256) {
+    const int gx = x0 + (p >> 5), gy = y0 + (p & 31);
+    if (gx < (int)a.W && gy < (int)a.H) {
+      const unsigned long long k = skeys[p];
+      const uint64_t g = (uint64_t)gx * a.H + gy;
+      b.idx_out[g] = (uint32_t)(k & 0xFFFFFFFFull);
+      b.depth_out[g] = __uint_as_float((uint32_t)(k >> 32));
+    }
+  }
+}
+
 // Split the key image into the two output planes and re-arm the keys for the next render.
 __global__ void k_resolve(unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx, float* __restrict__ depth,
-                          uint64_t N) {
+                          uint32_t W, uint32_t H) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  const unsigned long long k = keys[i];
-  keys[i] = kBackgroundKey;
+  if (i >= (uint64_t)W * H) return;
+  const uint32_t x = (uint32_t)(i / H), y = (uint32_t)(i - (uint64_t)x * H);
+  const uint64_t g = key_index(x, y, H);
+  const unsigned long long k = keys[g];
+  keys[g] = kBackgroundKey;
   idx[i] = (uint32_t)(k & 0xFFFFFFFFull);
   depth[i] = __uint_as_float((uint32_t)(k >> 32));
 }
@@ -323,6 +517,9 @@ struct smesh_renderer {
   uint32_t* big_queue = nullptr;
   uint32_t* big_count = nullptr;
   uint32_t big_capacity = 0;
+  uint32_t* tri_code = nullptr;    // [F] tiled path: packed tile range per triangle
+  uint32_t* tile_list = nullptr;   // [16 F]
+  Scratch tile_tables;             // tile_count[ntiles] + tile_offset[ntiles+1]
   std::vector<ImagePair> images;   // pooled output planes
   Scratch own_idx;                 // for the host-output entry point
   std::mutex mu;
@@ -330,7 +527,8 @@ struct smesh_renderer {
 
 namespace {
 
-int ensure_keys(smesh_renderer* r, uint64_t N) {
+int ensure_keys(smesh_renderer* r, uint64_t W, uint64_t H) {
+  const uint64_t N = div_up(W, 4) * div_up(H, 4) * 16;   // 4 x 4 blocked layout, padded
   if (N <= r->keys_pixels) return SMESH_OK;
   if (r->keys) SMESH_HIP(hipFree(r->keys));
   r->keys = nullptr;
@@ -347,7 +545,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   DeviceCtx* ctx = r->ctx;
   hipStream_t st = ctx->stream;
   const uint64_t W = cam->width, H = cam->height, N = W * H;
-  SMESH_TRY(ensure_keys(r, N));
+  SMESH_TRY(ensure_keys(r, W, H));
   ProfScope prof(ctx, SMESH_PROF_RASTER);
   CameraArgs ca;
   memcpy(ca.R, cam->rotation, sizeof ca.R);
@@ -364,14 +562,38 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     a.keys = r->keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
     a.big_queue = r->big_queue; a.big_count = r->big_count; a.big_capacity = r->big_capacity;
     a.small_limit = 64;
+    { static const int rdbg = getenv("SMESH_RDBG") ? atoi(getenv("SMESH_RDBG")) : 0; a.dbg = rdbg; }
+    static const bool direct = !(getenv("SMESH_RASTER") && std::string(getenv("SMESH_RASTER")) == "tiled");
+    const uint32_t tiles_x = (uint32_t)div_up(W, kTW), tiles_y = (uint32_t)div_up(H, kTH);
+    const uint64_t ntiles = (uint64_t)tiles_x * tiles_y;
     SMESH_HIP(hipMemsetAsync(r->big_count, 0, 4, st));
+    const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus * 8);
+    if (!direct && ntiles <= (1u << 20)) {
+      // tiled path: bin (count, scan, fill), big triangles through global atomics, then one workgroup per tile
+      SMESH_TRY(r->tile_tables.reserve((2 * ntiles + 1) * 4));
+      BinArgs b;
+      b.r = a;
+      b.tiles_x = tiles_x; b.tiles_y = tiles_y; b.ntiles = (uint32_t)ntiles;
+      b.tile_count = static_cast<uint32_t*>(r->tile_tables.ptr);
+      b.tile_offset = b.tile_count + ntiles;
+      b.tri_code = r->tri_code; b.tile_list = r->tile_list;
+      b.idx_out = d_idx; b.depth_out = d_depth;
+      SMESH_HIP(hipMemsetAsync(b.tile_count, 0, ntiles * 4, st));
+      const dim3 gtri((uint32_t)div_up(r->F, 256));
+      hipLaunchKernelGGL(k_bin_count, gtri, dim3(256), 0, st, b);
+      hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b);
+      hipLaunchKernelGGL(k_bin_fill, gtri, dim3(256), 0, st, b);
+      hipLaunchKernelGGL(k_raster_big, dim3(big_grid), dim3(256), 0, st, a, 0u);
+      hipLaunchKernelGGL(k_raster_tile, dim3((uint32_t)ntiles), dim3(256), 0, st, b);
+      SMESH_HIP(hipGetLastError());
+      return SMESH_OK;
+    }
     hipLaunchKernelGGL(k_raster_small, dim3((uint32_t)div_up(r->F, 256)), dim3(256), 0, st, a);
     SMESH_HIP(hipGetLastError());
-    const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus * 8);
     hipLaunchKernelGGL(k_raster_big, dim3(big_grid), dim3(256), 0, st, a, 0u);
     SMESH_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, N);
+  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
@@ -425,6 +647,8 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->big_queue), (size_t)r->big_capacity * 4);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->big_count), 16);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tri_code), std::max<uint64_t>(F * 4, 16));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tile_list), std::max<uint64_t>(F * 4 * kMaxTilesPerTri, 16));
   if (e == hipSuccess && V) e = hipMemcpyAsync(r->verts, vertices, V * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -534,10 +758,11 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->stream);
   for (void* p : {(void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
-                  (void*)r->big_queue, (void*)r->big_count})
+                  (void*)r->big_queue, (void*)r->big_count, (void*)r->tri_code, (void*)r->tile_list})
     if (p) (void)hipFree(p);
   for (auto& im : r->images) { (void)hipFree(im.idx); (void)hipFree(im.depth); }
   r->own_idx.release();
+  r->tile_tables.release();
   delete r;
   return SMESH_OK;
 }
