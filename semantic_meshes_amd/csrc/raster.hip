@@ -189,12 +189,9 @@ struct RasterArgs {
   int dbg;                    // development ablation (SMESH_RDBG): 1 = no atomics, 2 = setup only
 };
 
-// Key image layout: 4 x 4 pixel blocks, one 128-byte line each, so that the fragments neighbouring triangles
-// emit (in any screen direction) fall into the same lines and their atomics travel as one request.
-__device__ __forceinline__ uint64_t key_index(uint32_t x, uint32_t y, uint32_t H) {
-  const uint32_t hb = (H + 3u) >> 2;
-  return ((uint64_t)(x >> 2) * hb + (y >> 2)) * 16u + ((x & 3u) << 2) + (y & 3u);
-}
+// Key image layout: same (W,H) y-fastest order as the output planes.  (A 4 x 4 blocked layout was tried to
+// make neighbouring fragments share cache lines: no change in k_raster_small, slower resolve.)
+__device__ __forceinline__ uint64_t key_index(uint32_t x, uint32_t y, uint32_t H) { return (uint64_t)x * H + y; }
 
 __device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t) {
   const int32_t i0 = a.faces[3 * f + 0], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
