@@ -151,6 +151,19 @@ int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind
 int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* num_floats);
 int smesh_aggregator_row_stride(smesh_aggregator_t* a, uint32_t* row_stride);
 
+/* ---- annotation renderer: fused annotations gathered back to an image ------------------------- */
+/* Replaces ModelAggregator::renderer() + ModelRenderer::render (include/semantic_meshes/fusion/Mesh.h:124-129,
+ * 25-42; the harness does the same with tf.gather, eval-scannet/eval_scannet.py:314): the renderer holds
+ * a snapshot of get() (float32[P,C]); render writes out[x,y,:] = snapshot[idx[x,y]] if idx < P else
+ * background[:] into a contiguous float32 (W,H,C) image.  `background` is C floats in HOST memory. */
+typedef struct smesh_annotation_renderer smesh_annotation_renderer_t;
+int smesh_aggregator_renderer(smesh_aggregator_t* a, smesh_annotation_renderer_t** out);
+int smesh_annotation_renderer_render(smesh_annotation_renderer_t* r,
+                                     const void* indices, int idx_dtype, const int64_t idx_strides[2], int idx_memkind,
+                                     const float* background, float* out, int out_memkind,
+                                     uint64_t width, uint64_t height);
+int smesh_annotation_renderer_destroy(smesh_annotation_renderer_t* r);
+
 /* ---- fused view: render(camera) -> add(indices, probs) without leaving the device ----------- */
 /* One iteration of the loop at python/scripts/colorize_cityscapes_mesh.py:54-67. probs/weights as
  * in smesh_aggregator_add with contiguous (W,H,C)/(W,H) layout. */

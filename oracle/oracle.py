@@ -207,6 +207,23 @@ class OracleAggregator:
         _check(lib().smesh_aggregator_set_raw(self._h, raw.ctypes.data_as(ctypes.c_void_p), 0))
 
 
+def render_annotations(aggregator, idx, background):
+    """ModelAggregator::renderer() + ModelRenderer::render (Mesh.h:25-42,124-129) on the oracle."""
+    idx = np.ascontiguousarray(idx)
+    bg = np.ascontiguousarray(background, dtype=np.float32)
+    h = ctypes.c_void_p()
+    _check(lib().smesh_aggregator_renderer(aggregator._h, ctypes.byref(h)))
+    W, H = idx.shape
+    out = np.empty((W, H, aggregator.C), np.float32)
+    try:
+        _check(lib().smesh_annotation_renderer_render(h, idx.ctypes.data_as(ctypes.c_void_p), _IDX_DTYPES[idx.dtype], _strides(idx), 0,
+                                                      bg.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), 0,
+                                                      ctypes.c_uint64(W), ctypes.c_uint64(H)))
+    finally:
+        lib().smesh_annotation_renderer_destroy(h)
+    return out
+
+
 def synth_probs(num_pixels, classes, seed, zero_fraction=0.0):
     out = np.empty((int(num_pixels), int(classes)), np.float32)
     _check(lib().smesh_synth_probs(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(int(num_pixels)), ctypes.c_uint32(int(classes)),

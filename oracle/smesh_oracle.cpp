@@ -539,6 +539,41 @@ int smesh_aggregator_row_stride(smesh_aggregator_t* a, uint32_t* stride) {
   return SMESH_OK;
 }
 
+// ModelAggregator::renderer (Mesh.h:124-129) + ModelRenderer::render (Mesh.h:25-42)
+struct smesh_annotation_renderer {
+  uint64_t P; uint32_t C;
+  std::vector<float> ann;
+};
+
+int smesh_aggregator_renderer(smesh_aggregator_t* a, smesh_annotation_renderer_t** out) {
+  if (!a || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
+  auto* r = new (std::nothrow) smesh_annotation_renderer();
+  if (!r) return fail(SMESH_ERR_RUNTIME, "out of memory");
+  r->P = a->P; r->C = a->C;
+  r->ann.resize(a->P * a->C);
+  int st = smesh_aggregator_get(a, r->ann.data(), SMESH_MEM_HOST);   // m_annotations = elwise(get) (:127)
+  if (st) { delete r; return st; }
+  *out = r;
+  return SMESH_OK;
+}
+
+int smesh_annotation_renderer_render(smesh_annotation_renderer_t* r, const void* indices, int idx_dtype, const int64_t is[2],
+                                     int imem, const float* background, float* out, int omem, uint64_t W, uint64_t H) {
+  if (!r || !indices || !is || !background || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (imem != SMESH_MEM_HOST || omem != SMESH_MEM_HOST) return fail(SMESH_ERR_INVALID, "oracle only handles host memory");
+  if (idx_dtype < 0 || idx_dtype > 3) return fail(SMESH_ERR_INVALID, "bad index dtype");
+  for (uint64_t x = 0; x < W; x++)
+    for (uint64_t y = 0; y < H; y++) {
+      const size_t primitive_index = load_idx(indices, idx_dtype, (int64_t)x * is[0] + (int64_t)y * is[1]);
+      float* p = out + (x * H + y) * r->C;
+      if (primitive_index < r->P) std::memcpy(p, &r->ann[primitive_index * r->C], r->C * sizeof(float));   // :34-36
+      else std::memcpy(p, background, r->C * sizeof(float));                                                // :38-40
+    }
+  return SMESH_OK;
+}
+
+int smesh_annotation_renderer_destroy(smesh_annotation_renderer_t* r) { delete r; return SMESH_OK; }
+
 int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cam,
                     const float* probs, const float* weights, int memkind) {
   if (!r || !a || !cam || !probs) return fail(SMESH_ERR_INVALID, "NULL argument");

@@ -57,6 +57,9 @@ SIGNATURES = {
     "smesh_aggregator_set_raw": (c_int, [c_void_p, c_void_p, c_int]),
     "smesh_aggregator_raw_pointer": (c_int, [c_void_p, P(c_void_p), P(c_u64)]),
     "smesh_aggregator_row_stride": (c_int, [c_void_p, P(c_u32)]),
+    "smesh_aggregator_renderer": (c_int, [c_void_p, P(c_void_p)]),
+    "smesh_annotation_renderer_render": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int, c_void_p, c_void_p, c_int, c_u64, c_u64]),
+    "smesh_annotation_renderer_destroy": (c_int, [c_void_p]),
     "smesh_fuse_view": (c_int, [c_void_p, c_void_p, P(CameraPOD), c_void_p, c_void_p, c_int]),
     "smesh_profile_enable": (c_int, [c_int, c_int]),
     "smesh_profile_read": (c_int, [c_int, c_int, P(ctypes.c_double), P(c_u64)]),

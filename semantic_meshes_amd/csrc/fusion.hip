@@ -675,6 +675,18 @@ __global__ void k_finalize_rows(const float* __restrict__ acc, float* __restrict
   finalize_row<KIND>(dst, C);
 }
 
+// ModelRenderer::render (Mesh.h:25-42): per-pixel gather of the fused annotation rows
+__global__ void k_gather_annotations(const uint32_t* __restrict__ idx, const float* __restrict__ ann,
+                                     const float* __restrict__ background, float* __restrict__ out,
+                                     uint64_t total, uint32_t P, uint32_t C) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const uint64_t pix = e / C;
+  const uint32_t c = (uint32_t)(e - pix * C);
+  const uint32_t v = idx[pix];
+  out[e] = v < P ? ann[(uint64_t)v * C + c] : background[c];
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -896,6 +908,29 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
   return SMESH_OK;
 }
 
+// Contiguous uint32 view of an index image already in device memory (gathers/casts only when needed).
+int normalize_idx(DeviceCtx* ctx, Scratch& scratch, const void* d_idx, int idx_dtype, const int64_t is[2],
+                  uint64_t W, uint64_t H, const uint32_t** out) {
+  const uint64_t N = W * H;
+  if (is[0] == (int64_t)H && is[1] == 1 && (idx_dtype == SMESH_IDX_U32 || idx_dtype == SMESH_IDX_I32)) {
+    *out = static_cast<const uint32_t*>(d_idx);
+    return SMESH_OK;
+  }
+  SMESH_TRY(scratch.reserve(N * 4));
+  uint32_t* o = static_cast<uint32_t*>(scratch.ptr);
+  const dim3 g((uint32_t)div_up(N, 256)), b(256);
+  hipStream_t st = ctx->stream;
+  switch (idx_dtype) {
+    case SMESH_IDX_U32: hipLaunchKernelGGL(k_gather_idx<uint32_t>, g, b, 0, st, (const uint32_t*)d_idx, is[0], is[1], o, N, (uint32_t)H); break;
+    case SMESH_IDX_I32: hipLaunchKernelGGL(k_gather_idx<int32_t>, g, b, 0, st, (const int32_t*)d_idx, is[0], is[1], o, N, (uint32_t)H); break;
+    case SMESH_IDX_U64: hipLaunchKernelGGL(k_gather_idx<uint64_t>, g, b, 0, st, (const uint64_t*)d_idx, is[0], is[1], o, N, (uint32_t)H); break;
+    default:            hipLaunchKernelGGL(k_gather_idx<int64_t>, g, b, 0, st, (const int64_t*)d_idx, is[0], is[1], o, N, (uint32_t)H); break;
+  }
+  SMESH_HIP(hipGetLastError());
+  *out = o;
+  return SMESH_OK;
+}
+
 int check_strides(const int64_t* s, int n, const char* what) {
   if (!s) return fail(SMESH_ERR_INVALID, std::string(what) + ": strides are NULL");
   for (int i = 0; i < n; i++)
@@ -1111,6 +1146,87 @@ int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* n)
 int smesh_aggregator_row_stride(smesh_aggregator_t* a, uint32_t* stride) {
   if (!a || !stride) return fail(SMESH_ERR_INVALID, "NULL argument");
   *stride = a->S;
+  return SMESH_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// annotation renderer (Mesh.h:25-42, 124-129)
+// ------------------------------------------------------------------------------------------------
+struct smesh_annotation_renderer {
+  DeviceCtx* ctx = nullptr;
+  uint64_t P = 0;
+  uint32_t C = 0;
+  float* ann = nullptr;      // snapshot of get(): float32[P*C]
+  float* bg = nullptr;       // background vector [C]
+  Scratch st_idx, nm_idx, out_tmp;
+  std::mutex mu;
+};
+
+extern "C" {
+
+int smesh_aggregator_renderer(smesh_aggregator_t* a, smesh_annotation_renderer_t** out) {
+  if (!a || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  std::lock_guard<std::mutex> g(a->mu);
+  DeviceCtx* ctx = a->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  auto* r = new (std::nothrow) smesh_annotation_renderer();
+  if (!r) return fail(SMESH_ERR_RUNTIME, "out of memory");
+  r->ctx = ctx; r->P = a->P; r->C = a->C;
+  const size_t bytes = (size_t)a->P * a->C * 4;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->ann), bytes ? bytes : 16);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->bg), (size_t)a->C * 4);
+  if (e != hipSuccess) { if (r->ann) (void)hipFree(r->ann); delete r; return fail_hip(e, "annotation renderer allocation", __FILE__, __LINE__); }
+  int st = bytes ? finalize_into(a, r->ann) : SMESH_OK;   // m_annotations = elwise(get)  (Mesh.h:127)
+  if (st == SMESH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = fail(SMESH_ERR_RUNTIME, "stream sync failed");
+  if (st) { (void)hipFree(r->ann); (void)hipFree(r->bg); delete r; return st; }
+  *out = r;
+  return SMESH_OK;
+}
+
+int smesh_annotation_renderer_render(smesh_annotation_renderer_t* r, const void* indices, int idx_dtype, const int64_t is[2],
+                                     int imem, const float* background, float* out, int omem, uint64_t W, uint64_t H) {
+  if (!r || !indices || !background || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (idx_dtype < 0 || idx_dtype > 3) return fail(SMESH_ERR_INVALID, "bad index dtype");
+  SMESH_TRY(check_strides(is, 2, "indices"));
+  if (W == 0 || H == 0) return SMESH_OK;
+  std::lock_guard<std::mutex> g(r->mu);
+  DeviceCtx* ctx = r->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  const uint64_t N = W * H, total = N * r->C;
+  const void* d_idx = indices;
+  if (imem == SMESH_MEM_HOST) {
+    const size_t span = 1 + (W - 1) * is[0] + (H - 1) * is[1];
+    SMESH_TRY(stage_in(ctx, r->st_idx, indices, span * idx_itemsize(idx_dtype), &d_idx));
+  }
+  const uint32_t* idx = nullptr;
+  SMESH_TRY(normalize_idx(ctx, r->nm_idx, d_idx, idx_dtype, is, W, H, &idx));
+  SMESH_HIP(hipMemcpyAsync(r->bg, background, (size_t)r->C * 4, hipMemcpyHostToDevice, ctx->stream));
+  float* d_out = out;
+  if (omem == SMESH_MEM_HOST) {
+    SMESH_TRY(r->out_tmp.reserve(total * 4));
+    d_out = static_cast<float*>(r->out_tmp.ptr);
+  }
+  hipLaunchKernelGGL(k_gather_annotations, dim3((uint32_t)div_up(total, 256)), dim3(256), 0, ctx->stream, idx, r->ann, r->bg,
+                     d_out, total, (uint32_t)r->P, r->C);
+  SMESH_HIP(hipGetLastError());
+  if (omem == SMESH_MEM_HOST) SMESH_HIP(hipMemcpyAsync(out, d_out, total * 4, hipMemcpyDeviceToHost, ctx->stream));
+  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  return SMESH_OK;
+}
+
+int smesh_annotation_renderer_destroy(smesh_annotation_renderer_t* r) {
+  if (!r) return SMESH_OK;
+  (void)hipSetDevice(r->ctx->device);
+  (void)hipStreamSynchronize(r->ctx->stream);
+  (void)hipFree(r->ann);
+  (void)hipFree(r->bg);
+  r->st_idx.release(); r->nm_idx.release(); r->out_tmp.release();
+  delete r;
   return SMESH_OK;
 }
 

@@ -3,6 +3,7 @@
 Reference: /root/reference/python/semantic_meshes/src/Data.cu:5-20 registers `Colmap`, `Ply` and
 `Camera(rotation, translation, resolution, focal_lengths, principal_point)`.
 """
+import math
 import os
 import struct
 
@@ -238,3 +239,134 @@ def _write_ply(path, vertices, faces, colors, binary):
                 fh.write(("%r %r %r\n" % (float(v[0]), float(v[1]), float(v[2]))).encode("ascii"))
             for f, c in zip(faces, colors):
                 fh.write(("3 %d %d %d %d %d %d\n" % (f[0], f[1], f[2], c[0], c[1], c[2])).encode("ascii"))
+
+
+# ---- COLMAP workspace reader -----------------------------------------------------------
+_COLMAP_MODELS = {0: ("SIMPLE_PINHOLE", 3), 1: ("PINHOLE", 4), 2: ("SIMPLE_RADIAL", 4), 3: ("RADIAL", 5), 4: ("OPENCV", 8),
+                  5: ("OPENCV_FISHEYE", 8), 6: ("FULL_OPENCV", 12), 7: ("FOV", 5), 8: ("SIMPLE_RADIAL_FISHEYE", 4),
+                  9: ("RADIAL_FISHEYE", 5), 10: ("THIN_PRISM_FISHEYE", 12)}
+_COLMAP_BY_NAME = {name: (mid, n) for mid, (name, n) in _COLMAP_MODELS.items()}
+
+
+def _qvec_to_rotation(q):
+    w, x, y, z = (float(v) for v in q)
+    n = math.sqrt(w * w + x * x + y * y + z * z)
+    w, x, y, z = w / n, x / n, y / n, z / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]], dtype=np.float64)
+
+
+class Colmap:
+    """`semantic_meshes.data.Colmap(workspace)`: cameras.{bin,txt} + images.{bin,txt} -> `getCamera(index | path)`.
+
+    Reference: /root/reference/src/data/Colmap.cpp:7-62 (images sorted by name `:19-21`, lookup by file name
+    `:50-59`), /root/reference/include/semantic_meshes/data/Colmap.h:19-25 (Camera{projection, transform,
+    resolution}).  Only the two pinhole models the reference's Camera can hold (render/Camera.h:9-12) are
+    accepted.  An unknown image name raises KeyError (the reference prints and calls exit(-1), Colmap.cpp:60-61).
+    """
+
+    def __init__(self, workspace_path):
+        self.path = workspace_path
+        self._cameras = self._read_cameras(self._find(workspace_path, "cameras"))
+        images = self._read_images(self._find(workspace_path, "images"))
+        self._images = sorted(images, key=lambda im: im["name"])
+        for im in self._images:
+            if im["camera_id"] not in self._cameras:
+                raise ValueError("image %r references unknown camera %d" % (im["name"], im["camera_id"]))
+
+    @staticmethod
+    def _find(ws, stem):
+        for ext in (".bin", ".txt"):
+            p = os.path.join(ws, stem + ext)
+            if os.path.isfile(p):
+                return p
+        raise ValueError("no %s.bin / %s.txt in %s" % (stem, stem, ws))
+
+    @staticmethod
+    def _camera_entry(model, width, height, params):
+        if model == "SIMPLE_PINHOLE":
+            f, cx, cy = params[:3]
+            return dict(width=int(width), height=int(height), f=(f, f), c=(cx, cy))
+        if model == "PINHOLE":
+            fx, fy, cx, cy = params[:4]
+            return dict(width=int(width), height=int(height), f=(fx, fy), c=(cx, cy))
+        raise ValueError("COLMAP camera model %s is not supported (only SIMPLE_PINHOLE and PINHOLE)" % model)
+
+    def _read_cameras(self, path):
+        cams = {}
+        if path.endswith(".txt"):
+            for line in open(path):
+                tok = line.split()
+                if not tok or tok[0].startswith("#"):
+                    continue
+                cams[int(tok[0])] = self._camera_entry(tok[1], int(tok[2]), int(tok[3]), [float(v) for v in tok[4:]])
+        else:
+            with open(path, "rb") as fh:
+                (n,) = struct.unpack("<Q", fh.read(8))
+                for _ in range(n):
+                    cid, mid, w, h = struct.unpack("<iiQQ", fh.read(24))
+                    if mid not in _COLMAP_MODELS:
+                        raise ValueError("unknown COLMAP camera model id %d" % mid)
+                    name, np_ = _COLMAP_MODELS[mid]
+                    params = struct.unpack("<%dd" % np_, fh.read(8 * np_))
+                    cams[cid] = self._camera_entry(name, w, h, params)
+        return cams
+
+    @staticmethod
+    def _read_images(path):
+        images = []
+        if path.endswith(".txt"):
+            lines = [ln for ln in open(path) if not ln.startswith("#")]
+            # every image has two lines: pose + name, then its 2-D points (possibly empty)
+            k = 0
+            while k < len(lines):
+                tok = lines[k].split()
+                if len(tok) >= 10:
+                    images.append(dict(id=int(tok[0]), q=[float(v) for v in tok[1:5]], t=[float(v) for v in tok[5:8]],
+                                       camera_id=int(tok[8]), name=" ".join(tok[9:])))
+                    k += 2
+                else:
+                    k += 1
+        else:
+            with open(path, "rb") as fh:
+                (n,) = struct.unpack("<Q", fh.read(8))
+                for _ in range(n):
+                    iid = struct.unpack("<I", fh.read(4))[0]
+                    q = struct.unpack("<4d", fh.read(32))
+                    t = struct.unpack("<3d", fh.read(24))
+                    cid = struct.unpack("<I", fh.read(4))[0]
+                    name = b""
+                    while True:
+                        ch = fh.read(1)
+                        if ch in (b"\x00", b""):
+                            break
+                        name += ch
+                    (npts,) = struct.unpack("<Q", fh.read(8))
+                    fh.seek(24 * npts, 1)
+                    images.append(dict(id=iid, q=list(q), t=list(t), camera_id=cid, name=name.decode("utf-8", "replace")))
+        return images
+
+    def getImageNum(self):
+        return len(self._images)
+
+    def getImageIndex(self, path):
+        name = os.path.basename(os.path.normpath(str(path)))
+        for i, im in enumerate(self._images):
+            if im["name"] == name:
+                return i
+        raise KeyError("Image with name %s not found in colmap workspace" % name)
+
+    def getCamera(self, image_id):
+        """`getCamera(index)` or `getCamera(image_path)` (python/semantic_meshes/include/Colmap.h:15-23)."""
+        index = image_id if isinstance(image_id, (int, np.integer)) else self.getImageIndex(image_id)
+        if not 0 <= index < len(self._images):
+            raise IndexError("image index %d out of range" % index)
+        im = self._images[index]
+        cam = self._cameras[im["camera_id"]]
+        return Camera(_qvec_to_rotation(im["q"]), np.asarray(im["t"], dtype=np.float64),
+                      np.asarray([cam["width"], cam["height"]], dtype=np.int64),
+                      np.asarray(cam["f"], dtype=np.float64), np.asarray(cam["c"], dtype=np.float64))
+
+    def getCameras(self):
+        return [self.getCamera(i) for i in range(len(self._images))]

@@ -110,6 +110,10 @@ class _MeshAggregator:
         return DeviceArray(p.value, (self.primitives, self.classes), np.float32, self.device,
                            strides=(int(s.value), 1), owner=self)
 
+    def renderer(self):
+        """`ModelAggregator::renderer()` (Mesh.h:124-129): snapshot of the fused annotations for image gathers."""
+        return ModelRenderer(self)
+
     def fuse_view(self, renderer, camera, probs_image, weights_image=None):
         """render(camera) + add(indices, probs) in one call without the indices leaving the device."""
         W, H = camera.resolution
@@ -125,6 +129,42 @@ class _MeshAggregator:
                 raise ValueError("weights image must be contiguous float32 (W,H) in the same memory as probs")
             wp = ctypes.c_void_p(wp_)
         _lib.check(_lib.lib().smesh_fuse_view(renderer._h, self._h, ctypes.byref(camera._pod), ctypes.c_void_p(pp), wp, pmem))
+
+
+class ModelRenderer:
+    """Fused annotations gathered back to an image: `ModelAggregator::renderer()` + `ModelRenderer::render`
+    (/root/reference/include/semantic_meshes/fusion/Mesh.h:124-129, 25-42).  Holds a snapshot of get()."""
+
+    def __init__(self, aggregator):
+        self.classes, self.device = aggregator.classes, aggregator.device
+        h = ctypes.c_void_p()
+        _lib.check(_lib.lib().smesh_aggregator_renderer(aggregator._h, ctypes.byref(h)))
+        self._h = h
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h is not None and h.value:
+            try:
+                _lib.lib().smesh_annotation_renderer_destroy(h)
+            except Exception:
+                pass
+
+    def render(self, primitive_image, background=None):
+        """float32 (W,H,C) image: annotation of the primitive under each pixel, `background` (C floats,
+        default zeros) where the index is out of range."""
+        ip, imem, ishape, idt, istr, keep = describe(primitive_image, 2, "primitive image")
+        if idt not in _IDX_CODES:
+            raise ValueError("primitive image dtype must be one of uint32/int32/uint64/int64, got %s" % idt)
+        bg = np.zeros(self.classes, np.float32) if background is None else np.ascontiguousarray(background, dtype=np.float32)
+        if bg.shape != (self.classes,):
+            raise ValueError("background must have %d entries" % self.classes)
+        W, H = ishape
+        out = np.empty((W, H, self.classes), np.float32)
+        if out.size:
+            _lib.check(_lib.lib().smesh_annotation_renderer_render(
+                self._h, ctypes.c_void_p(ip), _IDX_CODES[idt], _c64(istr), imem, bg.ctypes.data_as(ctypes.c_void_p),
+                out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST, W, H))
+        return out
 
 
 class MeshAggregatorSum(_MeshAggregator):

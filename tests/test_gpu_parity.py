@@ -341,3 +341,24 @@ def test_full_size_properties_cfg2(sm):
     hp = np.asarray(probs[0]).reshape(-1, C)
     keep = (idx_a.reshape(-1) != BG) & (hp.sum(axis=1) > 0.5)
     np.testing.assert_allclose(plain.get_raw().astype(np.float64).sum(), hp[keep].astype(np.float64).sum(), rtol=1e-5)
+
+
+def test_annotation_renderer_matches_oracle(sm, oracle):
+    mesh, cams = small_scene()
+    C, P = 6, len(mesh.faces)
+    rng = np.random.default_rng(9)
+    r = sm.render.triangles(mesh)
+    agg, oagg = sm.fusion.MeshAggregator(P, C), oracle.OracleAggregator(P, C)
+    idx, _ = r.render(cams[0])
+    probs = random_probs(rng, *cams[0].resolution, C)
+    agg.add(idx, probs)
+    oagg.add(np.asarray(idx), probs)
+    bg = np.linspace(-1, 1, C).astype(np.float32)
+    idx2, _ = r.render(cams[1])
+    got = agg.renderer().render(idx2, bg)                                  # device indices
+    want = oracle.render_annotations(oagg, np.asarray(idx2), bg)
+    assert got.shape == cams[1].resolution + (C,) and got.dtype == np.float32
+    assert_fused_close(got, want)
+    got_i64 = agg.renderer().render(np.asarray(idx2).astype(np.int64).T.copy().T, bg)   # host, int64, strided
+    np.testing.assert_array_equal(got_i64, got)
+    assert (got[np.asarray(idx2) == BG] == bg).all()

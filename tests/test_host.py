@@ -106,3 +106,50 @@ def test_shard_views():
     assert distributed.shard_views(1600, 3, 8) == list(range(600, 800))
     with pytest.raises(ValueError):
         distributed.shard_views(10, 8, 8)
+
+
+def _write_colmap(ws, binary):
+    import struct
+    cams = {1: ("PINHOLE", 640, 480, [500.5, 501.5, 320.25, 240.75]), 7: ("SIMPLE_PINHOLE", 320, 200, [250.0, 160.0, 100.0])}
+    images = [(3, [0.5, 0.5, -0.5, 0.5], [0.1, -0.2, 3.0], 7, "b_second.jpg"), (9, [1, 0, 0, 0], [1, 2, 3], 1, "a_first.png")]
+    ids = {"PINHOLE": 1, "SIMPLE_PINHOLE": 0}
+    if binary:
+        with open(os.path.join(ws, "cameras.bin"), "wb") as fh:
+            fh.write(struct.pack("<Q", len(cams)))
+            for cid, (m, w, h, p) in cams.items():
+                fh.write(struct.pack("<iiQQ", cid, ids[m], w, h) + struct.pack("<%dd" % len(p), *p))
+        with open(os.path.join(ws, "images.bin"), "wb") as fh:
+            fh.write(struct.pack("<Q", len(images)))
+            for iid, q, t, cid, name in images:
+                fh.write(struct.pack("<I4d3dI", iid, *q, *t, cid) + name.encode() + b"\0")
+                fh.write(struct.pack("<Q", 2) + struct.pack("<ddq", 1.0, 2.0, -1) * 2)
+    else:
+        with open(os.path.join(ws, "cameras.txt"), "w") as fh:
+            fh.write("# Camera list\n")
+            for cid, (m, w, h, p) in cams.items():
+                fh.write("%d %s %d %d %s\n" % (cid, m, w, h, " ".join(repr(float(v)) for v in p)))
+        with open(os.path.join(ws, "images.txt"), "w") as fh:
+            fh.write("# Image list with two lines of data per image\n")
+            for iid, q, t, cid, name in images:
+                fh.write("%d %s %s %d %s\n" % (iid, " ".join(map(repr, map(float, q))), " ".join(map(repr, map(float, t))), cid, name))
+                fh.write("1.0 2.0 -1 3.0 4.0 -1\n")
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_colmap_reader(tmp_path, binary):
+    _write_colmap(str(tmp_path), binary)
+    ws = sm.data.Colmap(str(tmp_path))
+    assert ws.getImageNum() == 2
+    a = ws.getCamera(0)                                   # images are sorted by name (Colmap.cpp:19-21)
+    assert a.resolution == (640, 480)
+    np.testing.assert_allclose(a.focal_lengths, [500.5, 501.5])
+    np.testing.assert_allclose(a.principal_point, [320.25, 240.75])
+    np.testing.assert_allclose(a.rotation, np.eye(3), atol=1e-7)
+    np.testing.assert_allclose(a.translation, [1, 2, 3])
+    b = ws.getCamera("/some/dir/b_second.jpg")            # lookup by file name (Colmap.cpp:50-59)
+    assert b.resolution == (320, 200) and b.focal_lengths[0] == b.focal_lengths[1] == 250.0
+    np.testing.assert_allclose(b.rotation @ b.rotation.T, np.eye(3), atol=1e-6)
+    np.testing.assert_allclose(b.rotation, [[0, -1, 0], [0, 0, -1], [1, 0, 0]], atol=1e-6)  # q = (w,x,y,z) = (.5,.5,-.5,.5)
+    assert len(ws.getCameras()) == 2
+    with pytest.raises(KeyError):
+        ws.getCamera("missing.png")

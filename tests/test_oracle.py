@@ -213,3 +213,16 @@ def test_texel_counts(oracle):
     idx, _ = r.render(cam)
     seen = np.unique(idx[idx != BG])
     assert seen.max() < r.getPrimitivesNum() and len(seen) >= r.getPrimitivesNum() // 2
+
+
+def test_annotation_renderer_gathers_rows(oracle):
+    # ModelRenderer::render (Mesh.h:25-42): annotation row under each pixel, background where idx >= P
+    agg = _simple(oracle, P=3, C=2)
+    probs = np.zeros((1, 2, 2), np.float32)
+    probs[0, 0] = [0.25, 0.75]
+    probs[0, 1] = [1.0, 0.0]
+    agg.add(np.array([[0, 2]], np.uint32), probs)
+    idx = np.array([[0, 1, 2], [7, 0xFFFFFFFF, 2]], np.uint32)
+    img = oracle.render_annotations(agg, idx, [9.0, 8.0])
+    np.testing.assert_allclose(img[0], [[0.25, 0.75], [0, 0], [1, 0]], rtol=1e-6)
+    np.testing.assert_allclose(img[1], [[9, 8], [9, 8], [1, 0]], rtol=1e-6)
