@@ -332,10 +332,28 @@ struct FlushLists {
   uint8_t sorder[kWave];    // root lane (= LDS row holding the group total) at sorted position s
 };
 
+// Bitonic sort of the first N lanes' keys (N = 16, 32 or 64; other lanes unchanged garbage).
+template <int N>
+__device__ __forceinline__ uint32_t wave_sort(uint32_t key, int l) {
+#pragma unroll
+  for (int k = 2; k <= N; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint32_t other = (uint32_t)__shfl_xor((int)key, j);
+      const bool up = (l & k) == 0;          // ascending block
+      const bool lower = (l & j) == 0;       // the lower lane of a pair keeps the smaller key when ascending
+      const uint32_t lo = min(key, other), hi = max(key, other);
+      key = (up == lower) ? lo : hi;
+    }
+  }
+  return key;
+}
+
 template <int CT, int KIND, bool NT>
 __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
   constexpr int KV = PrefetchVecs<CT>::value;
   constexpr int CH = Chunk<CT>::value;
+  constexpr bool ONE_CHUNK = CT > 0 && CT <= 32;   // the whole class vector of a pixel lives in registers
   const int C = CT > 0 ? CT : (int)a.C;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int pfloats = (kWave * C + 3) & ~3;
@@ -357,8 +375,36 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
   const int nvec = kSX * seg_vecs;
   const f4* __restrict__ base4 = reinterpret_cast<const f4*>(a.probs);
 
+  // Strip geometry is carried incrementally (one division per wave, none per strip): strip (bx, by) covers
+  // columns 4*bx.., rows 16*by..; the next strip is one step down the image column.
+  struct Pos { uint32_t bx, by; };
+  auto geom = [&](const Pos& p) {
+    StripGeom g;
+    g.valid = true;
+    g.x0 = p.bx * kSX;
+    g.y0 = p.by * kTY;
+    g.nx = min((int)(a.W - g.x0), kSX);
+    g.ny = min((int)(a.H - g.y0), kTY);
+    return g;
+  };
+  auto advance = [&](Pos p) {
+    if (++p.by == a.strips_y) { p.by = 0; ++p.bx; }
+    return p;
+  };
   auto is_fast = [&](const StripGeom& g) { return g.nx == kSX && g.ny == kTY && a.vec_ok; };
-  auto src_index = [&](const StripGeom& g, int q) -> uint64_t {
+  // per-lane float4 offsets of a full strip relative to its first float4 (vec_ok: H*C is a multiple of 4)
+  uint32_t voff[KV > 0 ? KV : 1];
+  if constexpr (KV > 0) {
+    const uint32_t col_vecs = (uint32_t)(((uint64_t)a.H * (uint32_t)C) >> 2);
+#pragma unroll
+    for (int k = 0; k < KV; k++) {
+      const int q = min(l + k * kWave, nvec - 1);   // clamped: the surplus lanes of the last vector re-read it
+      const int seg = q / seg_vecs;
+      voff[k] = (uint32_t)seg * col_vecs + (uint32_t)(q - seg * seg_vecs);
+    }
+  }
+  auto strip_vec0 = [&](const StripGeom& g) -> uint64_t { return (((uint64_t)g.x0 * a.H + g.y0) * (uint64_t)C) >> 2; };
+  auto src_index = [&](const StripGeom& g, int q) -> uint64_t {   // generic (non-prefetched) path
     const int seg = q / seg_vecs;
     const int within = q - seg * seg_vecs;
     return (((uint64_t)(g.x0 + seg) * a.H + g.y0) * (uint64_t)C) / 4 + within;
@@ -368,23 +414,26 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
     return (uint64_t)(g.x0 + min(cx, g.nx - 1)) * a.H + g.y0 + min(ty, g.ny - 1);
   };
 
+  Pos pos;
+  pos.bx = s_begin / a.strips_y;
+  pos.by = s_begin - pos.bx * a.strips_y;
+
   // ---- prologue: load the first strip -----------------------------------------------------------
   // All prefetch loads are unconditional and land directly in the loop-carried registers: a load inside
   // a branch gets copied at the join, and that copy would wait for it (and for every older atomic).
   f4 r[KV > 0 ? KV : 1];
   {
-    const StripGeom g0 = strip_at(a, s_begin);
+    const StripGeom g0 = geom(pos);
     if constexpr (KV > 0) {
       // a partial (edge) strip is parked with dword loads instead; prefetch a harmless in-bounds address
+      const f4* p0 = base4 + (is_fast(g0) ? strip_vec0(g0) : 0);
 #pragma unroll
-      for (int k = 0; k < KV; k++) {
-        const int q = l + k * kWave;
-        r[k] = load_stream<NT>(base4 + (is_fast(g0) ? src_index(g0, q < nvec ? q : nvec - 1) : 0));
-      }
+      for (int k = 0; k < KV; k++) r[k] = load_stream<NT>(p0 + (is_fast(g0) ? voff[k] : 0u));
     }
+    (void)g0;
   }
-  uint32_t v_next = a.idx[pixel_of(strip_at(a, s_begin))];
-  float pw_next = a.pw ? a.pw[pixel_of(strip_at(a, s_begin))] : 1.0f;
+  uint32_t v_next = a.idx[pixel_of(geom(pos))];
+  float pw_next = a.pw ? a.pw[pixel_of(geom(pos))] : 1.0f;
   // wait for the prologue loads here, so that inside the loop the only pending memory operations at the
   // loop head are the previous strip's atomics (which no register depends on)
   if constexpr (KV > 0) {
@@ -394,8 +443,14 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
   pin(v_next);
   pin(pw_next);
 
+  // flush ownership: lane -> (row slot, class) with 64 / C rows per pass; no division inside the loop
+  const int rows_per_pass = C <= kWave ? kWave / C : 0;
+  const int f_slot = rows_per_pass ? l / C : 0;
+  const int f_c = rows_per_pass ? l - f_slot * C : 0;
+  const bool f_active = rows_per_pass && f_slot < rows_per_pass;
+
   for (uint32_t s = s_begin; s < s_end; s++) {
-    const StripGeom g = strip_at(a, s);
+    const StripGeom g = geom(pos);
     const uint32_t v_raw = v_next;
     const float pw_raw = pw_next;
 
@@ -437,47 +492,32 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
 
     // ---- 2. issue the loads of the next strip (consumed one iteration later) --------------------
     {
-      const StripGeom g1 = strip_at(a, min(s + 1, s_end - 1));
+      const Pos pos1 = (s + 1 < s_end) ? advance(pos) : pos;
+      const StripGeom g1 = geom(pos1);
       if constexpr (KV > 0) {
         const bool f1 = is_fast(g1);
+        const f4* p1 = base4 + (f1 ? strip_vec0(g1) : 0);
 #pragma unroll
-        for (int k = 0; k < KV; k++) {
-          const int q = l + k * kWave;
-          r[k] = load_stream<NT>(base4 + (f1 ? src_index(g1, q < nvec ? q : nvec - 1) : 0));
-        }
+        for (int k = 0; k < KV; k++) r[k] = load_stream<NT>(p1 + (f1 ? voff[k] : 0u));
       }
       v_next = a.idx[pixel_of(g1)];
       pw_next = a.pw ? a.pw[pixel_of(g1)] : 1.0f;
+      pos = pos1;
     }
 
     // ---- 3. compute: runs, links, groups (LDS + VALU only) ---------------------------------------
     const bool in = cx < g.nx && ty < g.ny;
     const uint32_t v = in ? v_raw : 0xFFFFFFFFu;
     float w = (in && v < a.P) ? pw_raw : 0.0f;          // Mesh.h:95,100-103 (k_pixel_weights)
-    if (a.dbg & 256) { wave_sync(); if (sp[l] == 123.456f) a.acc[0] = 1.0f; continue; }   // ablation: stream + park only
     const StripRuns rr = build_strip(L, v, a.P, l);     // wave syncs inside: the probs strip is complete in LDS
     // the per-view histogram was consumed by k_pixel_weights: restore its all-zero state on the way
     // (one plain store per run; replaces a memset launch per view)
     if (a.count && rr.head && v < a.P) a.count[v] = 0u;
-    if (a.dbg & 512) { if (rr.G == 99) a.acc[0] = 1.0f; continue; }                        // ablation: + runs/links/groups
-
-    // don't-care test on the float32 sequential class sum (Mesh.h:98)
-    float* row = sp + l * C;
-    int amax = 0;
-    {
-      float sum = 0.0f;
-      float best = row[0];
-      for (int c = 0; c < C; c++) {
-        const float p = row[c];
-        sum = sum + p;
-        if (KIND == SMESH_AGG_SUMMAX && p > best) { best = p; amax = c; }  // first max (Fusion.cu:53)
-      }
-      if (!(sum > 0.5f)) w = 0.0f;
-    }
 
     // ---- segmented reduction, all in registers -------------------------------------------------------
     // (a) down the column: suffix scan over the 16-lane DPP row folds every run into its head lane;
     // (b) along the chain: two pointer-doubling hops fold the <= 4 linked runs into the chain's root.
+    float* row = sp + l * C;
     const int hid = rr.hl + 1;  // 0 is reserved for "no lane"
     float samef[4];
     samef[0] = (row_down<1>(hid) == hid) ? 1.0f : 0.0f;
@@ -490,24 +530,12 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
     const int c2 = has1 ? (int)L.child[child1] : kNone;
     const bool has2 = c2 != kNone;
     const bool any1 = __ballot(has1) != 0ull, any2 = __ballot(has2) != 0ull;
-    for (int c0 = 0; c0 < C; c0 += CH) {
-      float val[CH];
-#pragma unroll
-      for (int k = 0; k < CH; k++) {
-        const int c = c0 + k;
-        float x = 0.0f;
-        if (c < C && w != 0.0f) {
-          const float p = row[c];
-          if (KIND == SMESH_AGG_SUMMAX) x = (c == amax) ? p * w : 0.0f;
-          else x = contribution<KIND>(p, w);
-        }
-        val[k] = x;
-      }
-      auto fold = [&](float mine, float other, float sf) -> float {
-        // Mul contributions can be -inf: select instead of multiplying by 0
-        if (KIND == SMESH_AGG_MUL) return mine + (sf != 0.0f ? other : 0.0f);
-        return fmaf(other, sf, mine);
-      };
+    auto fold = [&](float mine, float other, float sf) -> float {
+      // Mul contributions can be -inf: select instead of multiplying by 0
+      if (KIND == SMESH_AGG_MUL) return mine + (sf != 0.0f ? other : 0.0f);
+      return fmaf(other, sf, mine);
+    };
+    auto reduce_chunk = [&](float (&val)[CH], int c0) {
 #pragma unroll
       for (int k = 0; k < CH; k++) val[k] = fold(val[k], row_down<1>(val[k]), samef[0]);
 #pragma unroll
@@ -539,24 +567,74 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
         for (int k = 0; k < CH; k++)
           if (c0 + k < C) row[c0 + k] = val[k];
       }
+    };
+    if constexpr (ONE_CHUNK) {
+      // read the pixel's class vector once: don't-care test on the float32 sequential class sum (Mesh.h:98),
+      // then the aggregator's input map in place
+      float val[CH];
+      float sum = 0.0f;
+      int amax = 0;
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        val[k] = row[k];
+        sum = sum + val[k];
+      }
+      if (KIND == SMESH_AGG_SUMMAX) {
+        float best = val[0];
+#pragma unroll
+        for (int k = 1; k < CH; k++)
+          if (val[k] > best) { best = val[k]; amax = k; }   // first max (Fusion.cu:53)
+      }
+      if (!(sum > 0.5f)) w = 0.0f;
+      const bool live = w != 0.0f;
+#pragma unroll
+      for (int k = 0; k < CH; k++) {
+        float x = 0.0f;
+        if (KIND == SMESH_AGG_SUMMAX) x = (live && k == amax) ? val[k] * w : 0.0f;
+        else x = live ? contribution<KIND>(val[k], w) : 0.0f;
+        val[k] = x;
+      }
+      reduce_chunk(val, 0);
+    } else {
+      int amax = 0;
+      {
+        float sum = 0.0f;
+        float best = row[0];
+        for (int c = 0; c < C; c++) {
+          const float p = row[c];
+          sum = sum + p;
+          if (KIND == SMESH_AGG_SUMMAX && p > best) { best = p; amax = c; }
+        }
+        if (!(sum > 0.5f)) w = 0.0f;
+      }
+      for (int c0 = 0; c0 < C; c0 += CH) {
+        float val[CH];
+#pragma unroll
+        for (int k = 0; k < CH; k++) {
+          const int c = c0 + k;
+          float x = 0.0f;
+          if (c < C && w != 0.0f) {
+            const float p = row[c];
+            if (KIND == SMESH_AGG_SUMMAX) x = (c == amax) ? p * w : 0.0f;
+            else x = contribution<KIND>(p, w);
+          }
+          val[k] = x;
+        }
+        reduce_chunk(val, c0);
+      }
     }
 
-    // ---- 5. order the strip's groups by primitive id (bitonic network over the wave, key = prim << 6 | lane):
+    // ---- 5. order the strip's groups by primitive id (bitonic network, key = prim << 6 | root lane):
     // neighbouring primitives then sit on neighbouring lanes and share cache lines in one atomic instruction
     {
       const bool sortable = a.P <= (1u << 26) && !(a.dbg & 1);
-      uint32_t key = rr.root ? ((sortable ? (v << 6) : ((uint32_t)rr.gidx << 6)) | (uint32_t)l) : 0xFFFFFFFFu;
-#pragma unroll
-      for (int k = 2; k <= kWave; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-          const uint32_t other = (uint32_t)__shfl_xor((int)key, j);
-          const bool up = (l & k) == 0;          // ascending block
-          const bool lower = (l & j) == 0;       // the lower lane of a pair keeps the smaller key when ascending
-          const uint32_t lo = min(key, other), hi = max(key, other);
-          key = (up == lower) ? lo : hi;
-        }
-      }
+      if (rr.root) F.sprim[rr.gidx] = (sortable ? (v << 6) : ((uint32_t)rr.gidx << 6)) | (uint32_t)l;   // compact the keys
+      wave_sync();
+      uint32_t key = l < rr.G ? F.sprim[l] : 0xFFFFFFFFu;
+      if (rr.G <= 16) key = wave_sort<16>(key, l);
+      else if (rr.G <= 32) key = wave_sort<32>(key, l);
+      else key = wave_sort<64>(key, l);
+      wave_sync();
       if (l < rr.G) {
         const int lane = (int)(key & 63u);
         F.sorder[l] = (uint8_t)lane;
@@ -571,13 +649,24 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
       }
       pin(v_next);
       pin(pw_next);
-      // lanes own (sorted group, class) elements: ONE global atomic each, 19 consecutive lanes per 76-byte row
-      const int total = (a.dbg & 1024) ? 0 : rr.G * C;
-      for (int e = l; e < total; e += kWave) {
-        const int si = e / C;
-        const int c = e - si * C;
-        const float x = sp[(int)F.sorder[si] * C + c];
-        if (x != 0.0f && !(a.dbg & 2)) unsafeAtomicAdd(&a.acc[(uint64_t)F.sprim[si] * a.S + c], x);
+      if (!(a.dbg & 2)) {
+        if (rows_per_pass) {
+          // lane -> (row slot, class): 64 / C sorted groups per pass, C consecutive lanes per accumulator row
+          if (f_active) {
+            for (int si = f_slot; si < rr.G; si += rows_per_pass) {
+              const float x = sp[(int)F.sorder[si] * C + f_c];
+              if (x != 0.0f) unsafeAtomicAdd(&a.acc[(uint64_t)F.sprim[si] * a.S + f_c], x);
+            }
+          }
+        } else {
+          const int total = rr.G * C;
+          for (int e = l; e < total; e += kWave) {
+            const int si = e / C;
+            const int c = e - si * C;
+            const float x = sp[(int)F.sorder[si] * C + c];
+            if (x != 0.0f) unsafeAtomicAdd(&a.acc[(uint64_t)F.sprim[si] * a.S + c], x);
+          }
+        }
       }
     }
     wave_sync();  // the next iteration overwrites the LDS strip
