@@ -38,7 +38,8 @@ struct ProfSlot {
 // One per GPU: a compute stream all of this library's kernels and copies are ordered on.
 struct DeviceCtx {
   int device = -1;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;         // main stream: fusion kernels, copies, everything by default
+  hipStream_t raster_stream = nullptr;  // smesh_fuse_view rasterises view k+1 here while view k is being fused
   int num_cus = 256;
   unsigned profiling = 0;   // bit s set = bracket slot s with HIP events
   ProfSlot slots[SMESH_PROF_SLOTS];
@@ -53,7 +54,8 @@ struct ProfScope {
   DeviceCtx* ctx;
   int slot;
   hipEvent_t start = nullptr, stop = nullptr;
-  ProfScope(DeviceCtx* c, int s);
+  hipStream_t st;
+  ProfScope(DeviceCtx* c, int s, hipStream_t stream = nullptr);
   ~ProfScope();
 };
 

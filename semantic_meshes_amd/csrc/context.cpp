@@ -40,6 +40,7 @@ int get_ctx(int device, DeviceCtx** out) {
     auto ctx = std::make_unique<DeviceCtx>();
     ctx->device = device;
     SMESH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SMESH_HIP(hipStreamCreateWithFlags(&ctx->raster_stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     SMESH_HIP(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -49,7 +50,7 @@ int get_ctx(int device, DeviceCtx** out) {
   return SMESH_OK;
 }
 
-ProfScope::ProfScope(DeviceCtx* c, int s) : ctx(c), slot(s) {
+ProfScope::ProfScope(DeviceCtx* c, int s, hipStream_t stream) : ctx(c), slot(s), st(stream ? stream : c->stream) {
   if (!(ctx->profiling & (1u << slot))) return;
   ProfSlot& ps = ctx->slots[slot];
   if (!ps.pool.empty()) {
@@ -62,12 +63,12 @@ ProfScope::ProfScope(DeviceCtx* c, int s) : ctx(c), slot(s) {
       return;
     }
   }
-  (void)hipEventRecord(start, ctx->stream);
+  (void)hipEventRecord(start, st);
 }
 
 ProfScope::~ProfScope() {
   if (!start) return;
-  (void)hipEventRecord(stop, ctx->stream);
+  (void)hipEventRecord(stop, st);
   ctx->slots[slot].pending.emplace_back(start, stop);
 }
 
@@ -113,6 +114,7 @@ int smesh_synchronize(int device) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));
   SMESH_HIP(hipSetDevice(device));
+  SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
   return SMESH_OK;
 }
@@ -127,6 +129,7 @@ int smesh_profile_enable(int device, int enabled) {
 
 static int drain(DeviceCtx* ctx) {
   SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
   for (auto& ps : ctx->slots) {
     for (auto& ev : ps.pending) {

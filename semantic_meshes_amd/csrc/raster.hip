@@ -433,8 +433,9 @@ __global__ __launch_bounds__(256) void k_raster_tile(BinArgs b) {
 
 // Split the key image into the two output planes and re-arm the keys for the next render.
 __global__ void k_resolve(unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx, float* __restrict__ depth,
-                          uint32_t W, uint32_t H) {
+                          uint32_t W, uint32_t H, uint32_t* __restrict__ big_count) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *big_count = 0u;   // the big-triangle queue of this render has been consumed: re-arm it
   if (i >= (uint64_t)W * H) return;
   const uint32_t x = (uint32_t)(i / H), y = (uint32_t)(i - (uint64_t)x * H);
   const uint64_t g = key_index(x, y, H);
@@ -519,12 +520,19 @@ struct smesh_renderer {
   Scratch tile_tables;             // tile_count[ntiles] + tile_offset[ntiles+1]
   std::vector<ImagePair> images;   // pooled output planes
   Scratch own_idx;                 // for the host-output entry point
+  // smesh_fuse_view pipeline: two index/depth slots, rasterised on ctx->raster_stream
+  Scratch fused[2];
+  hipEvent_t ev_rendered[2] = {nullptr, nullptr};   // raster stream: slot is complete
+  hipEvent_t ev_consumed[2] = {nullptr, nullptr};   // main stream: the fusion kernels have read the slot
+  uint64_t fused_seq = 0;
+  bool raster_pending = false;     // work queued on the raster stream since the last synchronisation
+  bool main_pending = false;       // renderer state (keys, scratch) used on the main stream since then
   std::mutex mu;
 };
 
 namespace {
 
-int ensure_keys(smesh_renderer* r, uint64_t W, uint64_t H) {
+int ensure_keys(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st) {
   const uint64_t N = div_up(W, 4) * div_up(H, 4) * 16;   // 4 x 4 blocked layout, padded
   if (N <= r->keys_pixels) return SMESH_OK;
   if (r->keys) SMESH_HIP(hipFree(r->keys));
@@ -532,18 +540,26 @@ int ensure_keys(smesh_renderer* r, uint64_t W, uint64_t H) {
   r->keys_pixels = 0;
   SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&r->keys), N * 8));
   r->keys_pixels = N;
-  hipLaunchKernelGGL(k_fill_keys, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, r->ctx->stream, r->keys, N);
+  hipLaunchKernelGGL(k_fill_keys, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, N);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
 
 // Rasterise into caller-provided device planes (both required).
-int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, float* d_depth) {
+int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, float* d_depth, hipStream_t st = nullptr) {
   DeviceCtx* ctx = r->ctx;
-  hipStream_t st = ctx->stream;
+  if (!st) {
+    // plain render()/render_device(): main stream, after whatever smesh_fuse_view left on the raster stream
+    st = ctx->stream;
+    if (r->raster_pending) {
+      SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
+      r->raster_pending = false;
+    }
+    r->main_pending = true;
+  }
   const uint64_t W = cam->width, H = cam->height, N = W * H;
-  SMESH_TRY(ensure_keys(r, W, H));
-  ProfScope prof(ctx, SMESH_PROF_RASTER);
+  SMESH_TRY(ensure_keys(r, W, H, st));
+  ProfScope prof(ctx, SMESH_PROF_RASTER, st);
   CameraArgs ca;
   memcpy(ca.R, cam->rotation, sizeof ca.R);
   memcpy(ca.t, cam->translation, sizeof ca.t);
@@ -563,9 +579,9 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     static const bool direct = !(getenv("SMESH_RASTER") && std::string(getenv("SMESH_RASTER")) == "tiled");
     const uint32_t tiles_x = (uint32_t)div_up(W, kTW), tiles_y = (uint32_t)div_up(H, kTH);
     const uint64_t ntiles = (uint64_t)tiles_x * tiles_y;
-    SMESH_HIP(hipMemsetAsync(r->big_count, 0, 4, st));
-    const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus * 8);
+    const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
     if (!direct && ntiles <= (1u << 20)) {
+      SMESH_HIP(hipMemsetAsync(r->big_count, 0, 4, st));
       // tiled path: bin (count, scan, fill), big triangles through global atomics, then one workgroup per tile
       SMESH_TRY(r->tile_tables.reserve((2 * ntiles + 1) * 4));
       BinArgs b;
@@ -590,7 +606,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     hipLaunchKernelGGL(k_raster_big, dim3(big_grid), dim3(256), 0, st, a, 0u);
     SMESH_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H);
+  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H, r->big_count);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
@@ -646,6 +662,7 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->big_count), 16);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tri_code), std::max<uint64_t>(F * 4, 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tile_list), std::max<uint64_t>(F * 4 * kMaxTilesPerTri, 16));
+  if (e == hipSuccess) e = hipMemsetAsync(r->big_count, 0, 16, ctx->stream);
   if (e == hipSuccess && V) e = hipMemcpyAsync(r->verts, vertices, V * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -753,6 +770,7 @@ int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_
 int smesh_renderer_destroy(smesh_renderer_t* r) {
   if (!r) return SMESH_OK;
   (void)hipSetDevice(r->ctx->device);
+  (void)hipStreamSynchronize(r->ctx->raster_stream);
   (void)hipStreamSynchronize(r->ctx->stream);
   for (void* p : {(void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
                   (void*)r->big_queue, (void*)r->big_count, (void*)r->tri_code, (void*)r->tile_list})
@@ -760,6 +778,11 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   for (auto& im : r->images) { (void)hipFree(im.idx); (void)hipFree(im.depth); }
   r->own_idx.release();
   r->tile_tables.release();
+  for (int i = 0; i < 2; i++) {
+    r->fused[i].release();
+    if (r->ev_rendered[i]) (void)hipEventDestroy(r->ev_rendered[i]);
+    if (r->ev_consumed[i]) (void)hipEventDestroy(r->ev_consumed[i]);
+  }
   delete r;
   return SMESH_OK;
 }
@@ -835,10 +858,43 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
   const uint64_t W = cam->width, H = cam->height, N = W * H;
-  SMESH_TRY(r->own_idx.reserve(N * 8));
-  uint32_t* d_idx = static_cast<uint32_t*>(r->own_idx.ptr);
+  // Optional two-stage pipeline over two HIP streams (SMESH_FUSE_PIPELINE=1): the rasteriser of this view
+  // runs on the raster stream while the main stream is still fusing the previous view; events hand the index
+  // image over and back.  Measured on cfg2 it gains only ~2 % (5358 vs 5240 views/s): the rasteriser's 64-bit
+  // atomics and the scatter-add's float atomics contend for the same memory-side path and each kernel gets
+  // slower by about what the overlap saves, so it is off by default (and kernel timings stay clean).
+  static const bool pipelined = getenv("SMESH_FUSE_PIPELINE") && atoi(getenv("SMESH_FUSE_PIPELINE")) != 0;
+  const int slot = pipelined ? (int)(r->fused_seq & 1u) : 0;
+  hipStream_t rst = pipelined ? ctx->raster_stream : ctx->stream;
+  if (pipelined) {
+    for (int i = 0; i < 2; i++) {
+      if (!r->ev_rendered[i]) SMESH_HIP(hipEventCreateWithFlags(&r->ev_rendered[i], hipEventDisableTiming));
+      if (!r->ev_consumed[i]) SMESH_HIP(hipEventCreateWithFlags(&r->ev_consumed[i], hipEventDisableTiming));
+    }
+    if (r->main_pending) {   // a plain render() used the renderer's scratch on the main stream
+      SMESH_HIP(hipStreamSynchronize(ctx->stream));
+      r->main_pending = false;
+    }
+  } else if (r->raster_pending) {
+    SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
+    r->raster_pending = false;
+  }
+  if (r->fused[slot].bytes < N * 8) {
+    // growing a slot frees the old buffer: nothing may still be reading it
+    SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
+    SMESH_HIP(hipStreamSynchronize(ctx->stream));
+    SMESH_TRY(r->fused[slot].reserve(N * 8));
+  } else if (pipelined && r->fused_seq >= 2) {
+    SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, r->ev_consumed[slot], 0));   // view k-2 has been fused
+  }
+  uint32_t* d_idx = static_cast<uint32_t*>(r->fused[slot].ptr);
   float* d_depth = reinterpret_cast<float*>(d_idx + N);
-  SMESH_TRY(render_into(r, cam, d_idx, d_depth));
+  SMESH_TRY(render_into(r, cam, d_idx, d_depth, rst));
+  if (pipelined) {
+    r->raster_pending = true;
+    SMESH_HIP(hipEventRecord(r->ev_rendered[slot], ctx->raster_stream));
+    SMESH_HIP(hipStreamWaitEvent(ctx->stream, r->ev_rendered[slot], 0));
+  }
   const float* d_probs = probs;
   const float* d_w = weights;
   if (memkind == SMESH_MEM_HOST) {
@@ -854,7 +910,10 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
       d_w = static_cast<const float*>(sw.ptr);
     }
   }
-  return smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H);
+  SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));
+  if (pipelined) SMESH_HIP(hipEventRecord(r->ev_consumed[slot], ctx->stream));
+  r->fused_seq++;
+  return SMESH_OK;
 }
 
 }  // extern "C"
