@@ -59,3 +59,27 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def host_path(name="cfg2", views=10):
+    """render() + add(device indices, HOST numpy probs): the reference's usual calling convention
+    (colorize_cityscapes_mesh.py:65-67); every view crosses PCIe (pageable memory)."""
+    mesh, cams, C = synth.scene(name)
+    W, H = cams[0].resolution
+    r = render.triangles(mesh)
+    agg = fusion.MeshAggregator(len(mesh.faces), C)
+    probs = np.asarray(synth.device_probs(W, H, C, 5))
+    hwc = np.ascontiguousarray(probs.transpose(1, 0, 2))        # network layout (H,W,C)
+    for label, p in (("contiguous (W,H,C)", probs), ("transposed view of (H,W,C)", hwc.transpose(1, 0, 2))):
+        idx, _ = r.render(cams[0]); agg.add(idx, p); _lib.synchronize(0)
+        t0 = time.perf_counter()
+        for k in range(views):
+            idx, _ = r.render(cams[k])
+            agg.add(idx, p)
+        _lib.synchronize(0)
+        dt = time.perf_counter() - t0
+        print("host probs, %s: %.2f ms/view -> %.1f views/s (%.1f GB/s over PCIe)" % (label, 1e3 * dt / views, views / dt, views * p.nbytes / dt / 1e9))
+
+
+if __name__ == "__main__" and len(sys.argv) > 3 and sys.argv[3] == "host":
+    host_path()
