@@ -869,6 +869,7 @@ struct smesh_aggregator {
   Scratch nm_idx, nm_probs, nm_w;        // normalised (contiguous) copies
   Scratch fb_w, fb_amax;                 // fallback path scratch
   Scratch pw;                            // per-pixel weight image of the current view
+  hipEvent_t ev_staged = nullptr;        // host inputs have been copied into the staging buffers
   Scratch out_tmp;                       // get(): normalised result before the D2H copy
   std::mutex mu;
 };
@@ -1080,6 +1081,7 @@ int smesh_aggregator_destroy(smesh_aggregator_t* a) {
   (void)hipStreamSynchronize(a->ctx->stream);
   (void)hipFree(a->acc);
   (void)hipFree(a->count);
+  if (a->ev_staged) (void)hipEventDestroy(a->ev_staged);
   for (Scratch* s : {&a->st_idx, &a->st_probs, &a->st_w, &a->nm_idx, &a->nm_probs, &a->nm_w, &a->fb_w, &a->fb_amax, &a->pw, &a->out_tmp})
     s->release();
   delete a;
@@ -1129,9 +1131,16 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
     SMESH_TRY(stage_in(ctx, a->st_w, weights, span * 4, &p));
     d_w = static_cast<const float*>(p);
   }
+  const bool any_host = imem == SMESH_MEM_HOST || pmem == SMESH_MEM_HOST || (weights && wmem == SMESH_MEM_HOST);
+  if (any_host) {
+    // inputs are never retained after return (Fusion.h:45-47): the caller may overwrite its host arrays as
+    // soon as we return, so wait for the staging copies (only the copies -- the kernels run on)
+    if (!a->ev_staged) SMESH_HIP(hipEventCreateWithFlags(&a->ev_staged, hipEventDisableTiming));
+    SMESH_HIP(hipEventRecord(a->ev_staged, ctx->stream));
+  }
   SMESH_TRY(add_device(a, d_idx, idx_dtype, is, d_probs, ps, d_w, ws, W, H));
-  // host buffers may be reused by the caller as soon as we return; pageable H2D copies have already
-  // been consumed into the staging buffers, device inputs must stay valid until the stream drains
+  if (any_host) SMESH_HIP(hipEventSynchronize(a->ev_staged));
+  // device inputs must stay valid until the kernels that read them have run
   if (imem == SMESH_MEM_DEVICE || pmem == SMESH_MEM_DEVICE || (weights && wmem == SMESH_MEM_DEVICE)) {
     // inputs are never retained after return (Fusion.h:45-47): wait for the kernels that read them
     SMESH_HIP(hipStreamSynchronize(ctx->stream));

@@ -909,6 +909,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
       SMESH_HIP(hipMemcpyAsync(sw.ptr, weights, N * 4, hipMemcpyHostToDevice, ctx->stream));
       d_w = static_cast<const float*>(sw.ptr);
     }
+    SMESH_HIP(hipStreamSynchronize(ctx->stream));   // the caller may reuse its host arrays once we return
   }
   SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));
   if (pipelined) SMESH_HIP(hipEventRecord(r->ev_consumed[slot], ctx->stream));

@@ -64,6 +64,17 @@ class DeviceArray:
             "strides": tuple(s * self.dtype.itemsize for s in self.strides),
         }
 
+    def __dlpack_device__(self):
+        from . import dlpack
+        return (dlpack.kDLROCM, self.device)
+
+    def __dlpack__(self, stream=None, **kwargs):
+        """DLPack capsule over the HBM buffer (what the reference's render() returns, Renderer.h:37-38).
+        The producing stream is synchronised first: the consumer may use any stream."""
+        from . import dlpack
+        _lib.synchronize(self.device)
+        return dlpack.to_capsule(self.ptr, self.shape, self.strides, self.dtype, dlpack.kDLROCM, self.device, self)
+
     def transpose(self, *axes):
         """Stride permutation without a copy (callers transpose (H,W,C) network output to (W,H,C))."""
         if len(axes) == 1 and hasattr(axes[0], "__len__"):
@@ -160,6 +171,12 @@ def describe(obj, want_ndim, what):
                 raise ValueError("%s: strides are not a multiple of the item size" % what)
             strides = tuple(b // dtype.itemsize for b in bstr)
         mem, keep = _lib.MEM_DEVICE, obj
+    elif type(obj).__name__ == "PyCapsule" or (hasattr(obj, "__dlpack__") and not hasattr(obj, "__array_interface__")
+                                                and not isinstance(obj, np.ndarray)):
+        from . import dlpack
+        imp = dlpack.Imported(obj if type(obj).__name__ == "PyCapsule" else obj.__dlpack__())
+        shape, dtype, strides, ptr = imp.shape, imp.dtype, imp.strides, imp.ptr
+        mem, keep = (_lib.MEM_DEVICE if imp.on_device else _lib.MEM_HOST), imp
     else:
         a = np.asarray(obj)
         if a.ndim == want_ndim and a.size:

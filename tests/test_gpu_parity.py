@@ -362,3 +362,17 @@ def test_annotation_renderer_matches_oracle(sm, oracle):
     got_i64 = agg.renderer().render(np.asarray(idx2).astype(np.int64).T.copy().T, bg)   # host, int64, strided
     np.testing.assert_array_equal(got_i64, got)
     assert (got[np.asarray(idx2) == BG] == bg).all()
+
+
+def test_dlpack_export_feeds_add(sm, oracle):
+    """render() output exported as a DLPack capsule (as the reference returns it) is accepted by add()."""
+    mesh, cams = small_scene()
+    C, P = 5, len(mesh.faces)
+    rng = np.random.default_rng(4)
+    r = sm.render.triangles(mesh)
+    idx, _ = r.render(cams[0])
+    probs = random_probs(rng, *cams[0].resolution, C)
+    a1, a2 = sm.fusion.MeshAggregator(P, C), sm.fusion.MeshAggregator(P, C)
+    a1.add(idx, probs)
+    a2.add(idx.__dlpack__(), probs)          # capsule over HBM, kDLROCM
+    np.testing.assert_allclose(a1.get_raw(), a2.get_raw(), rtol=1e-5, atol=1e-7)   # float atomics: order differs run to run
