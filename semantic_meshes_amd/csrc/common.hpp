@@ -69,4 +69,17 @@ struct Scratch {
 
 inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// Per-triangle record the rasteriser leaves for the triangle-order fusion (smesh_fuse_view):
+//   kind 1 (small): bounding box at (x0, y0) of at most 8 x 8 pixels; bit (dx * 8 + dy) of `mask` is set when
+//                   the triangle emitted a fragment at (x0 + dx, y0 + dy) (it may still have lost the depth test);
+//   kind 2 (big):   bounding box (x0, y0) .. (x1, y1) with x1 = mask & 0xFFFF, y1 = (mask >> 16) & 0xFFFF;
+//   kind 0:         culled / nothing emitted.
+struct TriFrag {
+  uint16_t x0, y0;
+  uint16_t kind;
+  uint16_t pad;
+  unsigned long long mask;
+};
+static_assert(sizeof(TriFrag) == 16, "TriFrag must be 16 bytes");
+
 }  // namespace smesh

@@ -32,6 +32,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <string>
 
 using namespace smesh;
 
@@ -674,6 +675,176 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Triangle-order fusion (smesh_fuse_view with a triangle renderer): the rasteriser left, per triangle, the set
+// of pixels it emitted (TriFrag).  Every accumulator row is then owned by exactly one lane: NO atomics, no
+// histogram pass (the per-view count is the number of the triangle's fragments that won the depth test), no
+// sort/merge machinery, and the accumulator is read-modify-written once, sequentially, 64 rows per wave.
+// The arithmetic is the reference's, in its order (Mesh.h:94-106): for Sum/Summax the result is bit-identical
+// to the float32 CPU oracle run single-threaded.
+// ------------------------------------------------------------------------------------------------
+struct TriFuseArgs {
+  const TriFrag* frags;
+  const uint32_t* idx;
+  const float* probs;
+  const float* weights;       // may be null
+  float* acc;                 // [P][C] dense
+  uint64_t F;
+  uint32_t C, H;
+  float iew;
+  const uint32_t* big_queue;
+  const uint32_t* big_len;    // queue length of this render (kept by k_resolve)
+  uint32_t big_capacity;
+};
+
+template <int CT, int KIND>
+__global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
+  constexpr int C = CT;
+  __shared__ __attribute__((aligned(16))) float srow[kWave * CT + 4];   // the wave's 64 accumulator rows
+  const int l = threadIdx.x;
+  const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
+  const uint64_t f = f0 + l;
+  TriFrag rec;
+  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
+  if (f < a.F) rec = a.frags[f];
+  // ---- pass 1: which emitted fragments won the depth test?  n = pixels of this primitive in this view
+  unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
+  unsigned long long win = 0ull;
+  uint32_t n = 0;
+  while (__ballot(m != 0ull) != 0ull) {
+    if (m) {
+      const int k = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      const uint64_t pix = (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7);
+      if (a.idx[pix] == (uint32_t)f) { n++; win |= 1ull << k; }
+    }
+  }
+  if (__ballot(win != 0ull) == 0ull) return;   // nothing of these 64 triangles is visible: rows untouched
+
+  // ---- the wave's 64 accumulator rows: one contiguous block, streamed through LDS, one row per lane
+  const int nrows = (int)min((uint64_t)kWave, a.F - f0);
+  float* __restrict__ blk = a.acc + f0 * C;
+  if (nrows == kWave) {
+    const f4* b4 = reinterpret_cast<const f4*>(blk);
+    f4* s4 = reinterpret_cast<f4*>(srow);
+    for (int q = l; q < kWave * C / 4; q += kWave) s4[q] = b4[q];
+  } else {
+    for (int q = l; q < nrows * C; q += kWave) srow[q] = blk[q];
+  }
+  wave_sync();
+  float accr[CT];
+#pragma unroll
+  for (int c = 0; c < C; c++) accr[c] = srow[l * C + c];
+
+  // ---- pass 2: Mesh.h:94-106 for this primitive's pixels, in image order (x, then y)
+  float w0 = 0.0f;
+  if (n) {
+    const float image_weight = 1.0f / ((float)n);                          // Mesh.h:100
+    const float pixel_w = 1.0f;                                            // :101
+    w0 = a.iew * image_weight + (1 - a.iew) * pixel_w;                     // :102
+  }
+  m = win;
+  while (__ballot(m != 0ull) != 0ull) {
+    if (m) {
+      const int k = __ffsll((long long)m) - 1;
+      m &= m - 1ull;
+      const uint64_t pix = (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7);
+      const float* __restrict__ pr = a.probs + pix * C;
+      float p[CT];
+#pragma unroll
+      for (int c = 0; c < C; c++) p[c] = pr[c];
+      float sum = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; c++) sum = sum + p[c];                         // tt::sum, sequential float32
+      if (sum > 0.5f) {                                                     // :98
+        const float w = w0 * (a.weights ? a.weights[pix] : 1.0f);           // :103
+        if (KIND == SMESH_AGG_SUMMAX) {
+          int am = 0;
+#pragma unroll
+          for (int c = 1; c < C; c++) if (p[c] > p[am]) am = c;
+#pragma unroll
+          for (int c = 0; c < C; c++) if (c == am) accr[c] = accr[c] + p[c] * w;
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; c++) accr[c] = accr[c] + contribution<KIND>(p[c], w);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < C; c++) srow[l * C + c] = accr[c];
+  wave_sync();
+  if (nrows == kWave) {
+    f4* b4 = reinterpret_cast<f4*>(blk);
+    const f4* s4 = reinterpret_cast<const f4*>(srow);
+    for (int q = l; q < kWave * C / 4; q += kWave) b4[q] = s4[q];
+  } else {
+    for (int q = l; q < nrows * C; q += kWave) blk[q] = srow[q];
+  }
+}
+
+// Triangles with a bounding box larger than 8 x 8 pixels: one workgroup per triangle, threads over the box.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_fuse_big(TriFuseArgs a) {
+  __shared__ float spart[4 * 64];   // per-wave partial sums of up to 64 classes at a time
+  __shared__ uint32_t scount[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const uint32_t nbig = min(*a.big_len, a.big_capacity);
+  const int C = (int)a.C;
+  for (uint32_t q = blockIdx.x; q < nbig; q += gridDim.x) {
+    const uint32_t f = a.big_queue[q];
+    const TriFrag rec = a.frags[f];
+    if (rec.kind != 2) continue;
+    const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
+    const int bh = y1 - y0 + 1;
+    const long long npx = (long long)(x1 - x0 + 1) * bh;
+    // pass 1: pixels of this primitive in this view
+    uint32_t n = 0;
+    for (long long i = t; i < npx; i += 256) {
+      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+      n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
+    }
+    for (int d = 32; d > 0; d >>= 1) n += (uint32_t)__shfl_xor((int)n, d);
+    __syncthreads();
+    if (lane == 0) scount[wave] = n;
+    __syncthreads();
+    n = scount[0] + scount[1] + scount[2] + scount[3];
+    if (n == 0) continue;
+    const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
+    // pass 2: 64 classes at a time; every thread sums its pixels, waves reduce by shuffles, then LDS
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int cn = min(64, C - c0);
+      for (int c = 0; c < cn; c++) {
+        float part = 0.0f;
+        for (long long i = t; i < npx; i += 256) {
+          const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+          const uint64_t pix = (uint64_t)x * a.H + y;
+          if (a.idx[pix] != f) continue;
+          const float* pr = a.probs + pix * C;
+          float sum = 0.0f;
+          int am = 0;
+          for (int cc = 0; cc < C; cc++) {
+            sum = sum + pr[cc];
+            if (KIND == SMESH_AGG_SUMMAX && pr[cc] > pr[am]) am = cc;
+          }
+          if (!(sum > 0.5f)) continue;
+          const float w = w0 * (a.weights ? a.weights[pix] : 1.0f);
+          if (KIND == SMESH_AGG_SUMMAX) { if (am == c0 + c) part += pr[am] * w; }
+          else part += contribution<KIND>(pr[c0 + c], w);
+        }
+        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
+        if (lane == 0) spart[wave * 64 + c] = part;
+      }
+      __syncthreads();
+      if (t < cn) {
+        const float tot = (spart[t] + spart[64 + t]) + (spart[128 + t] + spart[192 + t]);
+        a.acc[(uint64_t)f * C + c0 + t] += tot;    // this workgroup owns the row: plain read-modify-write
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fallback for class counts whose strip does not fit LDS: per-pixel weights, then a flat scatter.
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
@@ -1036,6 +1207,48 @@ int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_id
   const int64_t is[2] = {(int64_t)H, 1};
   const int64_t ps[3] = {(int64_t)(H * a->C), (int64_t)a->C, 1};
   return add_device(a, d_idx, SMESH_IDX_U32, is, d_probs, ps, d_w, is, W, H);
+}
+
+// Triangle-order fusion entry used by raster.hip's smesh_fuse_view; see k_fuse_tri.
+bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F) {
+  static const bool off = getenv("SMESH_FUSE") && std::string(getenv("SMESH_FUSE")) == "strip";
+  return !off && a->P == F && (a->C == 5 || a->C == 19 || a->C == 40) && a->S == a->C;
+}
+
+int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* big_queue,
+                                    const uint32_t* big_len, uint32_t big_capacity, const uint32_t* d_idx,
+                                    const float* d_probs, const float* d_w, uint64_t H) {
+  DeviceCtx* ctx = a->ctx;
+  hipStream_t st = ctx->stream;
+  if (F == 0) return SMESH_OK;
+  TriFuseArgs t;
+  t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.F = F; t.C = a->C;
+  t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
+  const dim3 grid((uint32_t)div_up(F, kWave)), block(kWave);
+  {
+    ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
+#define SMESH_FT(K)                                                                           \
+    switch (a->C) {                                                                           \
+      case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K>), grid, block, 0, st, t); break;           \
+      case 19: hipLaunchKernelGGL((k_fuse_tri<19, K>), grid, block, 0, st, t); break;          \
+      default: hipLaunchKernelGGL((k_fuse_tri<40, K>), grid, block, 0, st, t); break;          \
+    }
+    switch (a->kind) {
+      case SMESH_AGG_SUM: SMESH_FT(SMESH_AGG_SUM); break;
+      case SMESH_AGG_SUMMAX: SMESH_FT(SMESH_AGG_SUMMAX); break;
+      default: SMESH_FT(SMESH_AGG_MUL); break;
+    }
+#undef SMESH_FT
+    SMESH_HIP(hipGetLastError());
+  }
+  const dim3 gbig((uint32_t)std::max(1, ctx->num_cus));
+  switch (a->kind) {
+    case SMESH_AGG_SUM: hipLaunchKernelGGL(k_fuse_big<SMESH_AGG_SUM>, gbig, dim3(256), 0, st, t); break;
+    case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_fuse_big<SMESH_AGG_SUMMAX>, gbig, dim3(256), 0, st, t); break;
+    default: hipLaunchKernelGGL(k_fuse_big<SMESH_AGG_MUL>, gbig, dim3(256), 0, st, t); break;
+  }
+  SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
 }
 
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a) { return a->ctx; }

@@ -31,6 +31,10 @@ using namespace smesh;
 struct smesh_aggregator;
 int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_idx, const float* d_probs,
                                        const float* d_w, uint64_t W, uint64_t H);
+bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
+int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* big_queue,
+                                    const uint32_t* big_len, uint32_t big_capacity, const uint32_t* d_idx,
+                                    const float* d_probs, const float* d_w, uint64_t H);
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a);
 uint32_t smesh_aggregator_classes(smesh_aggregator* a);
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a);
@@ -185,7 +189,7 @@ struct RasterArgs {
   uint32_t* big_queue;        // triangles deferred to the cooperative kernel
   uint32_t* big_count;
   uint32_t big_capacity;
-  uint32_t small_limit;       // bbox area up to which a single lane walks the triangle
+  TriFrag* frags;             // per-triangle fragment records for the triangle-order fusion (may be null)
   int dbg;                    // development ablation (SMESH_RDBG): 1 = no atomics, 2 = setup only
 };
 
@@ -212,21 +216,48 @@ __device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri&
   atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
 }
 
-// One lane per triangle; triangles with a large bounding box are queued for k_raster_big.
+__device__ __forceinline__ bool shade_key(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y,
+                                          unsigned long long* key) {
+  float z;
+  double b1, b2;
+  if (!shade(t, x, y, &z, a.tex_res ? &b1 : nullptr, &b2)) return false;
+  uint32_t prim = (uint32_t)f;
+  if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
+  *key = ((unsigned long long)__float_as_uint(z) << 32) | prim;
+  return true;
+}
+
+// One lane per triangle; triangles whose bounding box exceeds 8 x 8 pixels are queued for k_raster_big.
+// Besides the depth-tested keys, each triangle leaves a TriFrag record (which pixels it emitted).
 __global__ void k_raster_small(RasterArgs a) {
   const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= a.F) return;
+  TriFrag rec;
+  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   Tri t;
-  if (!load_tri(a, f, t)) return;
-  const uint32_t bw = (uint32_t)(t.x1 - t.x0 + 1), bh = (uint32_t)(t.y1 - t.y0 + 1);
-  if ((uint64_t)bw * bh > a.small_limit) {
-    const uint32_t slot = atomicAdd(a.big_count, 1u);
-    if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
-    return;
+  if (load_tri(a, f, t)) {
+    const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
+    rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
+    if (bw > 8 || bh > 8) {
+      const uint32_t slot = atomicAdd(a.big_count, 1u);
+      if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
+      rec.kind = 2;
+      rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
+    } else if (!(a.dbg & 2)) {
+      unsigned long long mask = 0ull;
+      for (int dx = 0; dx < bw; dx++)
+        for (int dy = 0; dy < bh; dy++) {
+          unsigned long long key;
+          if (shade_key(a, f, t, t.x0 + dx, t.y0 + dy, &key)) {
+            mask |= 1ull << (dx * 8 + dy);
+            if (!(a.dbg & 1)) atomicMin(&a.keys[key_index((uint32_t)(t.x0 + dx), (uint32_t)(t.y0 + dy), a.H)], key);
+          }
+        }
+      rec.kind = mask ? 1 : 0;
+      rec.mask = mask;
+    }
   }
-  if (a.dbg & 2) { if (t.s == 12345.0) a.keys[0] = 0; return; }
-  for (int x = t.x0; x <= t.x1; x++)
-    for (int y = t.y0; y <= t.y1; y++) emit(a, f, t, x, y);
+  if (a.frags) a.frags[f] = rec;
 }
 
 // One workgroup per (queued triangle, 64x64 pixel chunk of its bounding box); lanes run down columns.
@@ -270,17 +301,6 @@ struct BinArgs {
   uint32_t* idx_out;
   float* depth_out;
 };
-
-__device__ __forceinline__ bool shade_key(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y,
-                                          unsigned long long* key) {
-  float z;
-  double b1, b2;
-  if (!shade(t, x, y, &z, a.tex_res ? &b1 : nullptr, &b2)) return false;
-  uint32_t prim = (uint32_t)f;
-  if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
-  *key = ((unsigned long long)__float_as_uint(z) << 32) | prim;
-  return true;
-}
 
 // Adds `active ? 1 : 0` to counter[tile] with one atomic per distinct tile in the wave; returns this
 // lane's slot (old value + rank among the lanes of the same tile).  Must be called by the whole wave.
@@ -435,7 +455,10 @@ __global__ __launch_bounds__(256) void k_raster_tile(BinArgs b) {
 __global__ void k_resolve(unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx, float* __restrict__ depth,
                           uint32_t W, uint32_t H, uint32_t* __restrict__ big_count) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) *big_count = 0u;   // the big-triangle queue of this render has been consumed: re-arm it
+  if (i == 0) {   // the queue of this render has been consumed by the rasteriser: re-arm it, keep its length
+    big_count[1] = big_count[0];
+    big_count[0] = 0u;
+  }
   if (i >= (uint64_t)W * H) return;
   const uint32_t x = (uint32_t)(i / H), y = (uint32_t)(i - (uint64_t)x * H);
   const uint64_t g = key_index(x, y, H);
@@ -515,6 +538,7 @@ struct smesh_renderer {
   uint32_t* big_queue = nullptr;
   uint32_t* big_count = nullptr;
   uint32_t big_capacity = 0;
+  TriFrag* frags = nullptr;        // [F] per-triangle fragment records (direct path)
   uint32_t* tri_code = nullptr;    // [F] tiled path: packed tile range per triangle
   uint32_t* tile_list = nullptr;   // [16 F]
   Scratch tile_tables;             // tile_count[ntiles] + tile_offset[ntiles+1]
@@ -574,7 +598,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     a.faces = r->faces; a.sv = r->sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
     a.keys = r->keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
     a.big_queue = r->big_queue; a.big_count = r->big_count; a.big_capacity = r->big_capacity;
-    a.small_limit = 64;
+    a.frags = r->frags;
     { static const int rdbg = getenv("SMESH_RDBG") ? atoi(getenv("SMESH_RDBG")) : 0; a.dbg = rdbg; }
     static const bool direct = !(getenv("SMESH_RASTER") && std::string(getenv("SMESH_RASTER")) == "tiled");
     const uint32_t tiles_x = (uint32_t)div_up(W, kTW), tiles_y = (uint32_t)div_up(H, kTH);
@@ -660,6 +684,7 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->big_queue), (size_t)r->big_capacity * 4);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->big_count), 16);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->frags), std::max<uint64_t>(F * sizeof(TriFrag), 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tri_code), std::max<uint64_t>(F * 4, 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tile_list), std::max<uint64_t>(F * 4 * kMaxTilesPerTri, 16));
   if (e == hipSuccess) e = hipMemsetAsync(r->big_count, 0, 16, ctx->stream);
@@ -773,7 +798,7 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   (void)hipStreamSynchronize(r->ctx->raster_stream);
   (void)hipStreamSynchronize(r->ctx->stream);
   for (void* p : {(void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
-                  (void*)r->big_queue, (void*)r->big_count, (void*)r->tri_code, (void*)r->tile_list})
+                  (void*)r->big_queue, (void*)r->big_count, (void*)r->tri_code, (void*)r->tile_list, (void*)r->frags})
     if (p) (void)hipFree(p);
   for (auto& im : r->images) { (void)hipFree(im.idx); (void)hipFree(im.depth); }
   r->own_idx.release();
@@ -911,7 +936,14 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
     }
     SMESH_HIP(hipStreamSynchronize(ctx->stream));   // the caller may reuse its host arrays once we return
   }
-  SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));
+  static const bool tiled_raster = getenv("SMESH_RASTER") && std::string(getenv("SMESH_RASTER")) == "tiled";
+  if (!r->texels && !tiled_raster && smesh_aggregator_can_fuse_triangles(a, r->F)) {
+    // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
+    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->frags, r->F, r->big_queue, r->big_count + 1, r->big_capacity,
+                                              d_idx, d_probs, d_w, H));
+  } else {
+    SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));
+  }
   if (pipelined) SMESH_HIP(hipEventRecord(r->ev_consumed[slot], ctx->stream));
   r->fused_seq++;
   return SMESH_OK;

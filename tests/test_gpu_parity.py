@@ -376,3 +376,71 @@ def test_dlpack_export_feeds_add(sm, oracle):
     a1.add(idx, probs)
     a2.add(idx.__dlpack__(), probs)          # capsule over HBM, kDLROCM
     np.testing.assert_allclose(a1.get_raw(), a2.get_raw(), rtol=1e-5, atol=1e-7)   # float atomics: order differs run to run
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax"])
+@pytest.mark.parametrize("C", [5, 19, 40])
+def test_fuse_view_triangle_order_is_bit_exact(sm, oracle, kind, C):
+    """smesh_fuse_view on a triangle renderer takes the triangle-order path (k_fuse_tri): every accumulator row has
+    one owner and the reference's float32 operation order is kept, so the raw accumulator equals the float32
+    single-threaded oracle bit for bit (small triangles only; large ones are tree-reduced, see next test)."""
+    mesh, cams = small_scene(120, 60, 320, 240, views=3)     # ~1.5 px triangles: all bounding boxes <= 8 x 8
+    P = len(mesh.faces)
+    rng = np.random.default_rng(C)
+    r = sm.render.triangles(mesh)
+    agg = sm.fusion.MeshAggregator(P, C, kind, 0.5)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    oagg = oracle.OracleAggregator(P, C, kind, 0.5)             # float32 accumulators, 1 thread (conftest)
+    for cam in cams:
+        probs = random_probs(rng, *cam.resolution, C)
+        weights = rng.random(cam.resolution, dtype=np.float32)
+        agg.fuse_view(r, cam, probs, weights)
+        oagg.add(o.render(cam)[0], probs, weights)
+    np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+    np.testing.assert_array_equal(agg.get().view(np.uint32), oagg.get().view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+def test_fuse_view_mixed_triangle_sizes(sm, oracle, kind):
+    """Large triangles (bounding box > 8 x 8: cooperative k_fuse_big) next to small ones, device-resident probs."""
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(12, 6, 400, 300, views=3)        # ~40 px triangles
+    extra_v = np.array([[-6, -4, -0.5], [6, -4, -0.5], [0, 5, -0.5]], np.float32)   # one huge triangle behind the grid
+    verts = np.concatenate([mesh.vertices, extra_v])
+    faces = np.concatenate([mesh.faces, [[len(mesh.vertices), len(mesh.vertices) + 1, len(mesh.vertices) + 2]]]).astype(np.int32)
+    big = sm.data.Mesh(verts, faces)
+    P, C = len(faces), 19
+    rng = np.random.default_rng(1)
+    r = sm.render.triangles(big)
+    agg = sm.fusion.MeshAggregator(P, C, kind)
+    o = oracle.OracleRenderer(verts, faces)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind)
+        for cam in cams:
+            probs = random_probs(rng, *cam.resolution, C)
+            if kind == "mul":
+                probs = np.maximum(probs, 1e-3).astype(np.float32)
+            agg.fuse_view(r, cam, to_device(probs))
+            oidx = o.render(cam)[0]
+            oagg.add(oidx, probs)
+        assert (oidx == P - 1).sum() > 2000                     # the huge triangle is visible around the grid
+        # Mul keeps float32 LOG-domain sums (LogProb<float>, Fusion.cu:85): with thousands of pixels per primitive
+        # |L| ~ 1e4 and one float32 ulp of L is ~1e-3 relative after exp() -- inherent to the reference's state type
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else 3e-3)
+    finally:
+        oracle.set_accum_double(False)
+
+
+def test_fuse_view_falls_back_for_other_class_counts(sm, oracle):
+    mesh, cams = small_scene()
+    P, C = len(mesh.faces), 7                                   # not one of the register-resident class counts
+    rng = np.random.default_rng(3)
+    r = sm.render.triangles(mesh)
+    agg, oagg = sm.fusion.MeshAggregator(P, C), oracle.OracleAggregator(P, C)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    for cam in cams:
+        probs = random_probs(rng, *cam.resolution, C)
+        agg.fuse_view(r, cam, probs)
+        oagg.add(o.render(cam)[0], probs)
+    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
