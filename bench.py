@@ -140,6 +140,7 @@ def main():
     get_ms = 1e3 * (time.perf_counter() - t1)
     annotated = int((fused.sum(axis=1) > 0.9).sum())
 
+    fuse_kernel = _lib.lib().smesh_last_fuse_kernel().decode()
     scatter_ms, scatter_n = prof_read(device, _lib.PROF_FUSE_SCATTER)
     hist_ms, hist_n = prof_read(device, _lib.PROF_FUSE_HIST)
     raster_ms, raster_n = prof_read(device, _lib.PROF_RASTER)
@@ -150,10 +151,10 @@ def main():
         t_kernel = scatter_ms * 1e-3 / max(scatter_n, 1)
         achieved = bytes_per_view / t_kernel / 1e9 if t_kernel > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "scatter_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "fusion_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(fuse_kernel, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -173,7 +174,9 @@ def main():
                                    % (args.workload, P, args.steps, W, H, C),
                        "sharding": "views dp%d, one RCCL all-reduce of float32[P,C]" % world,
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
-            "roofline": {"kernel": "k_scatter_strip (segmented scatter-add)", "bound": "hbm",
+            "roofline": {"kernel": {"k_fuse_tri": "k_fuse_tri (triangle-order fusion: gather + accumulate, one owner per accumulator row)",
+                                    "k_scatter_strip": "k_scatter_strip (segmented scatter-add)"}.get(fuse_kernel, fuse_kernel),
+                         "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_view),

@@ -170,6 +170,10 @@ int smesh_annotation_renderer_destroy(smesh_annotation_renderer_t* r);
 int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* camera,
                     const float* probs, const float* weights, int memkind);
 
+/* Name of the fusion kernel the last smesh_fuse_view() on this thread dispatched ("k_fuse_tri": triangle-order
+ * gather-accumulate, no atomics; "k_scatter_strip": generic segmented scatter-add).  For reporting. */
+const char* smesh_last_fuse_kernel(void);
+
 /* ---- timing hooks (tracing) -------------------------------------------- */
 /* `slot_mask` is a bitmask of SMESH_PROF_* slots (bit s = slot s; 0 = off, 0xFF = all).
  * For every enabled slot the library brackets the kernels with HIP events on its own stream.

@@ -61,6 +61,7 @@ SIGNATURES = {
     "smesh_annotation_renderer_render": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int, c_void_p, c_void_p, c_int, c_u64, c_u64]),
     "smesh_annotation_renderer_destroy": (c_int, [c_void_p]),
     "smesh_fuse_view": (c_int, [c_void_p, c_void_p, P(CameraPOD), c_void_p, c_void_p, c_int]),
+    "smesh_last_fuse_kernel": (ctypes.c_char_p, []),
     "smesh_profile_enable": (c_int, [c_int, c_int]),
     "smesh_profile_read": (c_int, [c_int, c_int, P(ctypes.c_double), P(c_u64)]),
     "smesh_profile_reset": (c_int, [c_int]),

@@ -694,48 +694,118 @@ struct TriFuseArgs {
   const uint32_t* big_queue;
   const uint32_t* big_len;    // queue length of this render (kept by k_resolve)
   uint32_t big_capacity;
+  uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the rest the big-triangle queue
 };
+
+// Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle, lanes over the box;
+// per-lane partial sums are combined by a butterfly over the wave (so, unlike the small-triangle path, the
+// summation order is a tree) and lane c owns class c of the row.  Runs in the tail blocks of k_fuse_tri.
+template <int CT, int KIND>
+__device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers) {
+  constexpr int C = CT;
+  const int l = threadIdx.x;
+  const uint32_t nbig = min(*a.big_len, a.big_capacity);
+  for (uint32_t q = worker; q < nbig; q += nworkers) {
+    const uint32_t f = a.big_queue[q];
+    const TriFrag rec = a.frags[f];
+    if (rec.kind != 2) continue;
+    const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
+    const int bh = y1 - y0 + 1;
+    const long long npx = (long long)(x1 - x0 + 1) * bh;
+    uint32_t n = 0;
+    for (long long i = l; i < npx; i += kWave) {
+      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+      n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n += (uint32_t)__shfl_xor((int)n, d);
+    if (n == 0) continue;
+    const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
+    float part[CT];
+#pragma unroll
+    for (int c = 0; c < C; c++) part[c] = 0.0f;
+    for (long long i = l; i < npx; i += kWave) {
+      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+      const uint64_t pix = (uint64_t)x * a.H + y;
+      if (a.idx[pix] != f) continue;
+      const float* __restrict__ pr = a.probs + pix * C;
+      float p[CT];
+      float sum = 0.0f;
+#pragma unroll
+      for (int c = 0; c < C; c++) { p[c] = pr[c]; sum = sum + p[c]; }
+      if (!(sum > 0.5f)) continue;
+      const float w = w0 * (a.weights ? a.weights[pix] : 1.0f);
+      if (KIND == SMESH_AGG_SUMMAX) {
+        int am = 0;
+#pragma unroll
+        for (int c = 1; c < C; c++) if (p[c] > p[am]) am = c;
+#pragma unroll
+        for (int c = 0; c < C; c++) if (c == am) part[c] += p[c] * w;
+      } else {
+#pragma unroll
+        for (int c = 0; c < C; c++) part[c] += contribution<KIND>(p[c], w);
+      }
+    }
+    float mine = 0.0f;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+      float v = part[c];
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+      if (l == c) mine = v;
+    }
+    if (l < C) a.acc[(uint64_t)f * C + l] += mine;   // this wave owns the row: plain read-modify-write
+  }
+}
 
 template <int CT, int KIND>
 __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
   constexpr int C = CT;
+  constexpr int PB = CT <= 24 ? 2 : 1;        // pixels whose class vectors are in flight together
+  constexpr int KV = (kWave * CT / 4 + kWave - 1) / kWave;   // float4 per lane of the 64-row block
   __shared__ __attribute__((aligned(16))) float srow[kWave * CT + 4];   // the wave's 64 accumulator rows
   const int l = threadIdx.x;
+  if (blockIdx.x >= a.tri_blocks) {   // tail blocks: the queued big triangles
+    fuse_big_triangles<CT, KIND>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
+    return;
+  }
   const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
   const uint64_t f = f0 + l;
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   if (f < a.F) rec = a.frags[f];
-  // ---- pass 1: which emitted fragments won the depth test?  n = pixels of this primitive in this view
+  auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
+
+  // ---- pass 1: which emitted fragments won the depth test?  n = pixels of this primitive in this view.
+  // Four candidates per lane are checked per round so that their index loads are in flight together.
   unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
   unsigned long long win = 0ull;
   uint32_t n = 0;
   while (__ballot(m != 0ull) != 0ull) {
-    if (m) {
-      const int k = __ffsll((long long)m) - 1;
-      m &= m - 1ull;
-      const uint64_t pix = (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7);
-      if (a.idx[pix] == (uint32_t)f) { n++; win |= 1ull << k; }
+    int k[4];
+    uint32_t got[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      k[j] = -1;
+      if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
+      got[j] = a.idx[k[j] >= 0 ? pixel(k[j]) : 0];   // unconditional (clamped) so that the four loads overlap
     }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (k[j] >= 0 && got[j] == (uint32_t)f) { n++; win |= 1ull << k[j]; }
   }
   if (__ballot(win != 0ull) == 0ull) return;   // nothing of these 64 triangles is visible: rows untouched
 
-  // ---- the wave's 64 accumulator rows: one contiguous block, streamed through LDS, one row per lane
+  // ---- issue together: the wave's 64 accumulator rows (one contiguous block) and the first PB pixels'
+  // class vectors of every lane
   const int nrows = (int)min((uint64_t)kWave, a.F - f0);
   float* __restrict__ blk = a.acc + f0 * C;
+  f4 br[KV];
   if (nrows == kWave) {
     const f4* b4 = reinterpret_cast<const f4*>(blk);
-    f4* s4 = reinterpret_cast<f4*>(srow);
-    for (int q = l; q < kWave * C / 4; q += kWave) s4[q] = b4[q];
-  } else {
-    for (int q = l; q < nrows * C; q += kWave) srow[q] = blk[q];
-  }
-  wave_sync();
-  float accr[CT];
 #pragma unroll
-  for (int c = 0; c < C; c++) accr[c] = srow[l * C + c];
-
-  // ---- pass 2: Mesh.h:94-106 for this primitive's pixels, in image order (x, then y)
+    for (int q = 0; q < KV; q++) br[q] = b4[min(l + q * kWave, kWave * C / 4 - 1)];
+  }
   float w0 = 0.0f;
   if (n) {
     const float image_weight = 1.0f / ((float)n);                          // Mesh.h:100
@@ -743,29 +813,55 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
     w0 = a.iew * image_weight + (1 - a.iew) * pixel_w;                     // :102
   }
   m = win;
+  float accr[CT];
+  bool rows_loaded = false;
   while (__ballot(m != 0ull) != 0ull) {
-    if (m) {
-      const int k = __ffsll((long long)m) - 1;
-      m &= m - 1ull;
-      const uint64_t pix = (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7);
-      const float* __restrict__ pr = a.probs + pix * C;
-      float p[CT];
+    float p[PB][CT];
+    float wt[PB];
+    bool have[PB];
 #pragma unroll
-      for (int c = 0; c < C; c++) p[c] = pr[c];
+    for (int j = 0; j < PB; j++) {
+      have[j] = m != 0ull;
+      int k = 0;
+      if (m) { k = __ffsll((long long)m) - 1; m &= m - 1ull; }
+      const uint64_t pix = have[j] ? pixel(k) : 0;
+      const float* __restrict__ pr = a.probs + pix * C;
+#pragma unroll
+      for (int c = 0; c < C; c++) p[j][c] = pr[c];
+      wt[j] = a.weights ? a.weights[pix] : 1.0f;
+    }
+    if (!rows_loaded) {
+      // park the block in LDS (flat, coalesced) and pick up this lane's row
+      if (nrows == kWave) {
+        f4* s4 = reinterpret_cast<f4*>(srow);
+#pragma unroll
+        for (int q = 0; q < KV; q++)
+          if (l + q * kWave < kWave * C / 4) s4[l + q * kWave] = br[q];
+      } else {
+        for (int q = l; q < nrows * C; q += kWave) srow[q] = blk[q];
+      }
+      wave_sync();
+#pragma unroll
+      for (int c = 0; c < C; c++) accr[c] = srow[l * C + c];
+      rows_loaded = true;
+    }
+    // Mesh.h:94-106 for this primitive's pixels, in image order (x, then y)
+#pragma unroll
+    for (int j = 0; j < PB; j++) {
       float sum = 0.0f;
 #pragma unroll
-      for (int c = 0; c < C; c++) sum = sum + p[c];                         // tt::sum, sequential float32
-      if (sum > 0.5f) {                                                     // :98
-        const float w = w0 * (a.weights ? a.weights[pix] : 1.0f);           // :103
+      for (int c = 0; c < C; c++) sum = sum + p[j][c];                      // tt::sum, sequential float32
+      if (have[j] && sum > 0.5f) {                                          // :98
+        const float w = w0 * wt[j];                                         // :103
         if (KIND == SMESH_AGG_SUMMAX) {
           int am = 0;
 #pragma unroll
-          for (int c = 1; c < C; c++) if (p[c] > p[am]) am = c;
+          for (int c = 1; c < C; c++) if (p[j][c] > p[j][am]) am = c;
 #pragma unroll
-          for (int c = 0; c < C; c++) if (c == am) accr[c] = accr[c] + p[c] * w;
+          for (int c = 0; c < C; c++) if (c == am) accr[c] = accr[c] + p[j][c] * w;
         } else {
 #pragma unroll
-          for (int c = 0; c < C; c++) accr[c] = accr[c] + contribution<KIND>(p[c], w);
+          for (int c = 0; c < C; c++) accr[c] = accr[c] + contribution<KIND>(p[j][c], w);
         }
       }
     }
@@ -779,68 +875,6 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
     for (int q = l; q < kWave * C / 4; q += kWave) b4[q] = s4[q];
   } else {
     for (int q = l; q < nrows * C; q += kWave) blk[q] = srow[q];
-  }
-}
-
-// Triangles with a bounding box larger than 8 x 8 pixels: one workgroup per triangle, threads over the box.
-template <int KIND>
-__global__ __launch_bounds__(256) void k_fuse_big(TriFuseArgs a) {
-  __shared__ float spart[4 * 64];   // per-wave partial sums of up to 64 classes at a time
-  __shared__ uint32_t scount[4];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const uint32_t nbig = min(*a.big_len, a.big_capacity);
-  const int C = (int)a.C;
-  for (uint32_t q = blockIdx.x; q < nbig; q += gridDim.x) {
-    const uint32_t f = a.big_queue[q];
-    const TriFrag rec = a.frags[f];
-    if (rec.kind != 2) continue;
-    const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
-    const int bh = y1 - y0 + 1;
-    const long long npx = (long long)(x1 - x0 + 1) * bh;
-    // pass 1: pixels of this primitive in this view
-    uint32_t n = 0;
-    for (long long i = t; i < npx; i += 256) {
-      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
-      n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
-    }
-    for (int d = 32; d > 0; d >>= 1) n += (uint32_t)__shfl_xor((int)n, d);
-    __syncthreads();
-    if (lane == 0) scount[wave] = n;
-    __syncthreads();
-    n = scount[0] + scount[1] + scount[2] + scount[3];
-    if (n == 0) continue;
-    const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
-    // pass 2: 64 classes at a time; every thread sums its pixels, waves reduce by shuffles, then LDS
-    for (int c0 = 0; c0 < C; c0 += 64) {
-      const int cn = min(64, C - c0);
-      for (int c = 0; c < cn; c++) {
-        float part = 0.0f;
-        for (long long i = t; i < npx; i += 256) {
-          const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
-          const uint64_t pix = (uint64_t)x * a.H + y;
-          if (a.idx[pix] != f) continue;
-          const float* pr = a.probs + pix * C;
-          float sum = 0.0f;
-          int am = 0;
-          for (int cc = 0; cc < C; cc++) {
-            sum = sum + pr[cc];
-            if (KIND == SMESH_AGG_SUMMAX && pr[cc] > pr[am]) am = cc;
-          }
-          if (!(sum > 0.5f)) continue;
-          const float w = w0 * (a.weights ? a.weights[pix] : 1.0f);
-          if (KIND == SMESH_AGG_SUMMAX) { if (am == c0 + c) part += pr[am] * w; }
-          else part += contribution<KIND>(pr[c0 + c], w);
-        }
-        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d);
-        if (lane == 0) spart[wave * 64 + c] = part;
-      }
-      __syncthreads();
-      if (t < cn) {
-        const float tot = (spart[t] + spart[64 + t]) + (spart[128 + t] + spart[192 + t]);
-        a.acc[(uint64_t)f * C + c0 + t] += tot;    // this workgroup owns the row: plain read-modify-write
-      }
-      __syncthreads();
-    }
   }
 }
 
@@ -1224,7 +1258,8 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
   TriFuseArgs t;
   t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.F = F; t.C = a->C;
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
-  const dim3 grid((uint32_t)div_up(F, kWave)), block(kWave);
+  t.tri_blocks = (uint32_t)div_up(F, kWave);
+  const dim3 grid(t.tri_blocks + (uint32_t)std::max(1, ctx->num_cus)), block(kWave);   // + one big-triangle wave per CU
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
 #define SMESH_FT(K)                                                                           \
@@ -1239,13 +1274,6 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
       default: SMESH_FT(SMESH_AGG_MUL); break;
     }
 #undef SMESH_FT
-    SMESH_HIP(hipGetLastError());
-  }
-  const dim3 gbig((uint32_t)std::max(1, ctx->num_cus));
-  switch (a->kind) {
-    case SMESH_AGG_SUM: hipLaunchKernelGGL(k_fuse_big<SMESH_AGG_SUM>, gbig, dim3(256), 0, st, t); break;
-    case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_fuse_big<SMESH_AGG_SUMMAX>, gbig, dim3(256), 0, st, t); break;
-    default: hipLaunchKernelGGL(k_fuse_big<SMESH_AGG_MUL>, gbig, dim3(256), 0, st, t); break;
   }
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;

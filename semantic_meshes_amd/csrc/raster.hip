@@ -701,7 +701,11 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
 
 }  // namespace
 
+static thread_local const char* g_last_fuse_kernel = "none";
+
 extern "C" {
+
+const char* smesh_last_fuse_kernel(void) { return g_last_fuse_kernel; }
 
 int smesh_renderer_create_triangles(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F, int device,
                                     smesh_renderer_t** out) {
@@ -941,7 +945,9 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
     // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
     SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->frags, r->F, r->big_queue, r->big_count + 1, r->big_capacity,
                                               d_idx, d_probs, d_w, H));
+    g_last_fuse_kernel = "k_fuse_tri";
   } else {
+    g_last_fuse_kernel = "k_scatter_strip";
     SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));
   }
   if (pipelined) SMESH_HIP(hipEventRecord(r->ev_consumed[slot], ctx->stream));
