@@ -164,6 +164,17 @@ __device__ __forceinline__ bool shade(const Tri& t, int x, int y, float* z, doub
   return true;
 }
 
+// The coverage part of shade() alone (same expressions, same order).
+__device__ __forceinline__ bool covered(const Tri& t, int x, int y) {
+  const double px = (double)x + 0.5, py = (double)y + 0.5;
+  const double w0 = t.s * eval_edge(t.e0, px, py);
+  if (!(w0 > 0.0 || (w0 == 0.0 && t.own0))) return false;
+  const double w1 = t.s * eval_edge(t.e1, px, py);
+  if (!(w1 > 0.0 || (w1 == 0.0 && t.own1))) return false;
+  const double w2 = t.s * eval_edge(t.e2, px, py);
+  return w2 > 0.0 || (w2 == 0.0 && t.own2);
+}
+
 __device__ __forceinline__ uint32_t texel_of(uint32_t res, double b1, double b2) {
   // TexturedTriangleRenderer.h:34-38; toIndex bijection decided in DESIGN.md (B-5)
   const float u = (float)b1, v = (float)b2;
@@ -178,6 +189,18 @@ __device__ __forceinline__ uint32_t texel_of(uint32_t res, double b1, double b2)
   return (uint32_t)(row * (row + 1) / 2 + tu);
 }
 
+// Fragment queues of the default path: one queue per 32 x 64 pixel screen tile (see k_raster_frag / k_tile_resolve).
+constexpr int kQW = 32, kQH = 64, kQPixels = kQW * kQH;
+constexpr unsigned long long kNullKey = ~0ull;   // loses every depth test, including against the background key
+
+struct FragQueues {
+  unsigned long long* key = nullptr;   // [ntiles * cap] depth-test keys
+  uint16_t* pix = nullptr;             // [ntiles * cap] pixel inside the tile: (x - tile_x0) * kQH + (y - tile_y0)
+  uint32_t* count = nullptr;           // [ntiles] fragments queued (may exceed cap: the excess went to the key image)
+  uint32_t* flag = nullptr;            // [ntiles] nonzero: the global key image holds fragments of this tile
+  uint32_t cap = 0, tiles_y = 0;
+};
+
 struct RasterArgs {
   const int32_t* faces;
   const ScreenVertex* sv;
@@ -190,6 +213,7 @@ struct RasterArgs {
   uint32_t* big_count;
   uint32_t big_capacity;
   TriFrag* frags;             // per-triangle fragment records for the triangle-order fusion (may be null)
+  FragQueues q;               // fragment-queue path only
   int dbg;                    // development ablation (SMESH_RDBG): 1 = no atomics, 2 = setup only
 };
 
@@ -202,7 +226,9 @@ __device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t
   if (i0 < 0 || i1 < 0 || i2 < 0) return false;
   if ((uint64_t)i0 >= a.V || (uint64_t)i1 >= a.V || (uint64_t)i2 >= a.V) return false;
   if (a.tex_res && a.tex_res[f] == 0) return false;
-  return setup_tri(a.sv[i0], a.sv[i1], a.sv[i2], a.W, a.H, t);
+  // all three vertices are fetched before any of them is tested: one memory round trip instead of three
+  const ScreenVertex va = a.sv[i0], vb = a.sv[i1], vc = a.sv[i2];
+  return setup_tri(va, vb, vc, a.W, a.H, t);
 }
 
 __device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y) {
@@ -269,6 +295,12 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a, uint32_t chunk
     Tri t;
     if (!load_tri(a, f, t)) continue;
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
+    if (a.q.flag) {   // fragment-queue path: the tiles under this box must merge the key image
+      const int qx0 = t.x0 / kQW, qy0 = t.y0 / kQH;
+      const int nx = t.x1 / kQW - qx0 + 1, ny = t.y1 / kQH - qy0 + 1;
+      for (int k = threadIdx.x; k < nx * ny; k += 256)
+        a.q.flag[(uint32_t)(qx0 + k / ny) * a.q.tiles_y + (uint32_t)(qy0 + k % ny)] = 1u;
+    }
     const int ty = threadIdx.x & 63, tx = threadIdx.x >> 6;  // 64 rows x 4 columns per pass
     for (int cx = 0; cx < bw; cx += 4) {
       const int x = t.x0 + cx + tx;
@@ -283,172 +315,196 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a, uint32_t chunk
 }
 
 // ------------------------------------------------------------------------------------------------
-// Tiled path: triangles are binned to screen tiles of 16 columns x 32 rows (a tile column is one 128-byte
-// line of each output plane); one workgroup per tile resolves depth in LDS (4 KiB of 64-bit keys,
-// ds_min_u64) and writes both planes coalesced.  No global atomics per fragment, no clear, no split pass.
+// Fragment-queue path (default).  Measured on MI355X (tools/min_bench.hip): a 64-bit atomicMin costs ~39 ps per
+// distinct 64-byte segment a wave instruction touches, i.e. 55 us for the 1.4 M scattered fragments of a cfg2
+// view but 10 us when the lanes of an instruction hit consecutive keys.  One lane per triangle scatters by
+// construction, so the depth test is moved out of global memory: k_raster_frag appends each fragment
+// (key, pixel-in-tile) to the queue of its 32 x 64 pixel screen tile -- slots are reserved with ONE atomic per
+// (wave, distinct tile), the stores of neighbouring lanes land next to each other -- and k_tile_resolve runs
+// the depth test of a tile in LDS (ds_min_u64) and writes the output planes once, coalesced: no global atomic
+// per fragment, no key image to clear or split.  Fragments beyond a queue's capacity and the fragments of big
+// triangles (k_raster_big) still go through the global key image; the tiles they touch are flagged and merge
+// (and re-arm) their part of it.
 // ------------------------------------------------------------------------------------------------
-constexpr int kTW = 16, kTH = 32, kTilePixels = kTW * kTH;
-constexpr uint32_t kSkipCode = 0xFFFFFFFFu;
-constexpr int kMaxTilesPerTri = 16;   // triangles overlapping more tiles take the cooperative big-triangle path
 
-struct BinArgs {
-  RasterArgs r;
-  uint32_t tiles_x, tiles_y, ntiles;
-  uint32_t* tile_count;    // [ntiles]   triangles per tile; reused as the fill cursor
-  uint32_t* tile_offset;   // [ntiles+1] exclusive scan
-  uint32_t* tri_code;      // [F] packed tile range of each triangle (tx0:12 | ty0:12 | nx-1:4 | ny-1:4)
-  uint32_t* tile_list;     // [<= 16 F] triangle ids grouped by tile
-  uint32_t* idx_out;
-  float* depth_out;
-};
+// wave64 inclusive scan in registers: DPP row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31
+// carry the row totals (semantics checked on MI355X by tools/dpp_test.hip).
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
+  int s = (int)v;
+  s += __builtin_amdgcn_update_dpp(0, s, 0x111, 0xF, 0xF, true);
+  s += __builtin_amdgcn_update_dpp(0, s, 0x112, 0xF, 0xF, true);
+  s += __builtin_amdgcn_update_dpp(0, s, 0x114, 0xF, 0xF, true);
+  s += __builtin_amdgcn_update_dpp(0, s, 0x118, 0xF, 0xF, true);
+  s += __builtin_amdgcn_update_dpp(0, s, 0x142, 0xA, 0xF, false);
+  s += __builtin_amdgcn_update_dpp(0, s, 0x143, 0xC, 0xF, false);
+  return (uint32_t)s;
+}
 
-// Adds `active ? 1 : 0` to counter[tile] with one atomic per distinct tile in the wave; returns this
-// lane's slot (old value + rank among the lanes of the same tile).  Must be called by the whole wave.
-// The distinct tiles are found with ballots only (no memory traffic); then ALL leaders issue their atomics
-// in one instruction, so a wave pays one atomic round trip, not one per distinct tile.
-__device__ __forceinline__ uint32_t wave_claim(uint32_t* counter, uint32_t tile, bool active, bool want_slot) {
-  const int lane = threadIdx.x & 63;
+// First half of a slot reservation: groups the lanes with cnt > 0 by tile; every lane learns its offset inside
+// its group (prefix), the group's total and its leader lane.  No memory traffic.  Whole wave must call.
+struct Claim { uint32_t prefix, total; int leader; };
+__device__ __forceinline__ Claim wave_claim_prepare(uint32_t tile, uint32_t cnt) {
+  Claim c; c.prefix = 0u; c.total = 0u; c.leader = 0;
+  const bool active = cnt != 0u;
   unsigned long long todo = __ballot(active);
-  unsigned long long mine = 0ull;   // lanes holding the same tile as this lane
   while (todo) {
     const int first = __ffsll((long long)todo) - 1;
-    const uint32_t t0 = (uint32_t)__shfl((int)tile, first);
-    const unsigned long long same = __ballot(active && tile == t0);
-    if (active && tile == t0) mine = same;
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, first);
+    const bool in = active && tile == t0;
+    const unsigned long long same = __ballot(in);
+    const uint32_t v = in ? cnt : 0u;
+    const uint32_t s = wave_scan_incl(v);
+    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
+    if (in) { c.prefix = s - v; c.total = tot; c.leader = first; }
     todo &= ~same;
   }
-  if (!active) return 0u;
-  const int leader = __ffsll((long long)mine) - 1;
-  const uint32_t cnt = (uint32_t)__popcll(mine);
-  uint32_t base = 0;
-  if (lane == leader) {
-    if (want_slot) base = atomicAdd(&counter[tile], cnt);
-    else atomicAdd(&counter[tile], cnt);
-  }
-  if (!want_slot) return 0u;
-  base = (uint32_t)__shfl((int)base, leader);
-  return base + (uint32_t)__popcll(mine & ((1ull << lane) - 1ull));
+  return c;
 }
 
-// Pass A: one lane per triangle: setup, cull, tile range; count triangles per tile.
-__global__ __launch_bounds__(256) void k_bin_count(BinArgs b) {
-  const RasterArgs& a = b.r;
+__device__ __forceinline__ double flip_sign(double v, uint32_t hi_mask) {
+  return __hiloint2double(__double2hiint(v) ^ (int)hi_mask, __double2loint(v));
+}
+
+// One lane per triangle (bounding box <= 8 x 8, else queued for k_raster_big): coverage walk, slot
+// reservation in the (at most 2 x 2) tiles the box overlaps, then depth per covered sample and the queue stores.
+// The edge functions are shade()'s, regrouped: s * (sign * (a - b)) is +-(a - b) exactly, so the two sign
+// multiplications become one XOR of the sign bit, and b = dy * (px - lx) is hoisted out of the row loop.
+__global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t code = kSkipCode;
-  int tx0 = 0, ty0 = 0, nx = 0, n = 0;
+  const int lane = threadIdx.x & 63;
+  TriFrag rec;
+  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   Tri t;
+  t.x0 = 0; t.y0 = 0;
+  unsigned long long cover = 0ull;
+  uint32_t n0 = 0u, n1 = 0u, n2 = 0u;   // sign-bit masks of the three edge functions
   if (f < a.F && load_tri(a, f, t)) {
-    tx0 = t.x0 / kTW; ty0 = t.y0 / kTH;
-    nx = t.x1 / kTW - tx0 + 1;
-    const int ny = t.y1 / kTH - ty0 + 1;
-    if (nx * ny > kMaxTilesPerTri) {
+    const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
+    rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
+    if (bw > 8 || bh > 8) {
       const uint32_t slot = atomicAdd(a.big_count, 1u);
       if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
-    } else {
-      n = nx * ny;
-      code = ((uint32_t)tx0 << 20) | ((uint32_t)ty0 << 8) | ((uint32_t)(nx - 1) << 4) | (uint32_t)(ny - 1);
+      rec.kind = 2;
+      rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
+    } else if (!(a.dbg & 2)) {
+      n0 = (t.s * t.e0.sign < 0.0) ? 0x80000000u : 0u;
+      n1 = (t.s * t.e1.sign < 0.0) ? 0x80000000u : 0u;
+      n2 = (t.s * t.e2.sign < 0.0) ? 0x80000000u : 0u;
+      // one flattened loop over the box (trip count bw * bh, not max bw x max bh over the wave's lanes)
+      const int area = bw * bh;
+      int dx = 0, dy = 0;
+      for (int k = 0; k < area; k++) {
+        const double px = (double)(t.x0 + dx) + 0.5, py = (double)(t.y0 + dy) + 0.5;
+        const double w0 = flip_sign(t.e0.dx * (py - t.e0.ly) - t.e0.dy * (px - t.e0.lx), n0);
+        const double w1 = flip_sign(t.e1.dx * (py - t.e1.ly) - t.e1.dy * (px - t.e1.lx), n1);
+        const double w2 = flip_sign(t.e2.dx * (py - t.e2.ly) - t.e2.dy * (px - t.e2.lx), n2);
+        const bool in = (w0 > 0.0 || (w0 == 0.0 && t.own0)) & (w1 > 0.0 || (w1 == 0.0 && t.own1)) &
+                        (w2 > 0.0 || (w2 == 0.0 && t.own2));
+        if (in) cover |= 1ull << (dx * 8 + dy);
+        if (++dy == bh) { dy = 0; dx++; }
+      }
     }
   }
-  if (f < a.F) b.tri_code[f] = code;
-  for (int k = 0; __ballot(k < n) != 0ull; k++) {
-    const bool active = k < n;
-    const uint32_t tile = active ? (uint32_t)(tx0 + k % nx) * b.tiles_y + (uint32_t)(ty0 + k / nx) : 0u;
-    wave_claim(b.tile_count, tile, active, false);
+  // split the box at the tile borders: columns dx < bx / rows dy < by belong to tile (tx0, ty0)
+  const uint32_t tx0 = (uint32_t)t.x0 / kQW, ty0 = (uint32_t)t.y0 / kQH;
+  const int bx = (int)(tx0 + 1) * kQW - t.x0, by = (int)(ty0 + 1) * kQH - t.y0;
+  const unsigned long long lox = bx >= 8 ? ~0ull : ((1ull << (8 * bx)) - 1ull);
+  const unsigned long long loy = by >= 8 ? ~0ull : (0x0101010101010101ull * ((1ull << by) - 1ull));
+  const uint32_t T0 = tx0 * a.q.tiles_y + ty0;
+  // quadrant q: bit 0 = next tile in x, bit 1 = next tile in y.  Group, then ALL reservations of the wave in
+  // four back-to-back atomics (one round trip), then fetch the bases from the group leaders.
+  const Claim c0 = wave_claim_prepare(T0, (uint32_t)__popcll(cover & lox & loy));
+  const Claim c1 = wave_claim_prepare(T0 + a.q.tiles_y, (uint32_t)__popcll(cover & ~lox & loy));
+  const Claim c2 = wave_claim_prepare(T0 + 1u, (uint32_t)__popcll(cover & lox & ~loy));
+  const Claim c3 = wave_claim_prepare(T0 + a.q.tiles_y + 1u, (uint32_t)__popcll(cover & ~lox & ~loy));
+  uint32_t g0 = 0u, g1 = 0u, g2 = 0u, g3 = 0u;
+  if (c0.total && lane == c0.leader) g0 = atomicAdd(&a.q.count[T0], c0.total);
+  if (c1.total && lane == c1.leader) g1 = atomicAdd(&a.q.count[T0 + a.q.tiles_y], c1.total);
+  if (c2.total && lane == c2.leader) g2 = atomicAdd(&a.q.count[T0 + 1u], c2.total);
+  if (c3.total && lane == c3.leader) g3 = atomicAdd(&a.q.count[T0 + a.q.tiles_y + 1u], c3.total);
+  uint32_t off0 = (uint32_t)__shfl((int)g0, c0.leader) + c0.prefix;
+  uint32_t off1 = (uint32_t)__shfl((int)g1, c1.leader) + c1.prefix;
+  uint32_t off2 = (uint32_t)__shfl((int)g2, c2.leader) + c2.prefix;
+  uint32_t off3 = (uint32_t)__shfl((int)g3, c3.leader) + c3.prefix;
+  unsigned long long mask = 0ull;
+  for (unsigned long long m = cover; m; m &= m - 1ull) {
+    const int bit = __ffsll((long long)m) - 1;
+    const int dx = bit >> 3, dy = bit & 7;
+    const int x = t.x0 + dx, y = t.y0 + dy;
+    const double px = (double)x + 0.5, py = (double)y + 0.5;
+    const double w0 = flip_sign(t.e0.dx * (py - t.e0.ly) - t.e0.dy * (px - t.e0.lx), n0);
+    const double w1 = flip_sign(t.e1.dx * (py - t.e1.ly) - t.e1.dy * (px - t.e1.lx), n1);
+    const double w2 = flip_sign(t.e2.dx * (py - t.e2.ly) - t.e2.dy * (px - t.e2.lx), n2);
+    const double num = (w0 + w1) + w2;
+    const double den = (w0 * t.iz0 + w1 * t.iz1) + w2 * t.iz2;
+    const float zf = (float)(num / den);
+    unsigned long long key = kNullKey;
+    if (zf > 0.0f && isfinite(zf)) {
+      uint32_t prim = (uint32_t)f;
+      if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], w1 / num, w2 / num);
+      key = ((unsigned long long)__float_as_uint(zf) << 32) | prim;
+      mask |= 1ull << bit;
+    }
+    const bool hx = dx >= bx, hy = dy >= by;
+    uint32_t slot;
+    if (hy) { if (hx) slot = off3++; else slot = off2++; }
+    else    { if (hx) slot = off1++; else slot = off0++; }
+    const uint32_t tx = tx0 + (hx ? 1u : 0u), ty = ty0 + (hy ? 1u : 0u);
+    const uint32_t tile = tx * a.q.tiles_y + ty;
+    if (a.dbg & 1) continue;
+    if (slot < a.q.cap) {
+      const uint64_t e = (uint64_t)tile * a.q.cap + slot;
+      a.q.key[e] = key;
+      a.q.pix[e] = (uint16_t)(((uint32_t)x - tx * kQW) * kQH + ((uint32_t)y - ty * kQH));
+    } else if (key != kNullKey) {
+      atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
+      a.q.flag[tile] = 1u;
+    }
   }
+  if (mask) rec.kind = 1;
+  if (rec.kind == 1) rec.mask = mask;
+  if (a.frags && f < a.F) a.frags[f] = rec;
 }
 
-// Exclusive scan of the tile counts (one workgroup); the counts become zeroed fill cursors.
-__global__ __launch_bounds__(1024) void k_bin_scan(BinArgs b) {
-  __shared__ uint32_t part[1024];
-  const int t = threadIdx.x;
-  const uint32_t per = (b.ntiles + 1023u) / 1024u;
-  const uint32_t lo = min((uint32_t)t * per, b.ntiles), hi = min(lo + per, b.ntiles);
-  uint32_t sum = 0;
-  for (uint32_t i = lo; i < hi; i++) sum += b.tile_count[i];
-  part[t] = sum;
-  __syncthreads();
-  for (int d = 1; d < 1024; d <<= 1) {
-    const uint32_t v = t >= d ? part[t - d] : 0u;
-    __syncthreads();
-    part[t] += v;
-    __syncthreads();
-  }
-  uint32_t run = part[t] - sum;   // exclusive prefix of this thread's chunk
-  for (uint32_t i = lo; i < hi; i++) {
-    const uint32_t c = b.tile_count[i];
-    b.tile_offset[i] = run;
-    b.tile_count[i] = 0;
-    run += c;
-  }
-  if (t == 1023) b.tile_offset[b.ntiles] = part[1023];
-}
-
-// Pass B: write each triangle id into the lists of the tiles it overlaps.
-__global__ __launch_bounds__(256) void k_bin_fill(BinArgs b) {
-  const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t code = f < b.r.F ? b.tri_code[f] : kSkipCode;
-  int tx0 = 0, ty0 = 0, nx = 1, n = 0;
-  if (code != kSkipCode) {
-    tx0 = (int)(code >> 20); ty0 = (int)((code >> 8) & 0xFFFu);
-    nx = (int)((code >> 4) & 0xFu) + 1;
-    n = nx * ((int)(code & 0xFu) + 1);
-  }
-  for (int k = 0; __ballot(k < n) != 0ull; k++) {
-    const bool active = k < n;
-    const uint32_t tile = active ? (uint32_t)(tx0 + k % nx) * b.tiles_y + (uint32_t)(ty0 + k / nx) : 0u;
-    const uint32_t slot = wave_claim(b.tile_count, tile, active, true);
-    if (active) b.tile_list[b.tile_offset[tile] + slot] = (uint32_t)f;
-  }
-}
-
-// One workgroup per tile: depth resolve in LDS, then both planes written once.
-__global__ __launch_bounds__(256) void k_raster_tile(BinArgs b) {
-  const RasterArgs& a = b.r;
-  __shared__ unsigned long long skeys[kTilePixels];
+// One workgroup per tile: depth test in LDS over the tile's queue, then the output planes written once.
+__global__ __launch_bounds__(256) void k_tile_resolve(FragQueues q, unsigned long long* __restrict__ keys,
+                                                      uint32_t* __restrict__ idx_out, float* __restrict__ depth_out,
+                                                      uint32_t W, uint32_t H, uint32_t* __restrict__ big_count) {
+  __shared__ unsigned long long skeys[kQPixels];
   const int t = threadIdx.x;
   const uint32_t tile = blockIdx.x;
-  const uint32_t tx = tile / b.tiles_y, ty = tile - tx * b.tiles_y;
-  const int x0 = (int)tx * kTW, y0 = (int)ty * kTH;
-  const uint32_t off = b.tile_offset[tile];
-  const uint32_t n = b.tile_offset[tile + 1] - off;
-  const bool merge_big = *a.big_count != 0u;   // big triangles went through global atomics into a.keys
-  for (int p = t; p < kTilePixels; p += 256) {
-    const int gx = x0 + (p >> 5), gy = y0 + (p & 31);
+  if (tile == 0 && t == 0) {   // the big-triangle queue of this render has been consumed: re-arm it, keep its length
+    big_count[1] = big_count[0];
+    big_count[0] = 0u;
+  }
+  const uint32_t tx = tile / q.tiles_y, ty = tile - tx * q.tiles_y;
+  const uint32_t x0 = tx * kQW, y0 = ty * kQH;
+  const uint32_t n = min(q.count[tile], q.cap);
+  const bool merge = q.flag[tile] != 0u;
+  for (int p = t; p < kQPixels; p += 256) {
+    const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
     unsigned long long k = kBackgroundKey;
-    if (merge_big && gx < (int)a.W && gy < (int)a.H) {
-      const uint64_t g = key_index((uint32_t)gx, (uint32_t)gy, a.H);
-      k = a.keys[g];
-      a.keys[g] = kBackgroundKey;   // re-armed for the next render
+    if (merge && gx < W && gy < H) {
+      const uint64_t g = key_index(gx, gy, H);
+      k = keys[g];
+      keys[g] = kBackgroundKey;   // re-armed for the next render
     }
     skeys[p] = k;
   }
   __syncthreads();
-  for (uint32_t base = 0; base < n; base += 256) {
-    const uint32_t i = base + t;
-    if (i < n) {
-      const uint64_t f = b.tile_list[off + i];
-      Tri tr;
-      if (load_tri(a, f, tr)) {
-        const int xa = max(tr.x0, x0), xb = min(tr.x1, x0 + kTW - 1);
-        const int ya = max(tr.y0, y0), yb = min(tr.y1, y0 + kTH - 1);
-        for (int x = xa; x <= xb; x++)
-          for (int y = ya; y <= yb; y++) {
-            unsigned long long key;
-            if (shade_key(a, f, tr, x, y, &key)) atomicMin(&skeys[(x - x0) * kTH + (y - y0)], key);
-          }
-      }
-    }
-  }
+  const uint64_t base = (uint64_t)tile * q.cap;
+  for (uint32_t i = (uint32_t)t; i < n; i += 256u) atomicMin(&skeys[q.pix[base + i]], q.key[base + i]);
   __syncthreads();
-  for (int p = t; p < kTilePixels; p += 256) {
-    const int gx = x0 + (p >> 5), gy = y0 + (p & 31);
-    if (gx < (int)a.W && gy < (int)a.H) {
+  for (int p = t; p < kQPixels; p += 256) {
+    const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
+    if (gx < W && gy < H) {
       const unsigned long long k = skeys[p];
-      const uint64_t g = (uint64_t)gx * a.H + gy;
-      b.idx_out[g] = (uint32_t)(k & 0xFFFFFFFFull);
-      b.depth_out[g] = __uint_as_float((uint32_t)(k >> 32));
+      const uint64_t g = (uint64_t)gx * H + gy;
+      idx_out[g] = (uint32_t)(k & 0xFFFFFFFFull);
+      if (depth_out) depth_out[g] = __uint_as_float((uint32_t)(k >> 32));
     }
   }
+  if (t == 0) { q.count[tile] = 0u; q.flag[tile] = 0u; }
 }
 
 // Split the key image into the two output planes and re-arm the keys for the next render.
@@ -465,7 +521,7 @@ __global__ void k_resolve(unsigned long long* __restrict__ keys, uint32_t* __res
   const unsigned long long k = keys[g];
   keys[g] = kBackgroundKey;
   idx[i] = (uint32_t)(k & 0xFFFFFFFFull);
-  depth[i] = __uint_as_float((uint32_t)(k >> 32));
+  if (depth) depth[i] = __uint_as_float((uint32_t)(k >> 32));
 }
 
 __global__ void k_fill_keys(unsigned long long* __restrict__ keys, uint64_t N) {
@@ -535,13 +591,16 @@ struct smesh_renderer {
   std::vector<uint32_t> h_res, h_first;
   unsigned long long* keys = nullptr;
   uint64_t keys_pixels = 0;
-  uint32_t* big_queue = nullptr;
-  uint32_t* big_count = nullptr;
+  // What a render leaves behind for the triangle-order fusion.  Two sets: with SMESH_FUSE_PIPELINE the rasteriser of
+  // view k+1 (raster stream) fills one while the fusion of view k (main stream) still reads the other.
+  struct Side {
+    uint32_t* big_queue = nullptr;   // [big_capacity] triangles with a bounding box > 8 x 8
+    uint32_t* big_count = nullptr;   // [0] fill cursor of the current render, [1] length of the finished one
+    TriFrag* frags = nullptr;        // [F] per-triangle fragment records
+  } side[2];
   uint32_t big_capacity = 0;
-  TriFrag* frags = nullptr;        // [F] per-triangle fragment records (direct path)
-  uint32_t* tri_code = nullptr;    // [F] tiled path: packed tile range per triangle
-  uint32_t* tile_list = nullptr;   // [16 F]
-  Scratch tile_tables;             // tile_count[ntiles] + tile_offset[ntiles+1]
+  FragQueues fq;                   // fragment-queue path: per-tile queues, sized for the largest image seen
+  uint64_t fq_tiles = 0;
   std::vector<ImagePair> images;   // pooled output planes
   Scratch own_idx;                 // for the host-output entry point
   // smesh_fuse_view pipeline: two index/depth slots, rasterised on ctx->raster_stream
@@ -569,8 +628,55 @@ int ensure_keys(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st) {
   return SMESH_OK;
 }
 
-// Rasterise into caller-provided device planes (both required).
-int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, float* d_depth, hipStream_t st = nullptr) {
+enum class RasterPath { Frag, Direct };
+
+RasterPath raster_path() {
+  static const RasterPath p = [] {
+    const char* e = getenv("SMESH_RASTER");
+    const std::string v = e ? e : "";
+    if (v == "direct") return RasterPath::Direct;
+    return RasterPath::Frag;
+  }();
+  return p;
+}
+
+// Per-tile fragment queues.  Capacity per tile: 8 fragments per pixel of the tile (SMESH_FRAG_CAP overrides it;
+// fragments beyond it fall back to the global key image), shrunk if the whole set would exceed 4 GiB.
+// Returns false (queues unusable -> direct path) for images with so many tiles that the capacity would drop under 1024.
+bool ensure_queues(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st, int* status) {
+  *status = SMESH_OK;
+  const uint64_t tiles_x = div_up(W, kQW), tiles_y = div_up(H, kQH), ntiles = tiles_x * tiles_y;
+  uint64_t cap = 8ull * kQPixels;
+  if (const char* e = getenv("SMESH_FRAG_CAP")) cap = std::max<uint64_t>(1, (uint64_t)atoll(e));
+  else {
+    const uint64_t budget = 4ull << 30;
+    if (ntiles * cap * 10 > budget) cap = budget / (ntiles * 10);
+    if (cap < 1024) return false;
+  }
+  if (ntiles > r->fq_tiles || (uint32_t)cap != r->fq.cap) {
+    (void)hipStreamSynchronize(r->ctx->stream);
+    (void)hipStreamSynchronize(r->ctx->raster_stream);
+    for (void* p : {(void*)r->fq.key, (void*)r->fq.pix, (void*)r->fq.count, (void*)r->fq.flag})
+      if (p) (void)hipFree(p);
+    r->fq = FragQueues();
+    r->fq_tiles = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->fq.key), ntiles * cap * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.pix), ntiles * cap * 2);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.count), ntiles * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.flag), ntiles * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(r->fq.count, 0, ntiles * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->fq.flag, 0, ntiles * 4, st);
+    if (e != hipSuccess) { *status = fail_hip(e, "fragment queue allocation", __FILE__, __LINE__); return false; }
+    r->fq.cap = (uint32_t)cap;
+    r->fq_tiles = ntiles;
+  }
+  r->fq.tiles_y = (uint32_t)tiles_y;
+  return true;
+}
+
+// Rasterise into caller-provided device planes (d_depth may be null: index plane only).
+int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, float* d_depth, hipStream_t st = nullptr,
+                int side = 0) {
   DeviceCtx* ctx = r->ctx;
   if (!st) {
     // plain render()/render_device(): main stream, after whatever smesh_fuse_view left on the raster stream
@@ -597,40 +703,30 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     RasterArgs a;
     a.faces = r->faces; a.sv = r->sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
     a.keys = r->keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
-    a.big_queue = r->big_queue; a.big_count = r->big_count; a.big_capacity = r->big_capacity;
-    a.frags = r->frags;
+    a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
+    a.frags = r->side[side].frags;
     { static const int rdbg = getenv("SMESH_RDBG") ? atoi(getenv("SMESH_RDBG")) : 0; a.dbg = rdbg; }
-    static const bool direct = !(getenv("SMESH_RASTER") && std::string(getenv("SMESH_RASTER")) == "tiled");
-    const uint32_t tiles_x = (uint32_t)div_up(W, kTW), tiles_y = (uint32_t)div_up(H, kTH);
-    const uint64_t ntiles = (uint64_t)tiles_x * tiles_y;
     const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
-    if (!direct && ntiles <= (1u << 20)) {
-      SMESH_HIP(hipMemsetAsync(r->big_count, 0, 4, st));
-      // tiled path: bin (count, scan, fill), big triangles through global atomics, then one workgroup per tile
-      SMESH_TRY(r->tile_tables.reserve((2 * ntiles + 1) * 4));
-      BinArgs b;
-      b.r = a;
-      b.tiles_x = tiles_x; b.tiles_y = tiles_y; b.ntiles = (uint32_t)ntiles;
-      b.tile_count = static_cast<uint32_t*>(r->tile_tables.ptr);
-      b.tile_offset = b.tile_count + ntiles;
-      b.tri_code = r->tri_code; b.tile_list = r->tile_list;
-      b.idx_out = d_idx; b.depth_out = d_depth;
-      SMESH_HIP(hipMemsetAsync(b.tile_count, 0, ntiles * 4, st));
-      const dim3 gtri((uint32_t)div_up(r->F, 256));
-      hipLaunchKernelGGL(k_bin_count, gtri, dim3(256), 0, st, b);
-      hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, st, b);
-      hipLaunchKernelGGL(k_bin_fill, gtri, dim3(256), 0, st, b);
+    int qs = SMESH_OK;
+    if (raster_path() == RasterPath::Frag && ensure_queues(r, W, H, st, &qs)) {
+      a.q = r->fq;
+      hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(r->F, 256)), dim3(256), 0, st, a);
+      SMESH_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_raster_big, dim3(big_grid), dim3(256), 0, st, a, 0u);
-      hipLaunchKernelGGL(k_raster_tile, dim3((uint32_t)ntiles), dim3(256), 0, st, b);
+      SMESH_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_tile_resolve, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a.q, r->keys, d_idx,
+                         d_depth, (uint32_t)W, (uint32_t)H, r->side[side].big_count);
       SMESH_HIP(hipGetLastError());
       return SMESH_OK;
     }
+    SMESH_TRY(qs);
     hipLaunchKernelGGL(k_raster_small, dim3((uint32_t)div_up(r->F, 256)), dim3(256), 0, st, a);
     SMESH_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_raster_big, dim3(big_grid), dim3(256), 0, st, a, 0u);
     SMESH_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H, r->big_count);
+  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H,
+                     r->side[side].big_count);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
@@ -666,6 +762,17 @@ int check_camera(const smesh_camera_t* cam) {
   return SMESH_OK;
 }
 
+hipError_t alloc_side(smesh_renderer* r, int i) {
+  smesh_renderer::Side& sd = r->side[i];
+  if (sd.frags) return hipSuccess;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&sd.big_queue), (size_t)r->big_capacity * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sd.big_count), 16);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sd.frags), std::max<uint64_t>(r->F * sizeof(TriFrag), 16));
+  if (e == hipSuccess) e = hipMemsetAsync(sd.big_count, 0, 16, r->ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(r->ctx->stream);
+  return e;
+}
+
 int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F, int device,
                   smesh_renderer** out) {
   if (!out) return fail(SMESH_ERR_INVALID, "out is NULL");
@@ -682,12 +789,7 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->verts), std::max<uint64_t>(V * 12, 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->faces), std::max<uint64_t>(F * 12, 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->big_queue), (size_t)r->big_capacity * 4);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->big_count), 16);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->frags), std::max<uint64_t>(F * sizeof(TriFrag), 16));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tri_code), std::max<uint64_t>(F * 4, 16));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tile_list), std::max<uint64_t>(F * 4 * kMaxTilesPerTri, 16));
-  if (e == hipSuccess) e = hipMemsetAsync(r->big_count, 0, 16, ctx->stream);
+  if (e == hipSuccess) e = alloc_side(r, 0);
   if (e == hipSuccess && V) e = hipMemcpyAsync(r->verts, vertices, V * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -802,11 +904,13 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   (void)hipStreamSynchronize(r->ctx->raster_stream);
   (void)hipStreamSynchronize(r->ctx->stream);
   for (void* p : {(void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
-                  (void*)r->big_queue, (void*)r->big_count, (void*)r->tri_code, (void*)r->tile_list, (void*)r->frags})
+                  (void*)r->side[0].big_queue, (void*)r->side[0].big_count, (void*)r->side[0].frags, (void*)r->side[1].big_queue,
+                  (void*)r->side[1].big_count, (void*)r->side[1].frags})
+    if (p) (void)hipFree(p);
+  for (void* p : {(void*)r->fq.key, (void*)r->fq.pix, (void*)r->fq.count, (void*)r->fq.flag})
     if (p) (void)hipFree(p);
   for (auto& im : r->images) { (void)hipFree(im.idx); (void)hipFree(im.depth); }
   r->own_idx.release();
-  r->tile_tables.release();
   for (int i = 0; i < 2; i++) {
     r->fused[i].release();
     if (r->ev_rendered[i]) (void)hipEventDestroy(r->ev_rendered[i]);
@@ -917,8 +1021,8 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
     SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, r->ev_consumed[slot], 0));   // view k-2 has been fused
   }
   uint32_t* d_idx = static_cast<uint32_t*>(r->fused[slot].ptr);
-  float* d_depth = reinterpret_cast<float*>(d_idx + N);
-  SMESH_TRY(render_into(r, cam, d_idx, d_depth, rst));
+  if (slot == 1) SMESH_HIP(alloc_side(r, 1));
+  SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, rst, slot));   // the fusion only consumes the index plane
   if (pipelined) {
     r->raster_pending = true;
     SMESH_HIP(hipEventRecord(r->ev_rendered[slot], ctx->raster_stream));
@@ -940,10 +1044,10 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
     }
     SMESH_HIP(hipStreamSynchronize(ctx->stream));   // the caller may reuse its host arrays once we return
   }
-  static const bool tiled_raster = getenv("SMESH_RASTER") && std::string(getenv("SMESH_RASTER")) == "tiled";
-  if (!r->texels && !tiled_raster && smesh_aggregator_can_fuse_triangles(a, r->F)) {
+  if (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) {
     // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
-    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->frags, r->F, r->big_queue, r->big_count + 1, r->big_capacity,
+    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->side[slot].big_queue, r->side[slot].big_count + 1,
+                                              r->big_capacity,
                                               d_idx, d_probs, d_w, H));
     g_last_fuse_kernel = "k_fuse_tri";
   } else {

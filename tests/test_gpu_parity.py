@@ -444,3 +444,43 @@ def test_fuse_view_falls_back_for_other_class_counts(sm, oracle):
         agg.fuse_view(r, cam, probs)
         oagg.add(o.render(cam)[0], probs)
     assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("cap", [1, 7, 300])
+def test_render_fragment_queue_overflow(sm, oracle, monkeypatch, cap):
+    """Tiny per-tile fragment queues: most fragments overflow into the global key image and the flagged tiles
+    merge it; small and big triangles mixed, several renders in a row (queues, flags and keys re-armed)."""
+    monkeypatch.setenv("SMESH_FRAG_CAP", str(cap))
+    mesh, cams = small_scene(60, 30, 330, 250, views=3)
+    extra_v = np.array([[-6, -4, -0.5], [6, -4, -0.5], [0, 5, -0.5]], np.float32)
+    verts = np.concatenate([mesh.vertices, extra_v])
+    faces = np.concatenate([mesh.faces, [[len(mesh.vertices), len(mesh.vertices) + 1, len(mesh.vertices) + 2]]]).astype(np.int32)
+    r = sm.render.triangles(sm.data.Mesh(verts, faces))
+    o = oracle.OracleRenderer(verts, faces)
+    for cam in cams + cams[:1]:
+        idx, depth = r.render(cam)
+        oidx, odepth = o.render(cam)
+        np.testing.assert_array_equal(np.asarray(idx), oidx)
+        np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+    monkeypatch.delenv("SMESH_FRAG_CAP")
+    idx, depth = r.render(cams[1])                              # back to the default capacity (queues re-allocated)
+    np.testing.assert_array_equal(np.asarray(idx), o.render(cams[1])[0])
+
+
+@pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE_PIPELINE=1", "SMESH_FUSE=strip"])
+def test_alternative_paths_in_subprocess(knob):
+    """These knobs are read once per process: re-run the render / fuse_view parity tests with the direct rasteriser
+    (global 64-bit atomicMin per fragment), with the two-stream raster/fusion pipeline, and with the generic
+    scatter-add forced behind fuse_view."""
+    import os
+    import subprocess
+    import sys
+    k, v = knob.split("=")
+    env = dict(os.environ, **{k: v})
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "render_small_scene or render_cfg1 or overlap or mixed_triangle or texel_renderer or fuse_view_cfg2"
+    if k != "SMESH_FUSE":
+        sel += " or triangle_order"
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
+                          "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
