@@ -114,6 +114,9 @@ def main():
 
     for i in range(args.warmup):
         agg.fuse_view(renderer, cams[i], probs[i])
+    if dist is not None:   # untimed: RCCL builds its communicator / channels for this message size on first use
+        _lib.synchronize(device)
+        smdist.allreduce_raw(agg)
     barrier()
     agg.reset()
     _lib.check(_lib.lib().smesh_profile_reset(device))
@@ -175,6 +178,7 @@ def main():
                        "sharding": "views dp%d, one RCCL all-reduce of float32[P,C]" % world,
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
             "roofline": {"kernel": {"k_fuse_tri": "k_fuse_tri (triangle-order fusion: gather + accumulate, one owner per accumulator row)",
+                                    "k_fuse_tri_any": "k_fuse_tri_any (triangle-order fusion, run-time class count)",
                                     "k_scatter_strip": "k_scatter_strip (segmented scatter-add)"}.get(fuse_kernel, fuse_kernel),
                          "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -879,6 +879,210 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Triangle-order fusion for ANY class count (run-time C).  Same ownership scheme as k_fuse_tri, but a row is
+// split over a GROUP of G adjacent lanes (G = 1, 2, 4 .. 64: the smallest power of two with C / G <= kSlice), each
+// lane holding a contiguous slice of at most kSlice classes of the accumulator row and of the pixel's class vector
+// in registers: one pass over the probabilities whatever C is.  The don't-care test needs the float32 row sum in
+// class order (Mesh.h:98, tt::sum): the running sum (and the running arg-max for Summax) is handed from lane to
+// lane through the group, each lane adding its own classes one by one, so the order of operations -- and the
+// result -- is the single-threaded reference's.  Loads are 16 bytes wide at 4-byte alignment (rows are only
+// float-aligned).  Big triangles: tail blocks, chunked over kSlice classes (fuse_big_triangles_any).
+// ------------------------------------------------------------------------------------------------
+constexpr int kSlice = 40;
+constexpr uint32_t kSkipPixel = 0x7FC00001u;   // NaN payload in `pw`: pixel dropped by the don't-care test
+
+struct __attribute__((packed, aligned(4))) F4U { float v[4]; };
+
+// Loads n <= kSlice floats at src into dst; 16-byte loads as long as four floats remain.
+__device__ __forceinline__ void load_slice(const float* __restrict__ src, int n, float (&dst)[kSlice]) {
+#pragma unroll
+  for (int j = 0; j < kSlice; j += 4) {
+    if (j + 4 <= n) {
+      const F4U q = *reinterpret_cast<const F4U*>(src + j);
+      dst[j] = q.v[0]; dst[j + 1] = q.v[1]; dst[j + 2] = q.v[2]; dst[j + 3] = q.v[3];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; t++) dst[j + t] = (j + t < n) ? src[j + t] : 0.0f;
+    }
+  }
+}
+
+__device__ __forceinline__ void store_slice(float* __restrict__ dst, int n, const float (&src)[kSlice]) {
+#pragma unroll
+  for (int j = 0; j < kSlice; j += 4) {
+    if (j + 4 <= n) {
+      F4U q;
+      q.v[0] = src[j]; q.v[1] = src[j + 1]; q.v[2] = src[j + 2]; q.v[3] = src[j + 3];
+      *reinterpret_cast<F4U*>(dst + j) = q;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; t++) if (j + t < n) dst[j + t] = src[j + t];
+    }
+  }
+}
+
+// acc slice += contribution of one pixel's class slice
+template <int KIND>
+__device__ __forceinline__ void accumulate_slice(float (&accr)[kSlice], const float (&p)[kSlice], int cw, float w, int am_local) {
+  if (KIND == SMESH_AGG_SUMMAX) {
+#pragma unroll
+    for (int j = 0; j < kSlice; j++) accr[j] = (j == am_local) ? accr[j] + p[j] * w : accr[j];   // select, not an indexed update
+  } else {
+#pragma unroll
+    for (int j = 0; j < kSlice; j++) if (j < cw) accr[j] = accr[j] + contribution<KIND>(p[j], w);
+  }
+}
+
+// Big triangles for any C: one wave per queued triangle, lanes over its pixels.  First sweep: per pixel row sum /
+// arg-max / weight into the per-view scratch images (each lane re-reads only what it wrote itself); then one sweep
+// per kSlice-class chunk with per-lane partial sums and a butterfly over the wave.
+template <int KIND>
+__device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers,
+                                                       float* __restrict__ pw, uint32_t* __restrict__ amax) {
+  const int l = threadIdx.x;
+  const uint32_t C = a.C;
+  const uint32_t nbig = min(*a.big_len, a.big_capacity);
+  for (uint32_t q = worker; q < nbig; q += nworkers) {
+    const uint32_t f = a.big_queue[q];
+    const TriFrag rec = a.frags[f];
+    if (rec.kind != 2) continue;
+    const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
+    const int bh = y1 - y0 + 1;
+    const long long npx = (long long)(x1 - x0 + 1) * bh;
+    uint32_t n = 0;
+    for (long long i = l; i < npx; i += kWave) {
+      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+      n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n += (uint32_t)__shfl_xor((int)n, d);
+    if (n == 0) continue;
+    const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
+    for (long long i = l; i < npx; i += kWave) {
+      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+      const uint64_t pix = (uint64_t)x * a.H + y;
+      if (a.idx[pix] != f) continue;
+      const float* __restrict__ pr = a.probs + pix * C;
+      float sum = 0.0f, best = 0.0f;
+      uint32_t am = 0;
+      for (uint32_t c = 0; c < C; c++) {
+        const float p = pr[c];
+        sum = sum + p;
+        if (KIND == SMESH_AGG_SUMMAX && (c == 0 || p > best)) { best = p; am = c; }
+      }
+      pw[pix] = sum > 0.5f ? w0 * (a.weights ? a.weights[pix] : 1.0f) : __uint_as_float(kSkipPixel);
+      if (KIND == SMESH_AGG_SUMMAX) amax[pix] = am;
+    }
+    for (uint32_t c0 = 0; c0 < C; c0 += kSlice) {
+      const int cw = (int)min((uint32_t)kSlice, C - c0);
+      float part[kSlice];
+#pragma unroll
+      for (int j = 0; j < kSlice; j++) part[j] = 0.0f;
+      for (long long i = l; i < npx; i += kWave) {
+        const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+        const uint64_t pix = (uint64_t)x * a.H + y;
+        if (a.idx[pix] != f) continue;
+        const float w = pw[pix];
+        if (__float_as_uint(w) == kSkipPixel) continue;
+        float p[kSlice];
+        load_slice(a.probs + pix * C + c0, cw, p);
+        const int am_local = KIND == SMESH_AGG_SUMMAX ? (int)amax[pix] - (int)c0 : 0;
+        accumulate_slice<KIND>(part, p, cw, w, am_local);
+      }
+      float mine = 0.0f;
+#pragma unroll
+      for (int j = 0; j < kSlice; j++) {
+        float v = part[j];
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        if (l == j) mine = v;
+      }
+      if (l < cw) a.acc[(uint64_t)f * C + c0 + l] += mine;   // this wave owns the row: plain read-modify-write
+    }
+  }
+}
+
+template <int KIND, int G>
+__global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, float* __restrict__ pw, uint32_t* __restrict__ amax) {
+  constexpr int TPW = kWave / G;   // triangles per wave
+  const int l = threadIdx.x;
+  const uint32_t C = a.C;
+  if (blockIdx.x >= a.tri_blocks) {
+    fuse_big_triangles_any<KIND>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, pw, amax);
+    return;
+  }
+  const int g = l % G;                                   // rank inside the group
+  const uint64_t f = (uint64_t)blockIdx.x * TPW + (uint32_t)(l / G);
+  const uint32_t S = (C + G - 1) / G;                    // classes per lane
+  const uint32_t c_lo = (uint32_t)g * S;
+  const int cw = c_lo < C ? (int)min(S, C - c_lo) : 0;
+  TriFrag rec;
+  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
+  if (f < a.F) rec = a.frags[f];
+  auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
+  // pass 1 (as k_fuse_tri; the lanes of a group do it redundantly -- same addresses, one request)
+  unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
+  unsigned long long win = 0ull;
+  uint32_t n = 0;
+  while (__ballot(m != 0ull) != 0ull) {
+    int k[4];
+    uint32_t got[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      k[j] = -1;
+      if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
+      got[j] = a.idx[k[j] >= 0 ? pixel(k[j]) : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (k[j] >= 0 && got[j] == (uint32_t)f) { n++; win |= 1ull << k[j]; }
+  }
+  if (__ballot(win != 0ull) == 0ull) return;
+  const float w0 = n ? a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f : 0.0f;      // Mesh.h:100-102
+  float* __restrict__ row = a.acc + f * C + c_lo;
+  float accr[kSlice];
+  if (win) load_slice(row, cw, accr);
+  else {
+#pragma unroll
+    for (int j = 0; j < kSlice; j++) accr[j] = 0.0f;
+  }
+  for (m = win; __ballot(m != 0ull) != 0ull; m &= m - 1ull) {   // wave-uniform trip count: shuffles inside
+    const bool have = m != 0ull;
+    const uint64_t pix = have ? pixel(__ffsll((long long)m) - 1) : 0;
+    float p[kSlice];
+    load_slice(a.probs + pix * C + c_lo, have ? cw : 0, p);
+    const float wt = (have && a.weights) ? a.weights[pix] : 1.0f;
+    // row sum (and arg-max) in class order: the running values travel through the group's lanes
+    float s = 0.0f, best = 0.0f;
+    uint32_t am = 0;
+#pragma unroll
+    for (int ph = 0; ph < G; ph++) {
+      if (ph > 0) {
+        const float s_in = __shfl_up(s, 1);
+        const float b_in = KIND == SMESH_AGG_SUMMAX ? __shfl_up(best, 1) : 0.0f;
+        const uint32_t a_in = KIND == SMESH_AGG_SUMMAX ? (uint32_t)__shfl_up((int)am, 1) : 0u;
+        if (g == ph) { s = s_in; best = b_in; am = a_in; }
+      }
+      if (g == ph) {
+#pragma unroll
+        for (int j = 0; j < kSlice; j++)
+          if (j < cw) {
+            s = s + p[j];
+            if (KIND == SMESH_AGG_SUMMAX && ((ph == 0 && j == 0) || p[j] > best)) { best = p[j]; am = c_lo + (uint32_t)j; }
+          }
+      }
+    }
+    if (G > 1) {   // the group's last lane holds the totals
+      const int last = (l / G) * G + (G - 1);
+      s = __shfl(s, last);
+      if (KIND == SMESH_AGG_SUMMAX) am = (uint32_t)__shfl((int)am, last);
+    }
+    if (have && s > 0.5f) accumulate_slice<KIND>(accr, p, cw, w0 * wt, (int)am - (int)c_lo);
+  }
+  if (win) store_slice(row, cw, accr);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fallback for class counts whose strip does not fit LDS: per-pixel weights, then a flat scatter.
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
@@ -1246,27 +1450,54 @@ int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_id
 // Triangle-order fusion entry used by raster.hip's smesh_fuse_view; see k_fuse_tri.
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F) {
   static const bool off = getenv("SMESH_FUSE") && std::string(getenv("SMESH_FUSE")) == "strip";
-  return !off && a->P == F && (a->C == 5 || a->C == 19 || a->C == 40) && a->S == a->C;
+  return !off && a->P == F && a->S == a->C && a->C <= 64u * 40u;   // 64 lanes x kSlice classes per row
 }
 
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* big_queue,
                                     const uint32_t* big_len, uint32_t big_capacity, const uint32_t* d_idx,
-                                    const float* d_probs, const float* d_w, uint64_t H) {
+                                    const float* d_probs, const float* d_w, uint64_t W, uint64_t H) {
   DeviceCtx* ctx = a->ctx;
   hipStream_t st = ctx->stream;
   if (F == 0) return SMESH_OK;
+  const uint64_t N = W * H;
   TriFuseArgs t;
   t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.F = F; t.C = a->C;
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
+  const bool specialised = a->C == 5 || a->C == 19 || a->C == 40;   // row held in registers, block staged through LDS
+  float* pw = nullptr;
+  uint32_t* amax = nullptr;
+  int G = 1;
+  if (!specialised) {
+    while ((a->C + G - 1) / G > (uint32_t)kSlice) G *= 2;   // lanes per accumulator row (can_fuse_triangles: G <= 64)
+    // the big-triangle waves park per-pixel weights (and arg-max) here
+    SMESH_TRY(a->pw.reserve(N * 4));
+    pw = static_cast<float*>(a->pw.ptr);
+    if (a->kind == SMESH_AGG_SUMMAX) {
+      SMESH_TRY(a->fb_amax.reserve(N * 4));
+      amax = static_cast<uint32_t*>(a->fb_amax.ptr);
+    }
+    t.tri_blocks = (uint32_t)div_up(F, kWave / G);
+  }
   const dim3 grid(t.tri_blocks + (uint32_t)std::max(1, ctx->num_cus)), block(kWave);   // + one big-triangle wave per CU
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
+#define SMESH_FA(K)                                                                            \
+    switch (G) {                                                                               \
+      case 1:  hipLaunchKernelGGL((k_fuse_tri_any<K, 1>), grid, block, 0, st, t, pw, amax); break;  \
+      case 2:  hipLaunchKernelGGL((k_fuse_tri_any<K, 2>), grid, block, 0, st, t, pw, amax); break;  \
+      case 4:  hipLaunchKernelGGL((k_fuse_tri_any<K, 4>), grid, block, 0, st, t, pw, amax); break;  \
+      case 8:  hipLaunchKernelGGL((k_fuse_tri_any<K, 8>), grid, block, 0, st, t, pw, amax); break;  \
+      case 16: hipLaunchKernelGGL((k_fuse_tri_any<K, 16>), grid, block, 0, st, t, pw, amax); break; \
+      case 32: hipLaunchKernelGGL((k_fuse_tri_any<K, 32>), grid, block, 0, st, t, pw, amax); break; \
+      default: hipLaunchKernelGGL((k_fuse_tri_any<K, 64>), grid, block, 0, st, t, pw, amax); break; \
+    }
 #define SMESH_FT(K)                                                                           \
     switch (a->C) {                                                                           \
       case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K>), grid, block, 0, st, t); break;           \
       case 19: hipLaunchKernelGGL((k_fuse_tri<19, K>), grid, block, 0, st, t); break;          \
-      default: hipLaunchKernelGGL((k_fuse_tri<40, K>), grid, block, 0, st, t); break;          \
+      case 40: hipLaunchKernelGGL((k_fuse_tri<40, K>), grid, block, 0, st, t); break;          \
+      default: SMESH_FA(K); break;                                                            \
     }
     switch (a->kind) {
       case SMESH_AGG_SUM: SMESH_FT(SMESH_AGG_SUM); break;
@@ -1274,6 +1505,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
       default: SMESH_FT(SMESH_AGG_MUL); break;
     }
 #undef SMESH_FT
+#undef SMESH_FA
   }
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;

@@ -379,11 +379,12 @@ def test_dlpack_export_feeds_add(sm, oracle):
 
 
 @pytest.mark.parametrize("kind", ["sum", "summax"])
-@pytest.mark.parametrize("C", [5, 19, 40])
+@pytest.mark.parametrize("C", [5, 19, 40, 1, 7, 32, 33, 64, 150])
 def test_fuse_view_triangle_order_is_bit_exact(sm, oracle, kind, C):
-    """smesh_fuse_view on a triangle renderer takes the triangle-order path (k_fuse_tri): every accumulator row has
-    one owner and the reference's float32 operation order is kept, so the raw accumulator equals the float32
-    single-threaded oracle bit for bit (small triangles only; large ones are tree-reduced, see next test)."""
+    """smesh_fuse_view on a triangle renderer takes the triangle-order path (k_fuse_tri for C in {5, 19, 40}, the
+    chunked k_fuse_tri_any for every other class count): every accumulator row has one owner and the reference's
+    float32 operation order is kept, so the raw accumulator equals the float32 single-threaded oracle bit for bit
+    (small triangles only; large ones are tree-reduced, see next test)."""
     mesh, cams = small_scene(120, 60, 320, 240, views=3)     # ~1.5 px triangles: all bounding boxes <= 8 x 8
     P = len(mesh.faces)
     rng = np.random.default_rng(C)
@@ -432,9 +433,40 @@ def test_fuse_view_mixed_triangle_sizes(sm, oracle, kind):
         oracle.set_accum_double(False)
 
 
-def test_fuse_view_falls_back_for_other_class_counts(sm, oracle):
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C", [3, 70])
+def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
+    """k_fuse_tri_any incl. its big-triangle waves (single-chunk and multi-chunk rows), all three aggregators."""
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(12, 6, 400, 300, views=2)
+    extra_v = np.array([[-6, -4, -0.5], [6, -4, -0.5], [0, 5, -0.5]], np.float32)
+    verts = np.concatenate([mesh.vertices, extra_v])
+    faces = np.concatenate([mesh.faces, [[len(mesh.vertices), len(mesh.vertices) + 1, len(mesh.vertices) + 2]]]).astype(np.int32)
+    P = len(faces)
+    rng = np.random.default_rng(C)
+    r = sm.render.triangles(sm.data.Mesh(verts, faces))
+    agg = sm.fusion.MeshAggregator(P, C, kind)
+    o = oracle.OracleRenderer(verts, faces)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind)
+        for cam in cams:
+            probs = random_probs(rng, *cam.resolution, C)
+            if kind == "mul":
+                probs = np.maximum(probs, 1e-3).astype(np.float32)
+            agg.fuse_view(r, cam, to_device(probs))
+            oagg.add(o.render(cam)[0], probs)
+        import os
+        if os.environ.get("SMESH_FUSE") != "strip":
+            assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri_any"
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else 3e-3)
+    finally:
+        oracle.set_accum_double(False)
+
+
+def test_fuse_view_user_index_images_take_generic_path(sm, oracle):
     mesh, cams = small_scene()
-    P, C = len(mesh.faces), 7                                   # not one of the register-resident class counts
+    P, C = len(mesh.faces) + 5, 7                               # aggregator larger than the mesh: not triangle-order
     rng = np.random.default_rng(3)
     r = sm.render.triangles(mesh)
     agg, oagg = sm.fusion.MeshAggregator(P, C), oracle.OracleAggregator(P, C)
