@@ -59,9 +59,11 @@ struct CameraArgs {
 };
 
 // ---- vertex stage: float32 rigid transform, double pinhole projection (render/Camera.h:9-13) --------
+// Also opens the render: empties the big-triangle queue (its length stays readable until the next render).
 __global__ void k_project_vertices(const float* __restrict__ verts, uint64_t V, CameraArgs cam,
-                                   ScreenVertex* __restrict__ sv) {
+                                   ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) big_count[0] = 0u;
   if (i >= V) return;
   const float X = verts[3 * i + 0], Y = verts[3 * i + 1], Z = verts[3 * i + 2];
   const float xc = ((cam.R[0] * X + cam.R[1] * Y) + cam.R[2] * Z) + cam.t[0];
@@ -295,12 +297,6 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a, uint32_t chunk
     Tri t;
     if (!load_tri(a, f, t)) continue;
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
-    if (a.q.flag) {   // fragment-queue path: the tiles under this box must merge the key image
-      const int qx0 = t.x0 / kQW, qy0 = t.y0 / kQH;
-      const int nx = t.x1 / kQW - qx0 + 1, ny = t.y1 / kQH - qy0 + 1;
-      for (int k = threadIdx.x; k < nx * ny; k += 256)
-        a.q.flag[(uint32_t)(qx0 + k / ny) * a.q.tiles_y + (uint32_t)(qy0 + k % ny)] = 1u;
-    }
     const int ty = threadIdx.x & 63, tx = threadIdx.x >> 6;  // 64 rows x 4 columns per pass
     for (int cx = 0; cx < bw; cx += 4) {
       const int x = t.x0 + cx + tx;
@@ -466,34 +462,64 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   if (a.frags && f < a.F) a.frags[f] = rec;
 }
 
-// One workgroup per tile: depth test in LDS over the tile's queue, then the output planes written once.
-__global__ __launch_bounds__(256) void k_tile_resolve(FragQueues q, unsigned long long* __restrict__ keys,
-                                                      uint32_t* __restrict__ idx_out, float* __restrict__ depth_out,
-                                                      uint32_t W, uint32_t H, uint32_t* __restrict__ big_count) {
+// One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
+// > 8 x 8: the workgroup scans their queue, keeps those whose box overlaps the tile and shades the overlap, 256
+// samples at a time), then the output planes are written once.
+__global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out) {
   __shared__ unsigned long long skeys[kQPixels];
+  __shared__ uint32_t s_hits[256];
+  __shared__ uint32_t s_nhits;
+  const FragQueues& q = a.q;
   const int t = threadIdx.x;
   const uint32_t tile = blockIdx.x;
-  if (tile == 0 && t == 0) {   // the big-triangle queue of this render has been consumed: re-arm it, keep its length
-    big_count[1] = big_count[0];
-    big_count[0] = 0u;
-  }
+  const uint32_t W = a.W, H = a.H;
   const uint32_t tx = tile / q.tiles_y, ty = tile - tx * q.tiles_y;
   const uint32_t x0 = tx * kQW, y0 = ty * kQH;
   const uint32_t n = min(q.count[tile], q.cap);
   const bool merge = q.flag[tile] != 0u;
+  const uint32_t nbig = min(*a.big_count, a.big_capacity);
   for (int p = t; p < kQPixels; p += 256) {
     const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
     unsigned long long k = kBackgroundKey;
-    if (merge && gx < W && gy < H) {
+    if (merge && gx < W && gy < H) {   // fragments that did not fit the queue went through the global key image
       const uint64_t g = key_index(gx, gy, H);
-      k = keys[g];
-      keys[g] = kBackgroundKey;   // re-armed for the next render
+      k = a.keys[g];
+      a.keys[g] = kBackgroundKey;   // re-armed for the next render
     }
     skeys[p] = k;
   }
+  if (t == 0) s_nhits = 0u;
   __syncthreads();
   const uint64_t base = (uint64_t)tile * q.cap;
   for (uint32_t i = (uint32_t)t; i < n; i += 256u) atomicMin(&skeys[q.pix[base + i]], q.key[base + i]);
+  const int tx1 = (int)min(x0 + kQW, W) - 1, ty1 = (int)min(y0 + kQH, H) - 1;   // last pixel of the tile inside the image
+  for (uint32_t qb = 0; qb < nbig; qb += 256u) {
+    const uint32_t qi = qb + (uint32_t)t;
+    if (qi < nbig) {
+      const uint32_t f = a.big_queue[qi];
+      const TriFrag rec = a.frags[f];
+      const int bx1 = (int)(rec.mask & 0xFFFFu), by1 = (int)((rec.mask >> 16) & 0xFFFFu);
+      if (rec.kind == 2 && (int)rec.x0 <= tx1 && bx1 >= (int)x0 && (int)rec.y0 <= ty1 && by1 >= (int)y0)
+        s_hits[atomicAdd(&s_nhits, 1u)] = f;
+    }
+    __syncthreads();
+    const uint32_t nh = s_nhits;
+    for (uint32_t h = 0; h < nh; h++) {
+      const uint64_t f = s_hits[h];
+      Tri tr;
+      if (!load_tri(a, f, tr)) continue;
+      const int xa = max(tr.x0, (int)x0), xb = min(tr.x1, tx1), ya = max(tr.y0, (int)y0), yb = min(tr.y1, ty1);
+      const int hh = yb - ya + 1, area = (xb - xa + 1) * hh;
+      for (int i = t; i < area; i += 256) {
+        const int x = xa + i / hh, y = ya + i % hh;
+        unsigned long long key;
+        if (shade_key(a, f, tr, x, y, &key)) atomicMin(&skeys[(x - (int)x0) * kQH + (y - (int)y0)], key);
+      }
+    }
+    __syncthreads();
+    if (t == 0) s_nhits = 0u;
+    __syncthreads();
+  }
   __syncthreads();
   for (int p = t; p < kQPixels; p += 256) {
     const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
@@ -509,12 +535,8 @@ __global__ __launch_bounds__(256) void k_tile_resolve(FragQueues q, unsigned lon
 
 // Split the key image into the two output planes and re-arm the keys for the next render.
 __global__ void k_resolve(unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx, float* __restrict__ depth,
-                          uint32_t W, uint32_t H, uint32_t* __restrict__ big_count) {
+                          uint32_t W, uint32_t H) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) {   // the queue of this render has been consumed by the rasteriser: re-arm it, keep its length
-    big_count[1] = big_count[0];
-    big_count[0] = 0u;
-  }
   if (i >= (uint64_t)W * H) return;
   const uint32_t x = (uint32_t)(i / H), y = (uint32_t)(i - (uint64_t)x * H);
   const uint64_t g = key_index(x, y, H);
@@ -595,7 +617,7 @@ struct smesh_renderer {
   // view k+1 (raster stream) fills one while the fusion of view k (main stream) still reads the other.
   struct Side {
     uint32_t* big_queue = nullptr;   // [big_capacity] triangles with a bounding box > 8 x 8
-    uint32_t* big_count = nullptr;   // [0] fill cursor of the current render, [1] length of the finished one
+    uint32_t* big_count = nullptr;   // [0] length of the queue; emptied by the next render's vertex kernel
     TriFrag* frags = nullptr;        // [F] per-triangle fragment records
   } side[2];
   uint32_t big_capacity = 0;
@@ -696,8 +718,11 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   ca.fx = cam->focal[0]; ca.fy = cam->focal[1]; ca.cx = cam->principal[0]; ca.cy = cam->principal[1];
   ca.W = (uint32_t)W; ca.H = (uint32_t)H;
   if (r->V) {
-    hipLaunchKernelGGL(k_project_vertices, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, r->verts, r->V, ca, r->sv);
+    hipLaunchKernelGGL(k_project_vertices, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, r->verts, r->V, ca, r->sv,
+                       r->side[side].big_count);
     SMESH_HIP(hipGetLastError());
+  } else {
+    SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 4, st));
   }
   if (r->F) {
     RasterArgs a;
@@ -712,10 +737,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
       a.q = r->fq;
       hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(r->F, 256)), dim3(256), 0, st, a);
       SMESH_HIP(hipGetLastError());
-      hipLaunchKernelGGL(k_raster_big, dim3(big_grid), dim3(256), 0, st, a, 0u);
-      SMESH_HIP(hipGetLastError());
-      hipLaunchKernelGGL(k_tile_resolve, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a.q, r->keys, d_idx,
-                         d_depth, (uint32_t)W, (uint32_t)H, r->side[side].big_count);
+      hipLaunchKernelGGL(k_tile_resolve, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a, d_idx, d_depth);
       SMESH_HIP(hipGetLastError());
       return SMESH_OK;
     }
@@ -725,8 +747,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     hipLaunchKernelGGL(k_raster_big, dim3(big_grid), dim3(256), 0, st, a, 0u);
     SMESH_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H,
-                     r->side[side].big_count);
+  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
@@ -1046,7 +1067,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   }
   if (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) {
     // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
-    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->side[slot].big_queue, r->side[slot].big_count + 1,
+    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->side[slot].big_queue, r->side[slot].big_count,
                                               r->big_capacity,
                                               d_idx, d_probs, d_w, W, H));
     const uint32_t C = smesh_aggregator_classes(a);

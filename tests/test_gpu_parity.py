@@ -428,7 +428,10 @@ def test_fuse_view_mixed_triangle_sizes(sm, oracle, kind):
         assert (oidx == P - 1).sum() > 2000                     # the huge triangle is visible around the grid
         # Mul keeps float32 LOG-domain sums (LogProb<float>, Fusion.cu:85): with thousands of pixels per primitive
         # |L| ~ 1e4 and one float32 ulp of L is ~1e-3 relative after exp() -- inherent to the reference's state type
-        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else 3e-3)
+        # (1e-2 when the float-atomics scatter-add is forced: its summation order changes from run to run)
+        import os
+        mul_tol = 1e-2 if os.environ.get("SMESH_FUSE") == "strip" else 3e-3
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
         oracle.set_accum_double(False)
 
@@ -459,7 +462,8 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
         import os
         if os.environ.get("SMESH_FUSE") != "strip":
             assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri_any"
-        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else 3e-3)
+        mul_tol = 1e-2 if os.environ.get("SMESH_FUSE") == "strip" else 3e-3
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
         oracle.set_accum_double(False)
 
