@@ -121,7 +121,12 @@ def main():
     agg.reset()
     _lib.check(_lib.lib().smesh_profile_reset(device))
     prof_mask = 0xFF if os.environ.get("SMESH_BENCH_PROFILE_ALL") else (1 << _lib.PROF_FUSE_SCATTER)
-    _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))   # HIP events around the dominant kernel
+    if os.environ.get("SMESH_BENCH_NO_PROFILE"):   # experiment: what do the HIP events around the kernel cost?
+        prof_mask = 0
+    # HIP events on the library's stream around every 8th launch of the dominant kernel (an event pair costs ~4 us
+    # of stream time = 4 % of a view, so not every launch is bracketed)
+    _lib.check(_lib.lib().smesh_profile_sample_every(device, int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8"))))
+    _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.warmup, total_views):
@@ -184,7 +189,7 @@ def main():
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_view),
-                         "avg_launch_us": round(1e6 * t_kernel, 2), "launches": scatter_n,
+                         "avg_launch_us": round(1e6 * t_kernel, 2), "launches_timed": scatter_n,
                          "distinct_primitives_per_view": int(T_mean),
                          "other_kernels_us_per_view": ({"histogram+pixel_weights": round(1e3 * hist_ms / max(args.steps, 1), 2),
                                                         "raster": round(1e3 * raster_ms / max(raster_n, 1), 2)}

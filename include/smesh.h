@@ -171,7 +171,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
                     const float* probs, const float* weights, int memkind);
 
 /* Name of the fusion kernel the last smesh_fuse_view() on this thread dispatched ("k_fuse_tri": triangle-order
- * gather-accumulate, no atomics; "k_scatter_strip": generic segmented scatter-add).  For reporting. */
+ * gather-accumulate, no atomics; "k_fuse_tri_any": the same for any class count; "k_scatter_strip": generic segmented scatter-add).  For reporting. */
 const char* smesh_last_fuse_kernel(void);
 
 /* ---- timing hooks (tracing) -------------------------------------------- */
@@ -184,6 +184,9 @@ const char* smesh_last_fuse_kernel(void);
 #define SMESH_PROF_FINALIZE     3   /* get() normalisation                     */
 #define SMESH_PROF_SLOTS        8
 int smesh_profile_enable(int device, int slot_mask);
+/* Bracket only every n-th region of an enabled slot (default 1 = all): a HIP event pair costs ~4 us of stream
+ * time, 4 % of a cfg2 view.  `launches` of smesh_profile_read counts the bracketed regions. */
+int smesh_profile_sample_every(int device, uint32_t n);
 int smesh_profile_read(int device, int slot, double* total_ms, uint64_t* launches);
 int smesh_profile_reset(int device);
 

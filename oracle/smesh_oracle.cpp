@@ -590,6 +590,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
 // --------------------------------------------------------------------------------------------
 const char* smesh_last_fuse_kernel(void) { return "oracle"; }
 int smesh_profile_enable(int, int) { return SMESH_OK; }
+int smesh_profile_sample_every(int, uint32_t) { return SMESH_OK; }
 int smesh_profile_read(int, int, double* ms, uint64_t* n) { if (ms) *ms = 0; if (n) *n = 0; return SMESH_OK; }
 int smesh_profile_reset(int) { return SMESH_OK; }
 

@@ -63,6 +63,7 @@ SIGNATURES = {
     "smesh_fuse_view": (c_int, [c_void_p, c_void_p, P(CameraPOD), c_void_p, c_void_p, c_int]),
     "smesh_last_fuse_kernel": (ctypes.c_char_p, []),
     "smesh_profile_enable": (c_int, [c_int, c_int]),
+    "smesh_profile_sample_every": (c_int, [c_int, ctypes.c_uint32]),
     "smesh_profile_read": (c_int, [c_int, c_int, P(ctypes.c_double), P(c_u64)]),
     "smesh_profile_reset": (c_int, [c_int]),
     "smesh_synth_probs": (c_int, [c_void_p, c_u64, c_u32, c_u64, c_float, c_int, c_int]),

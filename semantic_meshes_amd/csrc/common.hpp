@@ -33,6 +33,7 @@ struct ProfSlot {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;     // free event pairs
   double total_ms = 0.0;
   uint64_t launches = 0;
+  uint64_t seen = 0;   // regions entered while the slot was enabled (only every `profile_every`-th is bracketed)
 };
 
 // One per GPU: a compute stream all of this library's kernels and copies are ordered on.
@@ -42,6 +43,7 @@ struct DeviceCtx {
   hipStream_t raster_stream = nullptr;  // smesh_fuse_view rasterises view k+1 here while view k is being fused
   int num_cus = 256;
   unsigned profiling = 0;   // bit s set = bracket slot s with HIP events
+  unsigned profile_every = 1;   // ... every n-th region of the slot (an event pair costs ~4 us of stream time)
   ProfSlot slots[SMESH_PROF_SLOTS];
   std::recursive_mutex mu;
 };

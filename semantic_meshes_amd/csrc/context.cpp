@@ -1,6 +1,8 @@
 // context.cpp -- device contexts, error strings, memory helpers and the timing hooks of the C ABI.
 #include "common.hpp"
 
+#include <algorithm>
+
 #include <cstring>
 #include <memory>
 
@@ -53,6 +55,7 @@ int get_ctx(int device, DeviceCtx** out) {
 ProfScope::ProfScope(DeviceCtx* c, int s, hipStream_t stream) : ctx(c), slot(s), st(stream ? stream : c->stream) {
   if (!(ctx->profiling & (1u << slot))) return;
   ProfSlot& ps = ctx->slots[slot];
+  if (ps.seen++ % std::max(1u, ctx->profile_every) != 0) return;
   if (!ps.pool.empty()) {
     start = ps.pool.back().first;
     stop = ps.pool.back().second;
@@ -127,6 +130,14 @@ int smesh_profile_enable(int device, int enabled) {
   return SMESH_OK;
 }
 
+int smesh_profile_sample_every(int device, uint32_t n) {
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  ctx->profile_every = n ? n : 1u;
+  return SMESH_OK;
+}
+
 static int drain(DeviceCtx* ctx) {
   SMESH_HIP(hipSetDevice(ctx->device));
   SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
@@ -164,6 +175,7 @@ int smesh_profile_reset(int device) {
   for (auto& ps : ctx->slots) {
     ps.total_ms = 0.0;
     ps.launches = 0;
+    ps.seen = 0;
   }
   return SMESH_OK;
 }
