@@ -695,6 +695,7 @@ struct TriFuseArgs {
   const uint32_t* big_len;    // queue length of this render (kept by k_resolve)
   uint32_t big_capacity;
   uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the rest the big-triangle queue
+  int dbg;                    // development ablation (SMESH_FDBG): 1 stop after pass 1, 2 no stores, 4 no row loads, 8 no probs loads
 };
 
 // Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle, lanes over the box;
@@ -888,18 +889,34 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
 // result -- is the single-threaded reference's.  Loads are 16 bytes wide at 4-byte alignment (rows are only
 // float-aligned).  Big triangles: tail blocks, chunked over kSlice classes (fuse_big_triangles_any).
 // ------------------------------------------------------------------------------------------------
+// Cross-lane moves in registers (DPP) instead of ds_bpermute: a dependent chain of LDS round trips per pixel made
+// the wide-row kernels latency-bound.  Lanes whose source is disabled or outside the row keep `old`.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
+
 constexpr int kSlice = 40;
 constexpr uint32_t kSkipPixel = 0x7FC00001u;   // NaN payload in `pw`: pixel dropped by the don't-care test
 
-struct __attribute__((packed, aligned(4))) F4U { float v[4]; };
+// float4 at 4-byte alignment: rows are only float-aligned; gfx950 global memory takes dwordx4 at any dword address.
+// (A packed struct gets scalarised: its stores became one write request per lane and dword.)
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef fvec4 fvec4_a4 __attribute__((aligned(4)));
 
 // Loads n <= kSlice floats at src into dst; 16-byte loads as long as four floats remain.
 __device__ __forceinline__ void load_slice(const float* __restrict__ src, int n, float (&dst)[kSlice]) {
 #pragma unroll
   for (int j = 0; j < kSlice; j += 4) {
     if (j + 4 <= n) {
-      const F4U q = *reinterpret_cast<const F4U*>(src + j);
-      dst[j] = q.v[0]; dst[j + 1] = q.v[1]; dst[j + 2] = q.v[2]; dst[j + 3] = q.v[3];
+      const fvec4 q = *reinterpret_cast<const fvec4_a4*>(src + j);
+      dst[j] = q.x; dst[j + 1] = q.y; dst[j + 2] = q.z; dst[j + 3] = q.w;
     } else {
 #pragma unroll
       for (int t = 0; t < 4; t++) dst[j + t] = (j + t < n) ? src[j + t] : 0.0f;
@@ -911,9 +928,9 @@ __device__ __forceinline__ void store_slice(float* __restrict__ dst, int n, cons
 #pragma unroll
   for (int j = 0; j < kSlice; j += 4) {
     if (j + 4 <= n) {
-      F4U q;
-      q.v[0] = src[j]; q.v[1] = src[j + 1]; q.v[2] = src[j + 2]; q.v[3] = src[j + 3];
-      *reinterpret_cast<F4U*>(dst + j) = q;
+      fvec4 q;
+      q.x = src[j]; q.y = src[j + 1]; q.z = src[j + 2]; q.w = src[j + 3];
+      *reinterpret_cast<fvec4_a4*>(dst + j) = q;
     } else {
 #pragma unroll
       for (int t = 0; t < 4; t++) if (j + t < n) dst[j + t] = src[j + t];
@@ -1013,7 +1030,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, float* __
   }
   const int g = l % G;                                   // rank inside the group
   const uint64_t f = (uint64_t)blockIdx.x * TPW + (uint32_t)(l / G);
-  const uint32_t S = (C + G - 1) / G;                    // classes per lane
+  const uint32_t S = G == 1 ? C : (((C + G - 1) / G + 3u) & ~3u);   // classes per lane (whole float4s when the row is split)
   const uint32_t c_lo = (uint32_t)g * S;
   const int cw = c_lo < C ? (int)min(S, C - c_lo) : 0;
   TriFrag rec;
@@ -1057,10 +1074,10 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, float* __
     uint32_t am = 0;
 #pragma unroll
     for (int ph = 0; ph < G; ph++) {
-      if (ph > 0) {
-        const float s_in = __shfl_up(s, 1);
-        const float b_in = KIND == SMESH_AGG_SUMMAX ? __shfl_up(best, 1) : 0.0f;
-        const uint32_t a_in = KIND == SMESH_AGG_SUMMAX ? (uint32_t)__shfl_up((int)am, 1) : 0u;
+      if (ph > 0) {   // from the lane below (wave_shr:1)
+        const float s_in = dpp_f<kDppWaveShr1>(0.0f, s);
+        const float b_in = KIND == SMESH_AGG_SUMMAX ? dpp_f<kDppWaveShr1>(0.0f, best) : 0.0f;
+        const uint32_t a_in = KIND == SMESH_AGG_SUMMAX ? dpp_u<kDppWaveShr1>(0u, am) : 0u;
         if (g == ph) { s = s_in; best = b_in; am = a_in; }
       }
       if (g == ph) {
@@ -1072,7 +1089,13 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, float* __
           }
       }
     }
-    if (G > 1) {   // the group's last lane holds the totals
+    if (G == 2) {          // the group's last lane holds the totals: quad_perm [1,1,3,3]
+      s = dpp_f<0xF5>(0.0f, s);
+      if (KIND == SMESH_AGG_SUMMAX) am = dpp_u<0xF5>(0u, am);
+    } else if (G == 4) {   // quad_perm [3,3,3,3]
+      s = dpp_f<0xFF>(0.0f, s);
+      if (KIND == SMESH_AGG_SUMMAX) am = dpp_u<0xFF>(0u, am);
+    } else if (G > 4) {
       const int last = (l / G) * G + (G - 1);
       s = __shfl(s, last);
       if (KIND == SMESH_AGG_SUMMAX) am = (uint32_t)__shfl((int)am, last);
@@ -1080,6 +1103,207 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, float* __
     if (have && s > 0.5f) accumulate_slice<KIND>(accr, p, cw, w0 * wt, (int)am - (int)c_lo);
   }
   if (win) store_slice(row, cw, accr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Triangle-order fusion for WIDE rows (128 <= C <= 1024): a row no longer belongs to a lane but to the wave.
+// Lane l holds classes 4 (l + 64 k) .. + 3 (k < NCH) of the current accumulator row and of the current pixel's class
+// vector, so every row moves as one coalesced run of 16-byte pieces.  The wave first finds, lane = triangle, the
+// visible pixels of its 64 triangles (pass 1 of k_fuse_tri) and parks them in LDS grouped by triangle; then it
+// walks the visible triangles one after the other (wave-uniform control flow): load the row, add its pixels in
+// image order, store the row.  Per class the additions happen in the reference's order, so the result is still
+// bit-identical.  The don't-care test needs the float32 row sum in class order (Mesh.h:98): the wave first
+// tree-reduces the row and its absolute values; only if that estimate is within its own error bound of 0.5
+// does it replay the additions one class at a time (never for probability rows, whose sums are ~1 or 0).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {   // same value in every lane (read back from lane 63)
+  v += dpp_f<kDppRowShr1>(0.0f, v);
+  v += dpp_f<kDppRowShr2>(0.0f, v);
+  v += dpp_f<kDppRowShr4>(0.0f, v);
+  v += dpp_f<kDppRowShr8>(0.0f, v);
+  v += dpp_f<kDppRowBcast15, 0xA>(0.0f, v);
+  v += dpp_f<kDppRowBcast31, 0xC>(0.0f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// One lane's share of a row: NCH chunks of four classes, chunk k covering classes 4 (l + 64 k) .. + 3.
+template <int NCH>
+__device__ __forceinline__ void load_wide(const float* __restrict__ src, uint32_t C, int l, fvec4 (&v)[NCH]) {
+#pragma unroll
+  for (int k = 0; k < NCH; k++) {
+    const uint32_t c = 4u * ((uint32_t)l + 64u * k);
+    if (c + 4u <= C) v[k] = *reinterpret_cast<const fvec4_a4*>(src + c);
+    else { v[k].x = c < C ? src[c] : 0.0f; v[k].y = c + 1 < C ? src[c + 1] : 0.0f; v[k].z = c + 2 < C ? src[c + 2] : 0.0f; v[k].w = 0.0f; }
+  }
+}
+
+template <int NCH>
+__device__ __forceinline__ void store_wide(float* __restrict__ dst, uint32_t C, int l, const fvec4 (&v)[NCH]) {
+#pragma unroll
+  for (int k = 0; k < NCH; k++) {
+    const uint32_t c = 4u * ((uint32_t)l + 64u * k);
+    if (c + 4u <= C) *reinterpret_cast<fvec4_a4*>(dst + c) = v[k];
+    else {
+      if (c < C) dst[c] = v[k].x;
+      if (c + 1 < C) dst[c + 1] = v[k].y;
+      if (c + 2 < C) dst[c + 2] = v[k].z;
+    }
+  }
+}
+
+// Mesh.h:94-106 for one pixel whose class vector is spread over the wave (wave-uniform control flow).
+template <int KIND, int NCH>
+__device__ __forceinline__ void fuse_pixel_wide(fvec4 (&ac)[NCH], const fvec4 (&p)[NCH], uint32_t C, int l, float w) {
+  float ps = 0.0f, pa = 0.0f;
+#pragma unroll
+  for (int k = 0; k < NCH; k++) {
+    ps += (p[k].x + p[k].y) + (p[k].z + p[k].w);
+    pa += (fabsf(p[k].x) + fabsf(p[k].y)) + (fabsf(p[k].z) + fabsf(p[k].w));
+  }
+  ps = wave_sum(ps);
+  pa = wave_sum(pa);
+  bool counted = ps > 0.5f;
+  if (!(fabsf(ps - 0.5f) > 1e-4f * (pa + 1.0f))) {
+    // too close to call from a tree sum (or not finite): replay tt::sum, one class at a time
+    float sq = 0.0f;
+    for (uint32_t c = 0; c < C; c++) {
+      const uint32_t q = c >> 2, comp = c & 3u;
+      float v = 0.0f;
+#pragma unroll
+      for (int k = 0; k < NCH; k++)
+        if ((int)(q >> 6) == k) v = comp == 0 ? p[k].x : comp == 1 ? p[k].y : comp == 2 ? p[k].z : p[k].w;
+      sq = sq + __shfl(v, (int)(q & 63u));
+    }
+    counted = sq > 0.5f;
+  }
+  if (!counted) return;
+  if (KIND == SMESH_AGG_SUMMAX) {
+    // first maximum in class order: per lane in order, then across lanes (greater, or equal at a lower class)
+    float best = -INFINITY;
+    uint32_t am = 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+      const uint32_t c = 4u * ((uint32_t)l + 64u * k);
+      const float v[4] = {p[k].x, p[k].y, p[k].z, p[k].w};
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (c + e < C && (am == 0xFFFFFFFFu || v[e] > best)) { best = v[e]; am = c + e; }
+    }
+#define SMESH_ARGMAX_STEP(CTRL, ROWS)                                                                      \
+    {                                                                                                      \
+      const float ob = dpp_f<CTRL, ROWS>(-INFINITY, best);                                                 \
+      const uint32_t oa = dpp_u<CTRL, ROWS>(0xFFFFFFFFu, am);                                              \
+      const bool take = oa != 0xFFFFFFFFu && (am == 0xFFFFFFFFu || ob > best || (ob == best && oa < am));  \
+      if (take) { best = ob; am = oa; }                                                                    \
+    }
+    SMESH_ARGMAX_STEP(kDppRowShr1, 0xF) SMESH_ARGMAX_STEP(kDppRowShr2, 0xF) SMESH_ARGMAX_STEP(kDppRowShr4, 0xF)
+    SMESH_ARGMAX_STEP(kDppRowShr8, 0xF) SMESH_ARGMAX_STEP(kDppRowBcast15, 0xA) SMESH_ARGMAX_STEP(kDppRowBcast31, 0xC)
+#undef SMESH_ARGMAX_STEP
+    am = (uint32_t)__builtin_amdgcn_readlane((int)am, 63);   // lane 63 has seen every lane
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+      const uint32_t c = 4u * ((uint32_t)l + 64u * k);
+      ac[k].x = (am == c) ? ac[k].x + p[k].x * w : ac[k].x;
+      ac[k].y = (am == c + 1) ? ac[k].y + p[k].y * w : ac[k].y;
+      ac[k].z = (am == c + 2) ? ac[k].z + p[k].z * w : ac[k].z;
+      ac[k].w = (am == c + 3) ? ac[k].w + p[k].w * w : ac[k].w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+      ac[k].x = ac[k].x + contribution<KIND>(p[k].x, w);
+      ac[k].y = ac[k].y + contribution<KIND>(p[k].y, w);
+      ac[k].z = ac[k].z + contribution<KIND>(p[k].z, w);
+      ac[k].w = ac[k].w + contribution<KIND>(p[k].w, w);
+    }
+  }
+}
+
+template <int KIND, int NCH>
+__global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, float* __restrict__ pw, uint32_t* __restrict__ amax) {
+  constexpr int B = NCH == 1 ? 4 : 2;      // visible triangles whose rows and first pixels are in flight together
+  __shared__ uint32_t s_pix[kWave * 64];   // visible pixels of the wave's triangles (linear pixel index), grouped by triangle
+  const int l = threadIdx.x;
+  const uint32_t C = a.C;
+  if (blockIdx.x >= a.tri_blocks) {
+    fuse_big_triangles_any<KIND>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, pw, amax);
+    return;
+  }
+  const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
+  const uint64_t f = f0 + l;
+  TriFrag rec;
+  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
+  if (f < a.F) rec = a.frags[f];
+  auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
+  unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
+  unsigned long long win = 0ull;
+  uint32_t n = 0;
+  while (__ballot(m != 0ull) != 0ull) {
+    int k[4];
+    uint32_t got[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      k[j] = -1;
+      if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
+      got[j] = a.idx[k[j] >= 0 ? pixel(k[j]) : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (k[j] >= 0 && got[j] == (uint32_t)f) { n++; win |= 1ull << k[j]; }
+  }
+  unsigned long long vis = __ballot(n != 0u);
+  if (vis == 0ull || (a.dbg & 1)) return;
+  uint32_t incl = n;   // inclusive scan of the pixel counts
+#pragma unroll
+  for (int d = 1; d < kWave; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+    if (l >= d) incl += o;
+  }
+  const uint32_t off = incl - n;
+  {
+    uint32_t j = off;
+    for (m = win; m; m &= m - 1ull) s_pix[j++] = (uint32_t)pixel(__ffsll((long long)m) - 1);
+  }
+  wave_sync();
+
+  while (vis) {
+    // a batch of up to B visible triangles: their accumulator rows and first pixels are requested together
+    int t[B];
+    uint32_t nt[B], ot[B];
+    fvec4 ac[B][NCH], p[B][NCH];
+    float wt[B];
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      t[b] = -1; nt[b] = 0; ot[b] = 0;
+      if (vis) {
+        t[b] = __ffsll((long long)vis) - 1;
+        vis &= vis - 1ull;
+        nt[b] = (uint32_t)__builtin_amdgcn_readlane((int)n, t[b]);
+        ot[b] = (uint32_t)__builtin_amdgcn_readlane((int)off, t[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      if (t[b] < 0) continue;
+      if (!(a.dbg & 4)) load_wide<NCH>(a.acc + (f0 + (uint32_t)t[b]) * C, C, l, ac[b]);
+      const uint64_t pix = s_pix[ot[b]];
+      if (!(a.dbg & 8)) load_wide<NCH>(a.probs + pix * C, C, l, p[b]);
+      wt[b] = a.weights ? a.weights[pix] : 1.0f;
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      if (t[b] < 0) continue;
+      const float w0 = a.iew * (1.0f / ((float)nt[b])) + (1 - a.iew) * 1.0f;     // Mesh.h:100-102
+      fuse_pixel_wide<KIND, NCH>(ac[b], p[b], C, l, w0 * wt[b]);                // :103
+      for (uint32_t j = 1; j < nt[b]; j++) {                                      // further pixels of this triangle, in image order
+        const uint64_t pix = s_pix[ot[b] + j];
+        fvec4 q[NCH];
+        load_wide<NCH>(a.probs + pix * C, C, l, q);
+        fuse_pixel_wide<KIND, NCH>(ac[b], q, C, l, w0 * (a.weights ? a.weights[pix] : 1.0f));
+      }
+      if (!(a.dbg & 2)) store_wide<NCH>(a.acc + (f0 + (uint32_t)t[b]) * C, C, l, ac[b]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1453,6 +1677,17 @@ bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F) {
   return !off && a->P == F && a->S == a->C && a->C <= 64u * 40u;   // 64 lanes x kSlice classes per row
 }
 
+// Which kernel smesh_aggregator_fuse_triangles dispatches for this aggregator (reporting only).
+static bool fuse_wide_enabled() {
+  static const bool off = getenv("SMESH_FUSE_WIDE") && atoi(getenv("SMESH_FUSE_WIDE")) == 0;
+  return !off;
+}
+const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a) {
+  if (a->C == 5 || a->C == 19 || a->C == 40) return "k_fuse_tri";
+  if (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) return "k_fuse_tri_wide";
+  return "k_fuse_tri_any";
+}
+
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* big_queue,
                                     const uint32_t* big_len, uint32_t big_capacity, const uint32_t* d_idx,
                                     const float* d_probs, const float* d_w, uint64_t W, uint64_t H) {
@@ -1464,12 +1699,14 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
   t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.F = F; t.C = a->C;
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
+  { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; t.dbg = fdbg; }
   const bool specialised = a->C == 5 || a->C == 19 || a->C == 40;   // row held in registers, block staged through LDS
   float* pw = nullptr;
   uint32_t* amax = nullptr;
   int G = 1;
+  const int wide_chunks = (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) ? (a->C <= 256 ? 1 : a->C <= 512 ? 2 : 4) : 0;   // k_fuse_tri_wide
   if (!specialised) {
-    while ((a->C + G - 1) / G > (uint32_t)kSlice) G *= 2;   // lanes per accumulator row (can_fuse_triangles: G <= 64)
+    while ((((a->C + G - 1) / G + 3u) & ~3u) > (uint32_t)kSlice) G *= 2;   // lanes per accumulator row (can_fuse_triangles: G <= 64)
     // the big-triangle waves park per-pixel weights (and arg-max) here
     SMESH_TRY(a->pw.reserve(N * 4));
     pw = static_cast<float*>(a->pw.ptr);
@@ -1477,7 +1714,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
       SMESH_TRY(a->fb_amax.reserve(N * 4));
       amax = static_cast<uint32_t*>(a->fb_amax.ptr);
     }
-    t.tri_blocks = (uint32_t)div_up(F, kWave / G);
+    t.tri_blocks = wide_chunks ? (uint32_t)div_up(F, kWave) : (uint32_t)div_up(F, kWave / G);
   }
   const dim3 grid(t.tri_blocks + (uint32_t)std::max(1, ctx->num_cus)), block(kWave);   // + one big-triangle wave per CU
   {
@@ -1492,12 +1729,18 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
       case 32: hipLaunchKernelGGL((k_fuse_tri_any<K, 32>), grid, block, 0, st, t, pw, amax); break; \
       default: hipLaunchKernelGGL((k_fuse_tri_any<K, 64>), grid, block, 0, st, t, pw, amax); break; \
     }
+#define SMESH_FW(K)                                                                            \
+    switch (wide_chunks) {                                                                     \
+      case 1:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 1>), grid, block, 0, st, t, pw, amax); break; \
+      case 2:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 2>), grid, block, 0, st, t, pw, amax); break; \
+      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4>), grid, block, 0, st, t, pw, amax); break; \
+    }
 #define SMESH_FT(K)                                                                           \
     switch (a->C) {                                                                           \
       case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K>), grid, block, 0, st, t); break;           \
       case 19: hipLaunchKernelGGL((k_fuse_tri<19, K>), grid, block, 0, st, t); break;          \
       case 40: hipLaunchKernelGGL((k_fuse_tri<40, K>), grid, block, 0, st, t); break;          \
-      default: SMESH_FA(K); break;                                                            \
+      default: if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); } break;                 \
     }
     switch (a->kind) {
       case SMESH_AGG_SUM: SMESH_FT(SMESH_AGG_SUM); break;
@@ -1505,6 +1748,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
       default: SMESH_FT(SMESH_AGG_MUL); break;
     }
 #undef SMESH_FT
+#undef SMESH_FW
 #undef SMESH_FA
   }
   SMESH_HIP(hipGetLastError());

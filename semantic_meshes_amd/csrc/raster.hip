@@ -35,6 +35,7 @@ bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* big_queue,
                                     const uint32_t* big_len, uint32_t big_capacity, const uint32_t* d_idx,
                                     const float* d_probs, const float* d_w, uint64_t W, uint64_t H);
+const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a);
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a);
 uint32_t smesh_aggregator_classes(smesh_aggregator* a);
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a);
@@ -1070,8 +1071,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
     SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->side[slot].big_queue, r->side[slot].big_count,
                                               r->big_capacity,
                                               d_idx, d_probs, d_w, W, H));
-    const uint32_t C = smesh_aggregator_classes(a);
-    g_last_fuse_kernel = (C == 5 || C == 19 || C == 40) ? "k_fuse_tri" : "k_fuse_tri_any";
+    g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a);
   } else {
     g_last_fuse_kernel = "k_scatter_strip";
     SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));

@@ -379,7 +379,7 @@ def test_dlpack_export_feeds_add(sm, oracle):
 
 
 @pytest.mark.parametrize("kind", ["sum", "summax"])
-@pytest.mark.parametrize("C", [5, 19, 40, 1, 7, 32, 33, 64, 150])
+@pytest.mark.parametrize("C", [5, 19, 40, 1, 7, 32, 33, 64, 127, 150, 258])
 def test_fuse_view_triangle_order_is_bit_exact(sm, oracle, kind, C):
     """smesh_fuse_view on a triangle renderer takes the triangle-order path (k_fuse_tri for C in {5, 19, 40}, the
     chunked k_fuse_tri_any for every other class count): every accumulator row has one owner and the reference's
@@ -437,7 +437,7 @@ def test_fuse_view_mixed_triangle_sizes(sm, oracle, kind):
 
 
 @pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
-@pytest.mark.parametrize("C", [3, 70])
+@pytest.mark.parametrize("C", [3, 70, 130])
 def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
     """k_fuse_tri_any incl. its big-triangle waves (single-chunk and multi-chunk rows), all three aggregators."""
     from semantic_meshes_amd.device import to_device
@@ -461,7 +461,7 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
             oagg.add(o.render(cam)[0], probs)
         import os
         if os.environ.get("SMESH_FUSE") != "strip":
-            assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri_any"
+            assert sm._lib.lib().smesh_last_fuse_kernel().decode() == ("k_fuse_tri_wide" if C >= 128 else "k_fuse_tri_any")
         mul_tol = 1e-2 if os.environ.get("SMESH_FUSE") == "strip" else 3e-3
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
@@ -520,3 +520,34 @@ def test_alternative_paths_in_subprocess(knob):
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
                           "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("C", [19, 64, 150])
+def test_fuse_view_dont_care_threshold_is_exact(sm, oracle, C):
+    """Row sums within a few ulps of the 0.5 don't-care threshold (Mesh.h:98): which pixels count is decided by the
+    float32 sum in class order, whatever the kernel's own reduction order is (k_fuse_tri_wide replays the sequential
+    sum when its tree estimate is too close to call; k_fuse_tri_any hands the running sum through the lane group)."""
+    mesh, cams = small_scene(120, 60, 320, 240, views=2)
+    P = len(mesh.faces)
+    rng = np.random.default_rng(C + 100)
+    r = sm.render.triangles(mesh)
+    agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
+    flips = 0
+    for cam in cams:
+        W, H = cam.resolution
+        probs = rng.random((W, H, C), dtype=np.float32) + 0.01
+        seq = np.zeros((W, H), np.float32)
+        for c in range(C):                                       # float32 sum in class order
+            seq = seq + probs[:, :, c]
+        probs *= (np.float32(0.5) / seq)[:, :, None]             # rows now sum to 0.5 up to rounding, on either side
+        seq = np.zeros((W, H), np.float32)
+        for c in range(C):
+            seq = seq + probs[:, :, c]
+        pair = probs.astype(np.float64).sum(-1)
+        flips += int(((seq > 0.5) != (pair > 0.5)).sum())
+        agg.fuse_view(r, cam, probs)
+        oagg.add(o.render(cam)[0], probs)
+    assert flips > 50                                            # the inputs do separate summation orders
+    np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
