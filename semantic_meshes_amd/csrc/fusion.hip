@@ -1019,15 +1019,18 @@ __device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, uin
   }
 }
 
+// The big triangles of the any-C paths run as their own launch: inlined into the kernels below, their kSlice-wide
+// partial sums set the register allocation (148 VGPRs) of waves that never execute them.
+template <int KIND>
+__global__ __launch_bounds__(kWave) void k_fuse_big_any(TriFuseArgs a, float* __restrict__ pw, uint32_t* __restrict__ amax) {
+  fuse_big_triangles_any<KIND>(a, blockIdx.x, gridDim.x, pw, amax);
+}
+
 template <int KIND, int G>
-__global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, float* __restrict__ pw, uint32_t* __restrict__ amax) {
+__global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a) {
   constexpr int TPW = kWave / G;   // triangles per wave
   const int l = threadIdx.x;
   const uint32_t C = a.C;
-  if (blockIdx.x >= a.tri_blocks) {
-    fuse_big_triangles_any<KIND>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, pw, amax);
-    return;
-  }
   const int g = l % G;                                   // rank inside the group
   const uint64_t f = (uint64_t)blockIdx.x * TPW + (uint32_t)(l / G);
   const uint32_t S = G == 1 ? C : (((C + G - 1) / G + 3u) & ~3u);   // classes per lane (whole float4s when the row is split)
@@ -1109,9 +1112,9 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, float* __
 // Triangle-order fusion for WIDE rows (128 <= C <= 1024): a row no longer belongs to a lane but to the wave.
 // Lane l holds classes 4 (l + 64 k) .. + 3 (k < NCH) of the current accumulator row and of the current pixel's class
 // vector, so every row moves as one coalesced run of 16-byte pieces.  The wave first finds, lane = triangle, the
-// visible pixels of its 64 triangles (pass 1 of k_fuse_tri) and parks them in LDS grouped by triangle; then it
-// walks the visible triangles one after the other (wave-uniform control flow): load the row, add its pixels in
-// image order, store the row.  Per class the additions happen in the reference's order, so the result is still
+// visible pixels of its 64 triangles (pass 1 of k_fuse_tri); then it walks the visible triangles a few at a time
+// (wave-uniform control flow, the pixel set of a triangle read from its owner lane into scalar registers): load the
+// row, add its pixels in image order, store the row.  Per class the additions happen in the reference's order, so the result is still
 // bit-identical.  The don't-care test needs the float32 row sum in class order (Mesh.h:98): the wave first
 // tree-reduces the row and its absolute values; only if that estimate is within its own error bound of 0.5
 // does it replay the additions one class at a time (never for probability rows, whose sums are ~1 or 0).
@@ -1220,15 +1223,10 @@ __device__ __forceinline__ void fuse_pixel_wide(fvec4 (&ac)[NCH], const fvec4 (&
 }
 
 template <int KIND, int NCH>
-__global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, float* __restrict__ pw, uint32_t* __restrict__ amax) {
+__global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
   constexpr int B = NCH == 1 ? 4 : 2;      // visible triangles whose rows and first pixels are in flight together
-  __shared__ uint32_t s_pix[kWave * 64];   // visible pixels of the wave's triangles (linear pixel index), grouped by triangle
   const int l = threadIdx.x;
   const uint32_t C = a.C;
-  if (blockIdx.x >= a.tri_blocks) {
-    fuse_big_triangles_any<KIND>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, pw, amax);
-    return;
-  }
   const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
   const uint64_t f = f0 + l;
   TriFrag rec;
@@ -1236,8 +1234,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, float* _
   if (f < a.F) rec = a.frags[f];
   auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
   unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
-  unsigned long long win = 0ull;
-  uint32_t n = 0;
+  unsigned long long win = 0ull;   // pass 1, lane = triangle: the emitted fragments that won the depth test
   while (__ballot(m != 0ull) != 0ull) {
     int k[4];
     uint32_t got[4];
@@ -1249,44 +1246,41 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, float* _
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (k[j] >= 0 && got[j] == (uint32_t)f) { n++; win |= 1ull << k[j]; }
+      if (k[j] >= 0 && got[j] == (uint32_t)f) win |= 1ull << k[j];
   }
-  unsigned long long vis = __ballot(n != 0u);
+  unsigned long long vis = __ballot(win != 0ull);
   if (vis == 0ull || (a.dbg & 1)) return;
-  uint32_t incl = n;   // inclusive scan of the pixel counts
-#pragma unroll
-  for (int d = 1; d < kWave; d <<= 1) {
-    const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
-    if (l >= d) incl += o;
-  }
-  const uint32_t off = incl - n;
-  {
-    uint32_t j = off;
-    for (m = win; m; m &= m - 1ull) s_pix[j++] = (uint32_t)pixel(__ffsll((long long)m) - 1);
-  }
-  wave_sync();
+  const uint32_t origin = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
+  const uint32_t win_lo = (uint32_t)win, win_hi = (uint32_t)(win >> 32);
 
+  // From here on the wave works on one triangle's row at a time; the triangle's pixel set travels in scalar
+  // registers (readlane of its owner lane's mask and box origin), so the control flow is wave-uniform.
   while (vis) {
     // a batch of up to B visible triangles: their accumulator rows and first pixels are requested together
     int t[B];
-    uint32_t nt[B], ot[B];
+    unsigned long long pm[B];
+    uint32_t org[B], nt[B];
     fvec4 ac[B][NCH], p[B][NCH];
     float wt[B];
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      t[b] = -1; nt[b] = 0; ot[b] = 0;
+      t[b] = -1; pm[b] = 0ull; org[b] = 0u; nt[b] = 0u;
       if (vis) {
         t[b] = __ffsll((long long)vis) - 1;
         vis &= vis - 1ull;
-        nt[b] = (uint32_t)__builtin_amdgcn_readlane((int)n, t[b]);
-        ot[b] = (uint32_t)__builtin_amdgcn_readlane((int)off, t[b]);
+        pm[b] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)win_lo, t[b]) |
+                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)win_hi, t[b]) << 32);
+        org[b] = (uint32_t)__builtin_amdgcn_readlane((int)origin, t[b]);
+        nt[b] = (uint32_t)__popcll(pm[b]);
       }
     }
+    auto pix_of = [&](uint32_t o, int k) -> uint64_t { return (uint64_t)((o & 0xFFFFu) + (uint32_t)(k >> 3)) * a.H + (o >> 16) + (uint32_t)(k & 7); };
 #pragma unroll
     for (int b = 0; b < B; b++) {
       if (t[b] < 0) continue;
       if (!(a.dbg & 4)) load_wide<NCH>(a.acc + (f0 + (uint32_t)t[b]) * C, C, l, ac[b]);
-      const uint64_t pix = s_pix[ot[b]];
+      const uint64_t pix = pix_of(org[b], __ffsll((long long)pm[b]) - 1);
+      pm[b] &= pm[b] - 1ull;
       if (!(a.dbg & 8)) load_wide<NCH>(a.probs + pix * C, C, l, p[b]);
       wt[b] = a.weights ? a.weights[pix] : 1.0f;
     }
@@ -1295,8 +1289,8 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, float* _
       if (t[b] < 0) continue;
       const float w0 = a.iew * (1.0f / ((float)nt[b])) + (1 - a.iew) * 1.0f;     // Mesh.h:100-102
       fuse_pixel_wide<KIND, NCH>(ac[b], p[b], C, l, w0 * wt[b]);                // :103
-      for (uint32_t j = 1; j < nt[b]; j++) {                                      // further pixels of this triangle, in image order
-        const uint64_t pix = s_pix[ot[b] + j];
+      for (; pm[b]; pm[b] &= pm[b] - 1ull) {                                      // further pixels of this triangle, in image order
+        const uint64_t pix = pix_of(org[b], __ffsll((long long)pm[b]) - 1);
         fvec4 q[NCH];
         load_wide<NCH>(a.probs + pix * C, C, l, q);
         fuse_pixel_wide<KIND, NCH>(ac[b], q, C, l, w0 * (a.weights ? a.weights[pix] : 1.0f));
@@ -1717,30 +1711,34 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
     t.tri_blocks = wide_chunks ? (uint32_t)div_up(F, kWave) : (uint32_t)div_up(F, kWave / G);
   }
   const dim3 grid(t.tri_blocks + (uint32_t)std::max(1, ctx->num_cus)), block(kWave);   // + one big-triangle wave per CU
+  const dim3 tgrid(t.tri_blocks), bgrid((uint32_t)std::max(1, ctx->num_cus));          // any-C paths: big triangles in a second launch
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
 #define SMESH_FA(K)                                                                            \
     switch (G) {                                                                               \
-      case 1:  hipLaunchKernelGGL((k_fuse_tri_any<K, 1>), grid, block, 0, st, t, pw, amax); break;  \
-      case 2:  hipLaunchKernelGGL((k_fuse_tri_any<K, 2>), grid, block, 0, st, t, pw, amax); break;  \
-      case 4:  hipLaunchKernelGGL((k_fuse_tri_any<K, 4>), grid, block, 0, st, t, pw, amax); break;  \
-      case 8:  hipLaunchKernelGGL((k_fuse_tri_any<K, 8>), grid, block, 0, st, t, pw, amax); break;  \
-      case 16: hipLaunchKernelGGL((k_fuse_tri_any<K, 16>), grid, block, 0, st, t, pw, amax); break; \
-      case 32: hipLaunchKernelGGL((k_fuse_tri_any<K, 32>), grid, block, 0, st, t, pw, amax); break; \
-      default: hipLaunchKernelGGL((k_fuse_tri_any<K, 64>), grid, block, 0, st, t, pw, amax); break; \
+      case 1:  hipLaunchKernelGGL((k_fuse_tri_any<K, 1>), tgrid, block, 0, st, t); break;  \
+      case 2:  hipLaunchKernelGGL((k_fuse_tri_any<K, 2>), tgrid, block, 0, st, t); break;  \
+      case 4:  hipLaunchKernelGGL((k_fuse_tri_any<K, 4>), tgrid, block, 0, st, t); break;  \
+      case 8:  hipLaunchKernelGGL((k_fuse_tri_any<K, 8>), tgrid, block, 0, st, t); break;  \
+      case 16: hipLaunchKernelGGL((k_fuse_tri_any<K, 16>), tgrid, block, 0, st, t); break; \
+      case 32: hipLaunchKernelGGL((k_fuse_tri_any<K, 32>), tgrid, block, 0, st, t); break; \
+      default: hipLaunchKernelGGL((k_fuse_tri_any<K, 64>), tgrid, block, 0, st, t); break; \
     }
 #define SMESH_FW(K)                                                                            \
     switch (wide_chunks) {                                                                     \
-      case 1:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 1>), grid, block, 0, st, t, pw, amax); break; \
-      case 2:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 2>), grid, block, 0, st, t, pw, amax); break; \
-      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4>), grid, block, 0, st, t, pw, amax); break; \
+      case 1:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 1>), tgrid, block, 0, st, t); break; \
+      case 2:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 2>), tgrid, block, 0, st, t); break; \
+      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4>), tgrid, block, 0, st, t); break; \
     }
 #define SMESH_FT(K)                                                                           \
     switch (a->C) {                                                                           \
       case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K>), grid, block, 0, st, t); break;           \
       case 19: hipLaunchKernelGGL((k_fuse_tri<19, K>), grid, block, 0, st, t); break;          \
       case 40: hipLaunchKernelGGL((k_fuse_tri<40, K>), grid, block, 0, st, t); break;          \
-      default: if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); } break;                 \
+      default:                                                                                \
+        if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                               \
+        hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, pw, amax);             \
+        break;                                                                                \
     }
     switch (a->kind) {
       case SMESH_AGG_SUM: SMESH_FT(SMESH_AGG_SUM); break;
