@@ -696,6 +696,10 @@ struct TriFuseArgs {
   uint32_t big_capacity;
   uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the rest the big-triangle queue
   int dbg;                    // development ablation (SMESH_FDBG): 1 stop after pass 1, 2 no stores, 4 no row loads, 8 no probs loads
+  // texel primitives (k_fuse_texel) only
+  const uint32_t* tex_first;  // [F] first texel id of each triangle
+  const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
+  uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
 };
 
 // Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle, lanes over the box;
@@ -1301,6 +1305,120 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Triangle-order fusion for TEXEL primitives (render.texels + fuse_view, C <= kSlice).  A triangle owns a contiguous
+// range of texel rows and nobody else writes them, so the lane that owns the triangle can read-modify-write the
+// row of each of its visible pixels in plain memory operations, in image order (= the reference's order per row).
+// The per-view count of a texel is the number of the triangle's visible pixels that carry the same texel id.
+// Big triangles (tail blocks, one wave each): lanes stride the pixels, so rows are shared inside the wave -> the
+// aggregator's scratch histogram and float atomics, like the generic path, but confined to the triangle's own rows.
+// ------------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ void fuse_big_texel_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers) {
+  const int l = threadIdx.x;
+  const uint32_t C = a.C;
+  const uint32_t nbig = min(*a.big_len, a.big_capacity);
+  for (uint32_t q = worker; q < nbig; q += nworkers) {
+    const uint32_t f = a.big_queue[q];
+    const TriFrag rec = a.frags[f];
+    if (rec.kind != 2) continue;
+    const uint32_t first = a.tex_first[f], res = a.tex_res[f], cnt = res * (res + 1u) / 2u;
+    const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
+    const int bh = y1 - y0 + 1;
+    const long long npx = (long long)(x1 - x0 + 1) * bh;
+    for (long long i = l; i < npx; i += kWave) {
+      const uint32_t v = a.idx[(uint64_t)(x0 + (int)(i / bh)) * a.H + (y0 + (int)(i % bh))];
+      if (v - first < cnt) atomicAdd(&a.count[v], 1u);
+    }
+    __threadfence();
+    for (long long i = l; i < npx; i += kWave) {
+      const uint64_t pix = (uint64_t)(x0 + (int)(i / bh)) * a.H + (y0 + (int)(i % bh));
+      const uint32_t v = a.idx[pix];
+      if (!(v - first < cnt)) continue;
+      const uint32_t n = __hip_atomic_load(&a.count[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const float* __restrict__ pr = a.probs + pix * C;
+      float sum = 0.0f, best = 0.0f;
+      uint32_t am = 0;
+      for (uint32_t c = 0; c < C; c++) {
+        const float pc = pr[c];
+        sum = sum + pc;
+        if (KIND == SMESH_AGG_SUMMAX && (c == 0 || pc > best)) { best = pc; am = c; }
+      }
+      if (!(sum > 0.5f)) continue;
+      const float w = (a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f) * (a.weights ? a.weights[pix] : 1.0f);
+      float* row = a.acc + (uint64_t)v * C;
+      if (KIND == SMESH_AGG_SUMMAX) unsafeAtomicAdd(&row[am], best * w);
+      else for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(&row[c], contribution<KIND>(pr[c], w));
+    }
+    __threadfence();
+    for (long long i = l; i < npx; i += kWave) {
+      const uint32_t v = a.idx[(uint64_t)(x0 + (int)(i / bh)) * a.H + (y0 + (int)(i % bh))];
+      if (v - first < cnt) a.count[v] = 0u;
+    }
+    __threadfence();
+  }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kWave) void k_fuse_texel_big(TriFuseArgs a) { fuse_big_texel_triangles<KIND>(a, blockIdx.x, gridDim.x); }
+
+template <int KIND>
+__global__ __launch_bounds__(kWave) void k_fuse_texel(TriFuseArgs a) {
+  const int l = threadIdx.x;
+  const uint32_t C = a.C;
+  const uint64_t f = (uint64_t)blockIdx.x * kWave + l;
+  TriFrag rec;
+  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
+  uint32_t first = 0, cnt = 0;
+  if (f < a.F) rec = a.frags[f];
+  if (rec.kind == 1) {   // (the tables are not read for the triangles that emitted nothing)
+    first = a.tex_first[f];
+    const uint32_t res = a.tex_res[f];
+    cnt = res * (res + 1u) / 2u;
+  }
+  auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
+  // pass 1: which emitted fragments won the depth test (the pixel then holds one of this triangle's texels)
+  unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
+  unsigned long long win = 0ull;
+  while (__ballot(m != 0ull) != 0ull) {
+    int k[4];
+    uint32_t got[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      k[j] = -1;
+      if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
+      got[j] = a.idx[k[j] >= 0 ? pixel(k[j]) : 0];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (k[j] >= 0 && got[j] - first < cnt) win |= 1ull << k[j];
+  }
+  if (win == 0ull) return;
+  for (m = win; m; m &= m - 1ull) {
+    const uint64_t pix = pixel(__ffsll((long long)m) - 1);
+    const uint32_t v = a.idx[pix];
+    uint32_t n = 0;                                   // Mesh.h:90-93 restricted to this triangle's pixels
+    for (unsigned long long m2 = win; m2; m2 &= m2 - 1ull) n += a.idx[pixel(__ffsll((long long)m2) - 1)] == v ? 1u : 0u;
+    float p[kSlice];
+    load_slice(a.probs + pix * C, (int)C, p);
+    float sum = 0.0f, best = p[0];
+    int am = 0;
+#pragma unroll
+    for (int j = 0; j < kSlice; j++)
+      if (j < (int)C) {
+        sum = sum + p[j];
+        if (KIND == SMESH_AGG_SUMMAX && p[j] > best) { best = p[j]; am = j; }
+      }
+    if (!(sum > 0.5f)) continue;                      // :98
+    const float w = (a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f) * (a.weights ? a.weights[pix] : 1.0f);   // :100-103
+    float* row = a.acc + (uint64_t)v * C;             // owned by this lane; a later pixel of the same texel re-reads it
+    float accr[kSlice];
+    load_slice(row, (int)C, accr);
+    accumulate_slice<KIND>(accr, p, (int)C, w, am);
+    store_slice(row, (int)C, accr);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fallback for class counts whose strip does not fit LDS: per-pixel weights, then a flat scatter.
 // ------------------------------------------------------------------------------------------------
 template <int KIND>
@@ -1694,6 +1812,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
   { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; t.dbg = fdbg; }
+  t.tex_first = nullptr; t.tex_res = nullptr; t.count = nullptr;
   const bool specialised = a->C == 5 || a->C == 19 || a->C == 40;   // row held in registers, block staged through LDS
   float* pw = nullptr;
   uint32_t* amax = nullptr;
@@ -1748,6 +1867,45 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
 #undef SMESH_FT
 #undef SMESH_FW
 #undef SMESH_FA
+  }
+  SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
+}
+
+bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P) {
+  static const bool off = getenv("SMESH_FUSE") && std::string(getenv("SMESH_FUSE")) == "strip";
+  return !off && a->P == P && a->S == a->C && a->C <= (uint32_t)kSlice;
+}
+
+int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
+                                 const uint32_t* tex_res, const uint32_t* big_queue, const uint32_t* big_len,
+                                 uint32_t big_capacity, const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t H) {
+  DeviceCtx* ctx = a->ctx;
+  hipStream_t st = ctx->stream;
+  if (F == 0) return SMESH_OK;
+  TriFuseArgs t;
+  t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.F = F; t.C = a->C;
+  t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
+  t.tri_blocks = (uint32_t)div_up(F, kWave);
+  t.dbg = 0;
+  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count;
+  const dim3 tgrid(t.tri_blocks), bgrid((uint32_t)std::max(1, ctx->num_cus)), block(kWave);
+  {
+    ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
+    switch (a->kind) {
+      case SMESH_AGG_SUM:
+        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_SUM>), tgrid, block, 0, st, t);
+        hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_SUM>), bgrid, block, 0, st, t);
+        break;
+      case SMESH_AGG_SUMMAX:
+        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_SUMMAX>), tgrid, block, 0, st, t);
+        hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_SUMMAX>), bgrid, block, 0, st, t);
+        break;
+      default:
+        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_MUL>), tgrid, block, 0, st, t);
+        hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_MUL>), bgrid, block, 0, st, t);
+        break;
+    }
   }
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;

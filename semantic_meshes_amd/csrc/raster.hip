@@ -36,6 +36,10 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
                                     const uint32_t* big_len, uint32_t big_capacity, const uint32_t* d_idx,
                                     const float* d_probs, const float* d_w, uint64_t W, uint64_t H);
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a);
+bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P);
+int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
+                                 const uint32_t* tex_res, const uint32_t* big_queue, const uint32_t* big_len,
+                                 uint32_t big_capacity, const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t H);
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a);
 uint32_t smesh_aggregator_classes(smesh_aggregator* a);
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a);
@@ -1072,6 +1076,11 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
                                               r->big_capacity,
                                               d_idx, d_probs, d_w, W, H));
     g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a);
+  } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
+    // texel primitives: a triangle owns its texel rows, its lane read-modify-writes them without atomics
+    SMESH_TRY(smesh_aggregator_fuse_texels(a, r->side[slot].frags, r->F, r->tex_first, r->tex_res, r->side[slot].big_queue,
+                                           r->side[slot].big_count, r->big_capacity, d_idx, d_probs, d_w, H));
+    g_last_fuse_kernel = "k_fuse_texel";
   } else {
     g_last_fuse_kernel = "k_scatter_strip";
     SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));

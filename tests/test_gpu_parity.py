@@ -514,7 +514,7 @@ def test_alternative_paths_in_subprocess(knob):
     k, v = knob.split("=")
     env = dict(os.environ, **{k: v})
     here = os.path.dirname(os.path.abspath(__file__))
-    sel = "render_small_scene or render_cfg1 or overlap or mixed_triangle or texel_renderer or fuse_view_cfg2"
+    sel = "render_small_scene or render_cfg1 or overlap or mixed_triangle or texel or fuse_view_cfg2"
     if k != "SMESH_FUSE":
         sel += " or triangle_order"
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
@@ -551,3 +551,64 @@ def test_fuse_view_dont_care_threshold_is_exact(sm, oracle, C):
         oagg.add(o.render(cam)[0], probs)
     assert flips > 50                                            # the inputs do separate summation orders
     np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C", [4, 40])
+def test_fuse_view_texels_small_triangles(sm, oracle, kind, C):
+    """render.texels + fuse_view: triangle-order fusion over texel rows (k_fuse_texel); small triangles only, so the
+    reference's float32 order is kept per texel row -> bit-equal to the single-threaded float32 oracle (Sum/Summax)."""
+    import os
+    mesh, cams = small_scene(160, 80, 330, 250, views=3)         # ~2 px triangles (all boxes <= 8 x 8), a few texels each
+    r = sm.render.texels(mesh, cams, 1.5)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces, cams, 1.5)
+    P = r.getPrimitivesNum()
+    assert P > 2 * len(mesh.faces)
+    rng = np.random.default_rng(C)
+    agg, oagg = sm.fusion.MeshAggregator(P, C, kind, 0.5), oracle.OracleAggregator(P, C, kind, 0.5)
+    for cam in cams:
+        probs = random_probs(rng, *cam.resolution, C)
+        if kind == "mul":
+            probs = np.maximum(probs, 1e-3).astype(np.float32)
+        weights = rng.random(cam.resolution, dtype=np.float32)
+        agg.fuse_view(r, cam, probs, weights)
+        oagg.add(o.render(cam)[0], probs, weights)
+    if os.environ.get("SMESH_FUSE") != "strip":
+        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_texel"
+        if kind != "mul":
+            np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+    assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else 2e-4)
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax"])
+def test_fuse_view_texels_big_triangles(sm, oracle, kind):
+    """Texel primitives on triangles larger than 8 x 8 pixels (cooperative waves: scratch histogram + float atomics
+    confined to the triangle's own texel rows), mixed with small ones; several views in a row."""
+    mesh, cams = small_scene(10, 5, 400, 300, views=3)            # ~50 px triangles
+    fine, _ = small_scene(40, 20, 400, 300, views=1)
+    verts = np.concatenate([mesh.vertices, fine.vertices + np.array([0, 0, 0.7], np.float32)])
+    faces = np.concatenate([mesh.faces, fine.faces + len(mesh.vertices)]).astype(np.int32)
+    both = sm.data.Mesh(verts, faces)
+    r = sm.render.texels(both, cams, 0.3)
+    o = oracle.OracleRenderer(verts, faces, cams, 0.3)
+    P, C = r.getPrimitivesNum(), 7
+    rng = np.random.default_rng(11)
+    agg = sm.fusion.MeshAggregator(P, C, kind)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind)
+        for cam in cams:
+            probs = random_probs(rng, *cam.resolution, C)
+            agg.fuse_view(r, cam, probs)
+            oagg.add(o.render(cam)[0], probs)
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    finally:
+        oracle.set_accum_double(False)
+    # the scratch histogram is all zero again: a plain add() (generic path) still gives the right counts
+    agg2, oagg2 = sm.fusion.MeshAggregator(P, C, kind), oracle.OracleAggregator(P, C, kind)
+    probs = random_probs(rng, *cams[0].resolution, C)
+    agg.reset()
+    idx = r.render(cams[0])[0]
+    agg.add(idx, probs)
+    oagg2.add(np.asarray(idx), probs)
+    assert_fused_close(agg.get(), oagg2.get(), rtol=2e-5)
