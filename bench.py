@@ -54,9 +54,25 @@ def cpu_baseline(workload, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
+    # the same sample with the one obvious CPU optimisation (dense parallel histogram instead of the serial std::map):
+    # reported beside the faithful port so that the ratio is not only against the reference's serial step
+    oracle.set_fast_histogram(True)
+    agg2 = oracle.OracleAggregator(P, C)
+    done2, t1 = 0, time.perf_counter()
+    while done2 < len(cams):
+        idx, _ = r.render(cams[done2])
+        agg2.add(idx, probs)
+        done2 += 1
+        if time.perf_counter() - t1 > budget_s / 2:
+            break
+    dt2 = time.perf_counter() - t1
+    oracle.set_fast_histogram(False)
     oracle.set_threads(1)
     return {"value": round(done / dt, 3), "unit": "views/s", "cores": cores, "kind": "port",
-            "sample": "%d of the %s views (render + add), %d OpenMP threads, %.1f s" % (done, workload, cores, dt)}
+            "sample": "%d of the %s views (render + add), %d OpenMP threads, %.1f s" % (done, workload, cores, dt),
+            "optimised_cpu": {"value": round(done2 / dt2, 3), "unit": "views/s",
+                              "what": "same port with a dense parallel histogram instead of the reference's serial std::map",
+                              "sample": "%d views, %.1f s" % (done2, dt2)}}
 
 
 def main():

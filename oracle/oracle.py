@@ -97,6 +97,11 @@ def set_accum_double(on):
     lib().smesh_oracle_set_accum_double(1 if on else 0)
 
 
+def set_fast_histogram(on):
+    """"Optimised CPU" baseline variant: dense parallel histogram instead of the reference's serial std::map (same counts)."""
+    lib().smesh_oracle_set_fast_histogram(1 if on else 0)
+
+
 class OracleRenderer:
     def __init__(self, vertices, faces, cameras=None, texels_per_pixel=0.1):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)

@@ -39,6 +39,7 @@ int fail(int code, const std::string& msg) { g_err = msg; return code; }
 
 int g_threads = 1;            // deterministic by default; bench raises it for the CPU baseline
 bool g_accum_double = false;  // float64 accumulators for tolerance tests (reference uses float32)
+bool g_fast_histogram = false;  // "optimised CPU" baseline variant: dense parallel histogram instead of the reference's serial std::map
 
 // ---------------------------------------------------------------------------------------------
 // Raster spec (DESIGN.md "Raster spec"); protocol from TriangleRenderer.h:30-39,46-61,63-89.
@@ -210,6 +211,7 @@ int smesh_synchronize(int) { return SMESH_OK; }
 int smesh_oracle_set_threads(int n) { g_threads = n < 1 ? 1 : n; return SMESH_OK; }
 int smesh_oracle_get_threads(void) { return g_threads; }
 int smesh_oracle_set_accum_double(int on) { g_accum_double = on != 0; return SMESH_OK; }
+int smesh_oracle_set_fast_histogram(int on) { g_fast_histogram = on != 0; return SMESH_OK; }
 
 // --------------------------------------------------------------------------------------------
 // renderer
@@ -445,7 +447,18 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
 
   // Mesh.h:90-93 -- serial std::map histogram over ALL pixels of this image
   std::map<size_t, size_t> pixels_per_face;
-  for (uint64_t i = 0; i < N; i++) pixels_per_face.insert({(size_t)idx[i], 0}).first->second += 1;
+  std::vector<uint32_t> dense_count;   // optimised variant (not the reference's algorithm): same counts, dense and parallel
+  if (g_fast_histogram) {
+    dense_count.assign(P + 1, 0u);     // slot P collects the background / out-of-range values
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (par)
+    for (int64_t i = 0; i < (int64_t)N; i++) {
+      const size_t v = idx[i] < P ? (size_t)idx[i] : (size_t)P;
+#pragma omp atomic
+      dense_count[v] += 1u;
+    }
+  } else {
+    for (uint64_t i = 0; i < N; i++) pixels_per_face.insert({(size_t)idx[i], 0}).first->second += 1;
+  }
 
   // Mesh.h:94-106 -- OpenMP 2-D loop, one lock per primitive
   const float iew = a->iew;
@@ -458,7 +471,8 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
     float sum = 0.0f;
     for (uint32_t c = 0; c < C; c++) sum = sum + next[c];        // tt::sum, sequential float32
     if (!(sum > 0.5f)) continue;                                // Mesh.h:98 "Not the don't-care class"
-    const float image_weight = 1.0f / ((float)pixels_per_face.find(primitive_index)->second);  // :100
+    const size_t npix = g_fast_histogram ? (size_t)dense_count[primitive_index] : pixels_per_face.find(primitive_index)->second;
+    const float image_weight = 1.0f / ((float)npix);                                         // :100
     const float pixel_weight = 1.0f;                                                        // :101
     const float image_pixel_weight = iew * image_weight + (1 - iew) * pixel_weight;           // :102
     const float w = image_pixel_weight * (weights ? wt[i] : 1.0f);                           // :103

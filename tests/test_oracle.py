@@ -226,3 +226,25 @@ def test_annotation_renderer_gathers_rows(oracle):
     img = oracle.render_annotations(agg, idx, [9.0, 8.0])
     np.testing.assert_allclose(img[0], [[0.25, 0.75], [0, 0], [1, 0]], rtol=1e-6)
     np.testing.assert_allclose(img[1], [[9, 8], [9, 8], [1, 0]], rtol=1e-6)
+
+
+def test_fast_histogram_variant_is_equivalent(oracle):
+    """bench.py's "optimised_cpu" leg swaps the reference's serial std::map histogram (Mesh.h:90-93) for a dense
+    parallel one: the counts, hence the fused accumulators, must be bit-identical."""
+    from helpers import random_probs, small_scene
+    mesh, cams = small_scene()
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    P, C = len(mesh.faces), 5
+    rng = np.random.default_rng(0)
+    a1, a2 = oracle.OracleAggregator(P, C, "summax", 0.7), oracle.OracleAggregator(P, C, "summax", 0.7)
+    try:
+        for cam in cams:
+            probs = random_probs(rng, *cam.resolution, C)
+            idx = o.render(cam)[0]
+            oracle.set_fast_histogram(False)
+            a1.add(idx, probs)
+            oracle.set_fast_histogram(True)
+            a2.add(idx, probs)
+    finally:
+        oracle.set_fast_histogram(False)
+    np.testing.assert_array_equal(a1.get_raw().view(np.uint32), a2.get_raw().view(np.uint32))
