@@ -170,7 +170,16 @@ int smesh_annotation_renderer_destroy(smesh_annotation_renderer_t* r);
 int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* camera,
                     const float* probs, const float* weights, int memkind);
 
-/* Name of the fusion kernel the last smesh_fuse_view() on this thread dispatched ("k_fuse_tri": triangle-order
+/* add() for an index image that is the UNMODIFIED device output `indices_dev` of r's most recent
+ * smesh_renderer_render_device(): the reference's two-call convention `idx, depth = renderer.render(cam);
+ * aggregator.add(idx, probs)` (python/scripts/colorize_cityscapes_mesh.py:65-67) then runs the same triangle-order
+ * fusion as smesh_fuse_view, using the per-triangle records that render left behind.  Same results as smesh_aggregator_add;
+ * if `idx_dev` is anything else, or the layout is not the dense (W,H[,C]) one, the call IS smesh_aggregator_add. */
+int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, const uint32_t* idx_dev,
+                                  const float* probs, const int64_t probs_strides[3], int probs_mem,
+                                  const float* weights, const int64_t w_strides[2], int w_mem, uint64_t W, uint64_t H);
+
+/* Name of the fusion kernel the last smesh_fuse_view() / smesh_aggregator_add_rendered() on this thread dispatched ("k_fuse_tri": triangle-order
  * gather-accumulate, no atomics; "k_fuse_tri_any": the same for any class count; "k_scatter_strip": generic segmented scatter-add).  For reporting. */
 const char* smesh_last_fuse_kernel(void);
 

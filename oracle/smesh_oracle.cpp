@@ -603,6 +603,12 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
 
 // --------------------------------------------------------------------------------------------
 const char* smesh_last_fuse_kernel(void) { return "oracle"; }
+int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, const uint32_t* idx, const float* probs,
+                                  const int64_t ps[3], int pmem, const float* weights, const int64_t ws[2], int wmem,
+                                  uint64_t W, uint64_t H) {
+  const int64_t is[2] = {(int64_t)H, 1};   // the oracle has one add(): the reference's
+  return smesh_aggregator_add(a, idx, SMESH_IDX_U32, is, SMESH_MEM_HOST, probs, ps, pmem, weights, ws, wmem, W, H);
+}
 int smesh_profile_enable(int, int) { return SMESH_OK; }
 int smesh_profile_sample_every(int, uint32_t) { return SMESH_OK; }
 int smesh_profile_read(int, int, double* ms, uint64_t* n) { if (ms) *ms = 0; if (n) *n = 0; return SMESH_OK; }

@@ -871,6 +871,15 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
       }
     }
   }
+  if (__ballot(rec.kind == 2) != 0ull) {
+    // Some of these 64 rows belong to big triangles, which the tail blocks of this launch update concurrently:
+    // writing the whole block back would overwrite their sums.  Every other lane stores its own row.
+    if (rec.kind != 2 && f < a.F) {
+#pragma unroll
+      for (int c = 0; c < C; c++) blk[l * C + c] = accr[c];
+    }
+    return;
+  }
 #pragma unroll
   for (int c = 0; c < C; c++) srow[l * C + c] = accr[c];
   wave_sync();

@@ -635,6 +635,9 @@ struct smesh_renderer {
   hipEvent_t ev_rendered[2] = {nullptr, nullptr};   // raster stream: slot is complete
   hipEvent_t ev_consumed[2] = {nullptr, nullptr};   // main stream: the fusion kernels have read the slot
   uint64_t fused_seq = 0;
+  // the index plane handed out by the most recent smesh_renderer_render_device(): side[0] still describes it
+  const uint32_t* last_idx = nullptr;
+  uint64_t last_W = 0, last_H = 0;
   bool raster_pending = false;     // work queued on the raster stream since the last synchronisation
   bool main_pending = false;       // renderer state (keys, scratch) used on the main stream since then
   std::mutex mu;
@@ -831,6 +834,46 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
 
 static thread_local const char* g_last_fuse_kernel = "none";
 
+// The fusion half of smesh_fuse_view / smesh_aggregator_add_rendered: `d_idx` is the index plane of the render
+// whose per-triangle records sit in r->side[slot].
+static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const uint32_t* d_idx, const float* probs,
+                         const float* weights, int memkind, uint64_t W, uint64_t H) {
+  DeviceCtx* ctx = r->ctx;
+  const uint64_t N = W * H;
+  const float* d_probs = probs;
+  const float* d_w = weights;
+  if (memkind == SMESH_MEM_HOST) {
+    const uint32_t C = smesh_aggregator_classes(a);
+    Scratch& sp = smesh_aggregator_stage_probs(a);
+    SMESH_TRY(sp.reserve(N * C * 4));
+    SMESH_HIP(hipMemcpyAsync(sp.ptr, probs, N * C * 4, hipMemcpyHostToDevice, ctx->stream));
+    d_probs = static_cast<const float*>(sp.ptr);
+    if (weights) {
+      Scratch& sw = smesh_aggregator_stage_w(a);
+      SMESH_TRY(sw.reserve(N * 4));
+      SMESH_HIP(hipMemcpyAsync(sw.ptr, weights, N * 4, hipMemcpyHostToDevice, ctx->stream));
+      d_w = static_cast<const float*>(sw.ptr);
+    }
+    SMESH_HIP(hipStreamSynchronize(ctx->stream));   // the caller may reuse its host arrays once we return
+  }
+  if (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) {
+    // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
+    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->side[slot].big_queue, r->side[slot].big_count,
+                                              r->big_capacity,
+                                              d_idx, d_probs, d_w, W, H));
+    g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a);
+  } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
+    // texel primitives: a triangle owns its texel rows, its lane read-modify-writes them without atomics
+    SMESH_TRY(smesh_aggregator_fuse_texels(a, r->side[slot].frags, r->F, r->tex_first, r->tex_res, r->side[slot].big_queue,
+                                           r->side[slot].big_count, r->big_capacity, d_idx, d_probs, d_w, H));
+    g_last_fuse_kernel = "k_fuse_texel";
+  } else {
+    g_last_fuse_kernel = "k_scatter_strip";
+    SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));
+  }
+  return SMESH_OK;
+}
+
 extern "C" {
 
 const char* smesh_last_fuse_kernel(void) { return g_last_fuse_kernel; }
@@ -970,6 +1013,7 @@ int smesh_renderer_render_device(smesh_renderer_t* r, const smesh_camera_t* cam,
   ImagePair* im;
   SMESH_TRY(acquire_image(r, cam->width * cam->height, &im));
   SMESH_TRY(render_into(r, cam, im->idx, im->depth));
+  r->last_idx = im->idx; r->last_W = cam->width; r->last_H = cam->height;
   im->idx_out = im->depth_out = true;
   *indices_dev = im->idx;
   *depth_dev = im->depth;
@@ -997,6 +1041,7 @@ int smesh_renderer_render(smesh_renderer_t* r, const smesh_camera_t* cam, uint32
   SMESH_TRY(r->own_idx.reserve(N * 8));
   uint32_t* d_idx = static_cast<uint32_t*>(r->own_idx.ptr);
   float* d_depth = reinterpret_cast<float*>(d_idx + N);
+  r->last_idx = nullptr;   // side[0] is about to describe this render, whose planes stay private
   SMESH_TRY(render_into(r, cam, d_idx, d_depth));
   SMESH_HIP(hipMemcpyAsync(indices_out, d_idx, N * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (depth_out) SMESH_HIP(hipMemcpyAsync(depth_out, d_depth, N * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1019,9 +1064,9 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   const uint64_t W = cam->width, H = cam->height, N = W * H;
   // Optional two-stage pipeline over two HIP streams (SMESH_FUSE_PIPELINE=1): the rasteriser of this view
   // runs on the raster stream while the main stream is still fusing the previous view; events hand the index
-  // image over and back.  Measured on cfg2 it gains only ~2 % (5358 vs 5240 views/s): the rasteriser's 64-bit
-  // atomics and the scatter-add's float atomics contend for the same memory-side path and each kernel gets
-  // slower by about what the overlap saves, so it is off by default (and kernel timings stay clean).
+  // image over and back (the per-triangle records are double-buffered: side[slot]).  Measured on cfg2 it gains
+  // under 1 %: k_raster_frag stretches from 44 to 82 us while k_fuse_tri runs beside it, and every cross-stream
+  // event costs 10-20 us of latency, so it is off by default (and kernel timings stay clean).
   static const bool pipelined = getenv("SMESH_FUSE_PIPELINE") && atoi(getenv("SMESH_FUSE_PIPELINE")) != 0;
   const int slot = pipelined ? (int)(r->fused_seq & 1u) : 0;
   hipStream_t rst = pipelined ? ctx->raster_stream : ctx->stream;
@@ -1047,6 +1092,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
     SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, r->ev_consumed[slot], 0));   // view k-2 has been fused
   }
   uint32_t* d_idx = static_cast<uint32_t*>(r->fused[slot].ptr);
+  r->last_idx = nullptr;   // the records of the last render_device() are being overwritten
   if (slot == 1) SMESH_HIP(alloc_side(r, 1));
   SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, rst, slot));   // the fusion only consumes the index plane
   if (pipelined) {
@@ -1054,40 +1100,41 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
     SMESH_HIP(hipEventRecord(r->ev_rendered[slot], ctx->raster_stream));
     SMESH_HIP(hipStreamWaitEvent(ctx->stream, r->ev_rendered[slot], 0));
   }
-  const float* d_probs = probs;
-  const float* d_w = weights;
-  if (memkind == SMESH_MEM_HOST) {
-    const uint32_t C = smesh_aggregator_classes(a);
-    Scratch& sp = smesh_aggregator_stage_probs(a);
-    SMESH_TRY(sp.reserve(N * C * 4));
-    SMESH_HIP(hipMemcpyAsync(sp.ptr, probs, N * C * 4, hipMemcpyHostToDevice, ctx->stream));
-    d_probs = static_cast<const float*>(sp.ptr);
-    if (weights) {
-      Scratch& sw = smesh_aggregator_stage_w(a);
-      SMESH_TRY(sw.reserve(N * 4));
-      SMESH_HIP(hipMemcpyAsync(sw.ptr, weights, N * 4, hipMemcpyHostToDevice, ctx->stream));
-      d_w = static_cast<const float*>(sw.ptr);
-    }
-    SMESH_HIP(hipStreamSynchronize(ctx->stream));   // the caller may reuse its host arrays once we return
-  }
-  if (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) {
-    // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
-    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->side[slot].big_queue, r->side[slot].big_count,
-                                              r->big_capacity,
-                                              d_idx, d_probs, d_w, W, H));
-    g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a);
-  } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
-    // texel primitives: a triangle owns its texel rows, its lane read-modify-writes them without atomics
-    SMESH_TRY(smesh_aggregator_fuse_texels(a, r->side[slot].frags, r->F, r->tex_first, r->tex_res, r->side[slot].big_queue,
-                                           r->side[slot].big_count, r->big_capacity, d_idx, d_probs, d_w, H));
-    g_last_fuse_kernel = "k_fuse_texel";
-  } else {
-    g_last_fuse_kernel = "k_scatter_strip";
-    SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));
-  }
+  SMESH_TRY(fuse_rendered(r, a, slot, d_idx, probs, weights, memkind, W, H));
   if (pipelined) SMESH_HIP(hipEventRecord(r->ev_consumed[slot], ctx->stream));
   r->fused_seq++;
   return SMESH_OK;
+}
+
+// add() for an index image that is the unmodified device output of `r`'s most recent smesh_renderer_render_device():
+// the reference's two-call convention (render, then add: colorize_cityscapes_mesh.py:65-67) at the speed of
+// smesh_fuse_view.  Anything else is forwarded to smesh_aggregator_add.
+int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, const uint32_t* idx_dev,
+                                  const float* probs, const int64_t probs_strides[3], int probs_mem,
+                                  const float* weights, const int64_t w_strides[2], int w_mem, uint64_t W, uint64_t H) {
+  if (!a || !r || !idx_dev || !probs || !probs_strides) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (weights && !w_strides) return fail(SMESH_ERR_INVALID, "weights without strides");
+  DeviceCtx* ctx = r->ctx;
+  const int64_t C = (int64_t)smesh_aggregator_classes(a);
+  bool fast = smesh_aggregator_ctx(a) == ctx && W != 0 && H != 0 &&
+              probs_strides[0] == (int64_t)H * C && probs_strides[1] == C && probs_strides[2] == 1 &&
+              (!weights || (w_mem == probs_mem && w_strides[0] == (int64_t)H && w_strides[1] == 1));
+  if (fast) {
+    std::lock_guard<std::mutex> g(r->mu);
+    std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    fast = idx_dev == r->last_idx && W == r->last_W && H == r->last_H &&
+           ((!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) ||
+            (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)));
+    if (fast) {
+      SMESH_HIP(hipSetDevice(ctx->device));
+      return fuse_rendered(r, a, 0, idx_dev, probs, weights, probs_mem, W, H);
+    }
+  }
+  const int64_t is[2] = {(int64_t)H, 1};
+  g_last_fuse_kernel = "k_scatter_strip";
+  return smesh_aggregator_add(a, idx_dev, SMESH_IDX_U32, is, SMESH_MEM_DEVICE, probs, probs_strides, probs_mem, weights, w_strides,
+                              w_mem, W, H);
 }
 
 }  // extern "C"

@@ -30,6 +30,8 @@ class DeviceArray:
         self.strides = tuple(int(s) for s in strides)  # in ELEMENTS
         self._owner = owner            # keeps the owning handle alive
         self._on_release = on_release  # returns the buffer to its pool
+        self._rendered_by = None       # render(): the renderer whose latest output this is (MeshAggregator.add fast path)
+        self._exported = False         # handed to another framework: the contents may have been changed behind our back
 
     def __del__(self):
         cb, self._on_release = getattr(self, "_on_release", None), None
@@ -56,6 +58,7 @@ class DeviceArray:
 
     @property
     def __cuda_array_interface__(self):
+        self._exported = True
         return {
             "shape": self.shape,
             "typestr": self.dtype.str,
@@ -72,6 +75,7 @@ class DeviceArray:
         """DLPack capsule over the HBM buffer (what the reference's render() returns, Renderer.h:37-38).
         The producing stream is synchronised first: the consumer may use any stream."""
         from . import dlpack
+        self._exported = True
         _lib.synchronize(self.device)
         return dlpack.to_capsule(self.ptr, self.shape, self.strides, self.dtype, dlpack.kDLROCM, self.device, self)
 

@@ -69,6 +69,15 @@ class _MeshAggregator:
         W, H = ishape
         if W == 0 or H == 0:
             return
+        rb = getattr(primitive_image, "_rendered_by", None)
+        if (rb is not None and not primitive_image._exported and getattr(rb, "_h", None) is not None and rb._h.value
+                and idt == np.uint32 and tuple(istr) == (H, 1)):
+            # the untouched output of renderer.render(): the reference's two-call loop (colorize_cityscapes_mesh.py:65-67)
+            # runs the same triangle-order fusion as fuse_view (the library re-checks that it is the latest render)
+            _lib.check(_lib.lib().smesh_aggregator_add_rendered(
+                self._h, rb._h, ctypes.c_void_p(ip), ctypes.c_void_p(pp), _c64(pstr), pmem,
+                None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H))
+            return
         _lib.check(_lib.lib().smesh_aggregator_add(
             self._h, ctypes.c_void_p(ip), _IDX_CODES[idt], _c64(istr), imem,
             ctypes.c_void_p(pp), _c64(pstr), pmem,

@@ -61,6 +61,7 @@ class _Renderer:
                 _lib.lib().smesh_renderer_release_image(h, None, ctypes.c_void_p(ptr))
 
         indices = DeviceArray(pi.value, (W, H), np.uint32, self.device, owner=self, on_release=rel_i)
+        indices._rendered_by = self   # add(indices, ...) can then reuse what this render left on the device
         depth = DeviceArray(pd.value, (W, H), np.float32, self.device, owner=self, on_release=rel_d)
         return indices, depth
 

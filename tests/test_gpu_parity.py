@@ -612,3 +612,72 @@ def test_fuse_view_texels_big_triangles(sm, oracle, kind):
     agg.add(idx, probs)
     oagg2.add(np.asarray(idx), probs)
     assert_fused_close(agg.get(), oagg2.get(), rtol=2e-5)
+
+
+def test_add_after_render_takes_triangle_order_path(sm, oracle):
+    """The reference's two-call loop `idx, depth = renderer.render(cam); aggregator.add(idx, probs)`
+    (colorize_cityscapes_mesh.py:65-67): add() recognises the untouched output of the latest render and runs the
+    triangle-order fusion; an older render, or an image another framework may have written to, takes the generic path.
+    All give the oracle's result."""
+    import os
+    mesh, cams = small_scene(120, 60, 320, 240, views=3)
+    P, C = len(mesh.faces), 19
+    rng = np.random.default_rng(5)
+    r = sm.render.triangles(mesh)
+    last = lambda: sm._lib.lib().smesh_last_fuse_kernel().decode()
+    agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
+    forced_generic = os.environ.get("SMESH_FUSE") == "strip"
+    for cam in cams:
+        probs = random_probs(rng, *cam.resolution, C)
+        weights = rng.random(cam.resolution, dtype=np.float32)
+        idx, depth = r.render(cam)
+        agg.add(idx, probs, weights)
+        assert last() == ("k_scatter_strip" if forced_generic else "k_fuse_tri")
+        oagg.add(o.render(cam)[0], probs, weights)
+    if not forced_generic:
+        np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+    # 1. an older render: its per-triangle records are gone -> generic path
+    probs = random_probs(rng, *cams[0].resolution, C)
+    idx0, _ = r.render(cams[0])
+    idx1, _ = r.render(cams[1])
+    agg.add(idx0, probs)
+    assert last() == "k_scatter_strip"
+    oagg.add(o.render(cams[0])[0], probs)
+    # 2. exported through __cuda_array_interface__ (someone else may have changed it) -> generic path
+    idx2, _ = r.render(cams[2])
+    _ = idx2.__cuda_array_interface__
+    agg.add(idx2, probs)
+    assert last() == "k_scatter_strip"
+    oagg.add(o.render(cams[2])[0], probs)
+    # 3. device-resident probs and the latest render -> fast path again
+    from semantic_meshes_amd.device import to_device
+    idx1b, _ = r.render(cams[1])
+    agg.add(idx1b, to_device(probs))
+    assert last() == ("k_scatter_strip" if forced_generic else "k_fuse_tri")
+    oagg.add(o.render(cams[1])[0], probs)
+    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+
+
+@pytest.mark.parametrize("C", [5, 19, 40, 7, 150])
+def test_fuse_view_small_and_big_triangles_interleaved(sm, oracle, C):
+    """Triangles of 8-12 pixels: bounding boxes on both sides of the 8 x 8 limit inside the same 64-row accumulator
+    block (regression: k_fuse_tri wrote the whole block back and overwrote the rows the big-triangle waves of the
+    same launch were updating)."""
+    mesh, cams = small_scene(100, 50, 640, 480, views=2)
+    P = len(mesh.faces)
+    rng = np.random.default_rng(C)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    agg = sm.fusion.MeshAggregator(P, C)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C)
+        for cam in cams:
+            probs = random_probs(rng, *cam.resolution, C)
+            agg.fuse_view(r, cam, probs)
+            oagg.add(o.render(cam)[0], probs)
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    finally:
+        oracle.set_accum_double(False)
