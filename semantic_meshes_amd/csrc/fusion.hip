@@ -674,6 +674,39 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
   }
 }
 
+// Cross-lane moves in registers (DPP) instead of ds_bpermute: a dependent chain of LDS round trips per pixel made
+// the wide-row kernels latency-bound.  Lanes whose source is disabled or outside the row keep `old`.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
+
+__device__ __forceinline__ float wave_sum(float v) {   // same value in every lane (read back from lane 63)
+  v += dpp_f<kDppRowShr1>(0.0f, v);
+  v += dpp_f<kDppRowShr2>(0.0f, v);
+  v += dpp_f<kDppRowShr4>(0.0f, v);
+  v += dpp_f<kDppRowShr8>(0.0f, v);
+  v += dpp_f<kDppRowBcast15, 0xA>(0.0f, v);
+  v += dpp_f<kDppRowBcast31, 0xC>(0.0f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) {
+  v += dpp_u<kDppRowShr1>(0u, v);
+  v += dpp_u<kDppRowShr2>(0u, v);
+  v += dpp_u<kDppRowShr4>(0u, v);
+  v += dpp_u<kDppRowShr8>(0u, v);
+  v += dpp_u<kDppRowBcast15, 0xA>(0u, v);
+  v += dpp_u<kDppRowBcast31, 0xC>(0u, v);
+  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Triangle-order fusion (smesh_fuse_view with a triangle renderer): the rasteriser left, per triangle, the set
 // of pixels it emitted (TriFrag).  Every accumulator row is then owned by exactly one lane: NO atomics, no
@@ -722,8 +755,7 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
       const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
       n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) n += (uint32_t)__shfl_xor((int)n, d);
+    n = wave_sum_u(n);
     if (n == 0) continue;
     const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
     float part[CT];
@@ -754,9 +786,7 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
     float mine = 0.0f;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-      float v = part[c];
-#pragma unroll
-      for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+      const float v = wave_sum(part[c]);
       if (l == c) mine = v;
     }
     if (l < C) a.acc[(uint64_t)f * C + l] += mine;   // this wave owns the row: plain read-modify-write
@@ -902,19 +932,6 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
 // result -- is the single-threaded reference's.  Loads are 16 bytes wide at 4-byte alignment (rows are only
 // float-aligned).  Big triangles: tail blocks, chunked over kSlice classes (fuse_big_triangles_any).
 // ------------------------------------------------------------------------------------------------
-// Cross-lane moves in registers (DPP) instead of ds_bpermute: a dependent chain of LDS round trips per pixel made
-// the wide-row kernels latency-bound.  Lanes whose source is disabled or outside the row keep `old`.
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float dpp_f(float old, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
-constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
-
 constexpr int kSlice = 40;
 constexpr uint32_t kSkipPixel = 0x7FC00001u;   // NaN payload in `pw`: pixel dropped by the don't-care test
 
@@ -984,8 +1001,7 @@ __device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, uin
       const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
       n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
     }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) n += (uint32_t)__shfl_xor((int)n, d);
+    n = wave_sum_u(n);
     if (n == 0) continue;
     const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
     for (long long i = l; i < npx; i += kWave) {
@@ -1022,9 +1038,7 @@ __device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, uin
       float mine = 0.0f;
 #pragma unroll
       for (int j = 0; j < kSlice; j++) {
-        float v = part[j];
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+        const float v = wave_sum(part[j]);
         if (l == j) mine = v;
       }
       if (l < cw) a.acc[(uint64_t)f * C + c0 + l] += mine;   // this wave owns the row: plain read-modify-write
@@ -1132,16 +1146,6 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a) {
 // tree-reduces the row and its absolute values; only if that estimate is within its own error bound of 0.5
 // does it replay the additions one class at a time (never for probability rows, whose sums are ~1 or 0).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {   // same value in every lane (read back from lane 63)
-  v += dpp_f<kDppRowShr1>(0.0f, v);
-  v += dpp_f<kDppRowShr2>(0.0f, v);
-  v += dpp_f<kDppRowShr4>(0.0f, v);
-  v += dpp_f<kDppRowShr8>(0.0f, v);
-  v += dpp_f<kDppRowBcast15, 0xA>(0.0f, v);
-  v += dpp_f<kDppRowBcast31, 0xC>(0.0f, v);
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
 // One lane's share of a row: NCH chunks of four classes, chunk k covering classes 4 (l + 64 k) .. + 3.
 template <int NCH>
 __device__ __forceinline__ void load_wide(const float* __restrict__ src, uint32_t C, int l, fvec4 (&v)[NCH]) {
@@ -1838,8 +1842,9 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
     }
     t.tri_blocks = wide_chunks ? (uint32_t)div_up(F, kWave) : (uint32_t)div_up(F, kWave / G);
   }
-  const dim3 grid(t.tri_blocks + (uint32_t)std::max(1, ctx->num_cus)), block(kWave);   // + one big-triangle wave per CU
-  const dim3 tgrid(t.tri_blocks), bgrid((uint32_t)std::max(1, ctx->num_cus));          // any-C paths: big triangles in a second launch
+  const uint32_t big_waves = 12u * (uint32_t)std::max(1, ctx->num_cus);    // one wave per queued big triangle at a time; they exit at once if the queue is empty
+  const dim3 grid(t.tri_blocks + big_waves), block(kWave);
+  const dim3 tgrid(t.tri_blocks), bgrid(big_waves);                        // any-C paths: big triangles in a second launch
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
 #define SMESH_FA(K)                                                                            \
@@ -1898,7 +1903,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   t.tri_blocks = (uint32_t)div_up(F, kWave);
   t.dbg = 0;
   t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count;
-  const dim3 tgrid(t.tri_blocks), bgrid((uint32_t)std::max(1, ctx->num_cus)), block(kWave);
+  const dim3 tgrid(t.tri_blocks), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave);
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
     switch (a->kind) {

@@ -68,7 +68,7 @@ struct CameraArgs {
 __global__ void k_project_vertices(const float* __restrict__ verts, uint64_t V, CameraArgs cam,
                                    ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i == 0) big_count[0] = 0u;
+  if (i == 0) { big_count[0] = 0u; big_count[2] = 0u; }
   if (i >= V) return;
   const float X = verts[3 * i + 0], Y = verts[3 * i + 1], Z = verts[3 * i + 2];
   const float xc = ((cam.R[0] * X + cam.R[1] * Y) + cam.R[2] * Z) + cam.t[0];
@@ -198,6 +198,7 @@ __device__ __forceinline__ uint32_t texel_of(uint32_t res, double b1, double b2)
 
 // Fragment queues of the default path: one queue per 32 x 64 pixel screen tile (see k_raster_frag / k_tile_resolve).
 constexpr int kQW = 32, kQH = 64, kQPixels = kQW * kQH;
+constexpr int kMedium = 64;   // boxes up to kMedium x kMedium (and larger than 8 x 8) are rasterised by a whole wave inside k_raster_frag
 constexpr unsigned long long kNullKey = ~0ull;   // loses every depth test, including against the background key
 
 struct FragQueues {
@@ -216,11 +217,13 @@ struct RasterArgs {
   unsigned long long* keys;
   uint64_t F, V;
   uint32_t W, H;
-  uint32_t* big_queue;        // triangles deferred to the cooperative kernel
-  uint32_t* big_count;
+  uint32_t* big_queue;        // triangles with a box larger than 8 x 8 (the fusion's cooperative waves walk it)
+  uint32_t* huge_queue;       // ... of those, the ones larger than kMedium x kMedium: rasterised by the tile workgroups
+  uint32_t* big_count;        // [0] length of big_queue, [2] length of huge_queue
   uint32_t big_capacity;
   TriFrag* frags;             // per-triangle fragment records for the triangle-order fusion (may be null)
   FragQueues q;               // fragment-queue path only
+  uint32_t tpw;               // k_raster_frag: triangles per wave (power of two <= 64)
   int dbg;                    // development ablation (SMESH_RDBG): 1 = no atomics, 2 = setup only
 };
 
@@ -371,26 +374,35 @@ __device__ __forceinline__ double flip_sign(double v, uint32_t hi_mask) {
 // The edge functions are shade()'s, regrouped: s * (sign * (a - b)) is +-(a - b) exactly, so the two sign
 // multiplications become one XOR of the sign bit, and b = dy * (px - lx) is hoisted out of the row loop.
 __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
-  const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // a.tpw triangles per wave (64 for large meshes; fewer for small ones, so that the cooperative medium-triangle
+  // loop below has enough waves to spread over the chip)
   const int lane = threadIdx.x & 63;
+  const uint64_t wave0 = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * a.tpw;   // first triangle of this wave
+  const uint64_t f = lane < (int)a.tpw ? wave0 + lane : a.F;
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   Tri t;
   t.x0 = 0; t.y0 = 0;
   unsigned long long cover = 0ull;
   uint32_t n0 = 0u, n1 = 0u, n2 = 0u;   // sign-bit masks of the three edge functions
+  bool medium = false;
   if (f < a.F && load_tri(a, f, t)) {
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
     rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
+    n0 = (t.s * t.e0.sign < 0.0) ? 0x80000000u : 0u;
+    n1 = (t.s * t.e1.sign < 0.0) ? 0x80000000u : 0u;
+    n2 = (t.s * t.e2.sign < 0.0) ? 0x80000000u : 0u;
     if (bw > 8 || bh > 8) {
-      const uint32_t slot = atomicAdd(a.big_count, 1u);
+      const uint32_t slot = atomicAdd(a.big_count, 1u);          // every such triangle: the fusion walks this queue
       if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
       rec.kind = 2;
       rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
+      if (bw <= kMedium && bh <= kMedium) medium = true;         // rasterised below by the whole wave
+      else {                                                     // rasterised by the tile workgroups it overlaps
+        const uint32_t hs = atomicAdd(a.big_count + 2, 1u);
+        if (hs < a.big_capacity) a.huge_queue[hs] = (uint32_t)f;
+      }
     } else if (!(a.dbg & 2)) {
-      n0 = (t.s * t.e0.sign < 0.0) ? 0x80000000u : 0u;
-      n1 = (t.s * t.e1.sign < 0.0) ? 0x80000000u : 0u;
-      n2 = (t.s * t.e2.sign < 0.0) ? 0x80000000u : 0u;
       // one flattened loop over the box (trip count bw * bh, not max bw x max bh over the wave's lanes)
       const int area = bw * bh;
       int dx = 0, dy = 0;
@@ -465,11 +477,87 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   if (mask) rec.kind = 1;
   if (rec.kind == 1) rec.mask = mask;
   if (a.frags && f < a.F) a.frags[f] = rec;
+
+  // ---- medium triangles (box up to kMedium x kMedium): one at a time, all 64 lanes on its bounding box.  The
+  // triangle is broadcast from its owner lane (readlane -> scalar registers).  Queue slots: the box overlaps at most
+  // 3 x 2 tiles; in each the whole sub-rectangle is reserved with one atomic (a sample's slot is its position in
+  // the sub-rectangle) and samples the triangle does not cover store the null key -- no per-fragment bookkeeping.
+  // All reservations of the wave are issued first, by the owner lanes: one memory round trip, not one per triangle.
+  uint32_t rb0 = 0u, rb1 = 0u, rb2 = 0u, rb3 = 0u, rb4 = 0u, rb5 = 0u;   // queue bases of this lane's (<= 3 x 2) sub-rectangles
+  if (medium && !(a.dbg & 1)) {
+    const int tX0 = t.x0 / kQW, tY0 = t.y0 / kQH;
+    const int ntx = t.x1 / kQW - tX0 + 1, nty = t.y1 / kQH - tY0 + 1;
+    auto reserve = [&](int j) -> uint32_t {
+      if (j >= ntx * nty) return 0u;
+      const int jx = tX0 + j / nty, jy = tY0 + j % nty;
+      const int wx = min(t.x1, jx * kQW + kQW - 1) - max(t.x0, jx * kQW) + 1, hy = min(t.y1, jy * kQH + kQH - 1) - max(t.y0, jy * kQH) + 1;
+      return atomicAdd(&a.q.count[(uint32_t)jx * a.q.tiles_y + (uint32_t)jy], (uint32_t)(wx * hy));
+    };
+    rb0 = reserve(0); rb1 = reserve(1); rb2 = reserve(2); rb3 = reserve(3); rb4 = reserve(4); rb5 = reserve(5);   // in flight together
+  }
+  unsigned long long todo = __ballot(medium);
+  while (todo) {
+    const int src = __ffsll((long long)todo) - 1;
+    todo &= todo - 1ull;
+    auto bi = [&](int v) -> int { return __builtin_amdgcn_readlane(v, src); };
+    auto bd = [&](double v) -> double { return __hiloint2double(bi(__double2hiint(v)), bi(__double2loint(v))); };
+    const int X0 = bi(t.x0), X1 = bi(t.x1), Y0 = bi(t.y0), Y1 = bi(t.y1);
+    const double e0lx = bd(t.e0.lx), e0ly = bd(t.e0.ly), e0dx = bd(t.e0.dx), e0dy = bd(t.e0.dy);
+    const double e1lx = bd(t.e1.lx), e1ly = bd(t.e1.ly), e1dx = bd(t.e1.dx), e1dy = bd(t.e1.dy);
+    const double e2lx = bd(t.e2.lx), e2ly = bd(t.e2.ly), e2dx = bd(t.e2.dx), e2dy = bd(t.e2.dy);
+    const double iz0 = bd(t.iz0), iz1 = bd(t.iz1), iz2 = bd(t.iz2);
+    const uint32_t m0 = (uint32_t)bi((int)n0), m1 = (uint32_t)bi((int)n1), m2 = (uint32_t)bi((int)n2);
+    const int owns = bi((t.own0 ? 1 : 0) | (t.own1 ? 2 : 0) | (t.own2 ? 4 : 0));
+    const uint32_t fb = (uint32_t)wave0 + (uint32_t)src;
+    uint32_t tfirst = 0u, tres = 0u;
+    if (a.tex_res) { tfirst = a.tex_first[fb]; tres = a.tex_res[fb]; }
+    const int tX0 = X0 / kQW, tY0 = Y0 / kQH, nty = Y1 / kQH - tY0 + 1;
+    const uint32_t sb0 = (uint32_t)bi((int)rb0), sb1 = (uint32_t)bi((int)rb1), sb2 = (uint32_t)bi((int)rb2),
+                   sb3 = (uint32_t)bi((int)rb3), sb4 = (uint32_t)bi((int)rb4), sb5 = (uint32_t)bi((int)rb5);
+    const int bh = Y1 - Y0 + 1, area = (X1 - X0 + 1) * bh;
+    for (int i = lane; i < area + lane; i += 64) {   // every lane runs the same number of steps (readlane inside)
+      const bool in_box = i < area;
+      const int x = X0 + (in_box ? i / bh : 0), y = Y0 + (in_box ? i % bh : 0);
+      const double px = (double)x + 0.5, py = (double)y + 0.5;
+      const double w0 = flip_sign(e0dx * (py - e0ly) - e0dy * (px - e0lx), m0);
+      const double w1 = flip_sign(e1dx * (py - e1ly) - e1dy * (px - e1lx), m1);
+      const double w2 = flip_sign(e2dx * (py - e2ly) - e2dy * (px - e2lx), m2);
+      const bool cov = (w0 > 0.0 || (w0 == 0.0 && (owns & 1))) & (w1 > 0.0 || (w1 == 0.0 && (owns & 2))) &
+                       (w2 > 0.0 || (w2 == 0.0 && (owns & 4)));
+      unsigned long long key = kNullKey;
+      if (in_box && cov) {
+        const double num = (w0 + w1) + w2;
+        const double den = (w0 * iz0 + w1 * iz1) + w2 * iz2;
+        const float zf = (float)(num / den);
+        if (zf > 0.0f && isfinite(zf)) {
+          uint32_t prim = fb;
+          if (a.tex_res) prim = tfirst + texel_of(tres, w1 / num, w2 / num);
+          key = ((unsigned long long)__float_as_uint(zf) << 32) | prim;
+        }
+      }
+      // slot of this sample inside its tile's sub-rectangle
+      const int jx = x / kQW, jy = y / kQH;
+      const int xlo = max(X0, jx * kQW), ylo = max(Y0, jy * kQH), hy = min(Y1, jy * kQH + kQH - 1) - ylo + 1;
+      const int jt = (jx - tX0) * nty + (jy - tY0);
+      const uint32_t tb = jt == 0 ? sb0 : jt == 1 ? sb1 : jt == 2 ? sb2 : jt == 3 ? sb3 : jt == 4 ? sb4 : sb5;
+      const uint32_t slot = tb + (uint32_t)((x - xlo) * hy + (y - ylo));
+      const uint32_t tile = (uint32_t)jx * a.q.tiles_y + (uint32_t)jy;
+      if (!in_box || (a.dbg & 1)) continue;
+      if (slot < a.q.cap) {
+        const uint64_t e = (uint64_t)tile * a.q.cap + slot;
+        a.q.key[e] = key;
+        a.q.pix[e] = (uint16_t)((x - jx * kQW) * kQH + (y - jy * kQH));
+      } else if (key != kNullKey) {
+        atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
+        a.q.flag[tile] = 1u;
+      }
+    }
+  }
 }
 
 // One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
 // > 8 x 8: the workgroup scans their queue, keeps those whose box overlaps the tile and shades the overlap, 256
-// samples at a time), then the output planes are written once.
+// samples at a time), then the output planes are written once.  "Big" here means larger than kMedium x kMedium.
 __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out) {
   __shared__ unsigned long long skeys[kQPixels];
   __shared__ uint32_t s_hits[256];
@@ -482,7 +570,7 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
   const uint32_t x0 = tx * kQW, y0 = ty * kQH;
   const uint32_t n = min(q.count[tile], q.cap);
   const bool merge = q.flag[tile] != 0u;
-  const uint32_t nbig = min(*a.big_count, a.big_capacity);
+  const uint32_t nbig = min(a.big_count[2], a.big_capacity);   // triangles larger than kMedium x kMedium
   for (int p = t; p < kQPixels; p += 256) {
     const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
     unsigned long long k = kBackgroundKey;
@@ -501,7 +589,7 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
   for (uint32_t qb = 0; qb < nbig; qb += 256u) {
     const uint32_t qi = qb + (uint32_t)t;
     if (qi < nbig) {
-      const uint32_t f = a.big_queue[qi];
+      const uint32_t f = a.huge_queue[qi];
       const TriFrag rec = a.frags[f];
       const int bx1 = (int)(rec.mask & 0xFFFFu), by1 = (int)((rec.mask >> 16) & 0xFFFFu);
       if (rec.kind == 2 && (int)rec.x0 <= tx1 && bx1 >= (int)x0 && (int)rec.y0 <= ty1 && by1 >= (int)y0)
@@ -611,6 +699,7 @@ struct smesh_renderer {
   float* verts = nullptr;          // float32[V*3]
   int32_t* faces = nullptr;        // int32[F*3]
   ScreenVertex* sv = nullptr;      // per-view projected vertices [V]
+  uint32_t* huge_queue = nullptr;  // [big_capacity] triangles larger than kMedium x kMedium of the render in progress
   bool texels = false;
   uint32_t* tex_res = nullptr;     // [F]
   uint32_t* tex_first = nullptr;   // [F]
@@ -737,13 +826,16 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     a.faces = r->faces; a.sv = r->sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
     a.keys = r->keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
     a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
+    a.huge_queue = r->huge_queue;
     a.frags = r->side[side].frags;
     { static const int rdbg = getenv("SMESH_RDBG") ? atoi(getenv("SMESH_RDBG")) : 0; a.dbg = rdbg; }
     const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
     int qs = SMESH_OK;
     if (raster_path() == RasterPath::Frag && ensure_queues(r, W, H, st, &qs)) {
       a.q = r->fq;
-      hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(r->F, 256)), dim3(256), 0, st, a);
+      a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~2048 waves
+      while (a.tpw > 1 && r->F / a.tpw < 2048) a.tpw >>= 1;
+      hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(div_up(r->F, a.tpw), 4)), dim3(256), 0, st, a);
       SMESH_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_tile_resolve, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a, d_idx, d_depth);
       SMESH_HIP(hipGetLastError());
@@ -819,6 +911,7 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->faces), std::max<uint64_t>(F * 12, 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
   if (e == hipSuccess) e = alloc_side(r, 0);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->huge_queue), (size_t)r->big_capacity * 4);
   if (e == hipSuccess && V) e = hipMemcpyAsync(r->verts, vertices, V * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -972,7 +1065,7 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->raster_stream);
   (void)hipStreamSynchronize(r->ctx->stream);
-  for (void* p : {(void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
+  for (void* p : {(void*)r->huge_queue, (void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
                   (void*)r->side[0].big_queue, (void*)r->side[0].big_count, (void*)r->side[0].frags, (void*)r->side[1].big_queue,
                   (void*)r->side[1].big_count, (void*)r->side[1].frags})
     if (p) (void)hipFree(p);
