@@ -54,24 +54,37 @@ def cpu_baseline(workload, budget_s=20.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    # the same sample with the one obvious CPU optimisation (dense parallel histogram instead of the serial std::map):
-    # reported beside the faithful port so that the ratio is not only against the reference's serial step
+    # the same sample with the one obvious CPU optimisation (dense parallel histogram instead of the serial std::map)
+    # at the thread count that suits this host best: reported beside the faithful port so that the ratio is not only
+    # against the reference's serial step (256 threads contending for one histogram are slower than 32)
     oracle.set_fast_histogram(True)
     agg2 = oracle.OracleAggregator(P, C)
-    done2, t1 = 0, time.perf_counter()
-    while done2 < len(cams):
-        idx, _ = r.render(cams[done2])
-        agg2.add(idx, probs)
+
+    def run_views(nthreads, first, count):
+        oracle.set_threads(nthreads)
+        t = time.perf_counter()
+        for k in range(first, first + count):
+            idx, _ = r.render(cams[k % len(cams)])
+            agg2.add(idx, probs)
+        return count / (time.perf_counter() - t)
+
+    candidates = sorted({c for c in (16, 32, 64, 128, cores) if c <= cores})
+    run_views(candidates[0], 0, 1)   # page in
+    rates = {c: run_views(c, 1, 2) for c in candidates}
+    best = max(rates, key=rates.get)
+    t1 = time.perf_counter()
+    done2 = 0
+    while time.perf_counter() - t1 < budget_s / 3:
+        run_views(best, 3 + done2, 1)
         done2 += 1
-        if time.perf_counter() - t1 > budget_s / 2:
-            break
     dt2 = time.perf_counter() - t1
     oracle.set_fast_histogram(False)
     oracle.set_threads(1)
     return {"value": round(done / dt, 3), "unit": "views/s", "cores": cores, "kind": "port",
             "sample": "%d of the %s views (render + add), %d OpenMP threads, %.1f s" % (done, workload, cores, dt),
-            "optimised_cpu": {"value": round(done2 / dt2, 3), "unit": "views/s",
-                              "what": "same port with a dense parallel histogram instead of the reference's serial std::map",
+            "optimised_cpu": {"value": round(done2 / dt2, 3), "unit": "views/s", "cores": best,
+                              "what": "same port with a dense parallel histogram instead of the reference's serial std::map, "
+                                      "best of %s threads" % candidates,
                               "sample": "%d views, %.1f s" % (done2, dt2)}}
 
 
