@@ -759,16 +759,16 @@ RasterPath raster_path() {
   return p;
 }
 
-// Per-tile fragment queues.  Capacity per tile: 8 fragments per pixel of the tile (SMESH_FRAG_CAP overrides it;
-// fragments beyond it fall back to the global key image), shrunk if the whole set would exceed 4 GiB.
+// Per-tile fragment queues.  Capacity per tile: 16 fragments per pixel of the tile (SMESH_FRAG_CAP overrides it;
+// fragments beyond it fall back to the global key image), shrunk if the whole set would exceed 8 GiB.
 // Returns false (queues unusable -> direct path) for images with so many tiles that the capacity would drop under 1024.
 bool ensure_queues(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st, int* status) {
   *status = SMESH_OK;
   const uint64_t tiles_x = div_up(W, kQW), tiles_y = div_up(H, kQH), ntiles = tiles_x * tiles_y;
-  uint64_t cap = 8ull * kQPixels;
+  uint64_t cap = 16ull * kQPixels;
   if (const char* e = getenv("SMESH_FRAG_CAP")) cap = std::max<uint64_t>(1, (uint64_t)atoll(e));
   else {
-    const uint64_t budget = 4ull << 30;
+    const uint64_t budget = 8ull << 30;
     if (ntiles * cap * 10 > budget) cap = budget / (ntiles * 10);
     if (cap < 1024) return false;
   }
