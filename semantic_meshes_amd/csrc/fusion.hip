@@ -729,6 +729,7 @@ struct TriFuseArgs {
   uint32_t big_capacity;
   uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the rest the big-triangle queue
   int dbg;                    // development ablation (SMESH_FDBG): 1 stop after pass 1, 2 no stores, 4 no row loads, 8 no probs loads
+  const uint32_t* prim_id;    // [F] primitive id of triangle f when the renderer re-ordered its triangles (null: id == f)
   // texel primitives (k_fuse_texel) only
   const uint32_t* tex_first;  // [F] first texel id of each triangle
   const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
@@ -744,9 +745,10 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
   const int l = threadIdx.x;
   const uint32_t nbig = min(*a.big_len, a.big_capacity);
   for (uint32_t q = worker; q < nbig; q += nworkers) {
-    const uint32_t f = a.big_queue[q];
-    const TriFrag rec = a.frags[f];
+    const uint32_t fi = a.big_queue[q];                       // position in the renderer's triangle order
+    const TriFrag rec = a.frags[fi];
     if (rec.kind != 2) continue;
+    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
     const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
     const int bh = y1 - y0 + 1;
     const long long npx = (long long)(x1 - x0 + 1) * bh;
@@ -990,9 +992,10 @@ __device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, uin
   const uint32_t C = a.C;
   const uint32_t nbig = min(*a.big_len, a.big_capacity);
   for (uint32_t q = worker; q < nbig; q += nworkers) {
-    const uint32_t f = a.big_queue[q];
-    const TriFrag rec = a.frags[f];
+    const uint32_t fi = a.big_queue[q];                       // position in the renderer's triangle order
+    const TriFrag rec = a.frags[fi];
     if (rec.kind != 2) continue;
+    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
     const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
     const int bh = y1 - y0 + 1;
     const long long npx = (long long)(x1 - x0 + 1) * bh;
@@ -1059,13 +1062,14 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a) {
   const int l = threadIdx.x;
   const uint32_t C = a.C;
   const int g = l % G;                                   // rank inside the group
-  const uint64_t f = (uint64_t)blockIdx.x * TPW + (uint32_t)(l / G);
+  const uint64_t fi = (uint64_t)blockIdx.x * TPW + (uint32_t)(l / G);   // position in the renderer's triangle order
+  const uint64_t f = (a.prim_id && fi < a.F) ? (uint64_t)a.prim_id[fi] : fi;   // primitive id (index image value, accumulator row)
   const uint32_t S = G == 1 ? C : (((C + G - 1) / G + 3u) & ~3u);   // classes per lane (whole float4s when the row is split)
   const uint32_t c_lo = (uint32_t)g * S;
   const int cw = c_lo < C ? (int)min(S, C - c_lo) : 0;
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
-  if (f < a.F) rec = a.frags[f];
+  if (fi < a.F) rec = a.frags[fi];
   auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
   // pass 1 (as k_fuse_tri; the lanes of a group do it redundantly -- same addresses, one request)
   unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
@@ -1249,6 +1253,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   if (f < a.F) rec = a.frags[f];
+  const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // primitive id (index image value, accumulator row)
   auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
   unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
   unsigned long long win = 0ull;   // pass 1, lane = triangle: the emitted fragments that won the depth test
@@ -1263,7 +1268,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (k[j] >= 0 && got[j] == (uint32_t)f) win |= 1ull << k[j];
+      if (k[j] >= 0 && got[j] == pid) win |= 1ull << k[j];
   }
   unsigned long long vis = __ballot(win != 0ull);
   if (vis == 0ull || (a.dbg & 1)) return;
@@ -1276,18 +1281,19 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
     // a batch of up to B visible triangles: their accumulator rows and first pixels are requested together
     int t[B];
     unsigned long long pm[B];
-    uint32_t org[B], nt[B];
+    uint32_t org[B], nt[B], rowid[B];
     fvec4 ac[B][NCH], p[B][NCH];
     float wt[B];
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      t[b] = -1; pm[b] = 0ull; org[b] = 0u; nt[b] = 0u;
+      t[b] = -1; pm[b] = 0ull; org[b] = 0u; nt[b] = 0u; rowid[b] = 0u;
       if (vis) {
         t[b] = __ffsll((long long)vis) - 1;
         vis &= vis - 1ull;
         pm[b] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)win_lo, t[b]) |
                 ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)win_hi, t[b]) << 32);
         org[b] = (uint32_t)__builtin_amdgcn_readlane((int)origin, t[b]);
+        rowid[b] = (uint32_t)__builtin_amdgcn_readlane((int)pid, t[b]);
         nt[b] = (uint32_t)__popcll(pm[b]);
       }
     }
@@ -1295,7 +1301,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
 #pragma unroll
     for (int b = 0; b < B; b++) {
       if (t[b] < 0) continue;
-      if (!(a.dbg & 4)) load_wide<NCH>(a.acc + (f0 + (uint32_t)t[b]) * C, C, l, ac[b]);
+      if (!(a.dbg & 4)) load_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
       const uint64_t pix = pix_of(org[b], __ffsll((long long)pm[b]) - 1);
       pm[b] &= pm[b] - 1ull;
       if (!(a.dbg & 8)) load_wide<NCH>(a.probs + pix * C, C, l, p[b]);
@@ -1312,7 +1318,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
         load_wide<NCH>(a.probs + pix * C, C, l, q);
         fuse_pixel_wide<KIND, NCH>(ac[b], q, C, l, w0 * (a.weights ? a.weights[pix] : 1.0f));
       }
-      if (!(a.dbg & 2)) store_wide<NCH>(a.acc + (f0 + (uint32_t)t[b]) * C, C, l, ac[b]);
+      if (!(a.dbg & 2)) store_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
     }
   }
 }
@@ -1807,15 +1813,15 @@ static bool fuse_wide_enabled() {
   static const bool off = getenv("SMESH_FUSE_WIDE") && atoi(getenv("SMESH_FUSE_WIDE")) == 0;
   return !off;
 }
-const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a) {
-  if (a->C == 5 || a->C == 19 || a->C == 40) return "k_fuse_tri";
+const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered) {
+  if (!reordered && (a->C == 5 || a->C == 19 || a->C == 40)) return "k_fuse_tri";
   if (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) return "k_fuse_tri_wide";
   return "k_fuse_tri_any";
 }
 
-int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* big_queue,
-                                    const uint32_t* big_len, uint32_t big_capacity, const uint32_t* d_idx,
-                                    const float* d_probs, const float* d_w, uint64_t W, uint64_t H) {
+int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* prim_id,
+                                    const uint32_t* big_queue, const uint32_t* big_len, uint32_t big_capacity,
+                                    const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t W, uint64_t H) {
   DeviceCtx* ctx = a->ctx;
   hipStream_t st = ctx->stream;
   if (F == 0) return SMESH_OK;
@@ -1826,7 +1832,9 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
   t.tri_blocks = (uint32_t)div_up(F, kWave);
   { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; t.dbg = fdbg; }
   t.tex_first = nullptr; t.tex_res = nullptr; t.count = nullptr;
-  const bool specialised = a->C == 5 || a->C == 19 || a->C == 40;   // row held in registers, block staged through LDS
+  t.prim_id = prim_id;
+  // row held in registers, block staged through LDS: needs consecutive primitive ids per wave (no re-ordered mesh)
+  const bool specialised = !prim_id && (a->C == 5 || a->C == 19 || a->C == 40);
   float* pw = nullptr;
   uint32_t* amax = nullptr;
   int G = 1;
@@ -1864,7 +1872,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
       default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4>), tgrid, block, 0, st, t); break; \
     }
 #define SMESH_FT(K)                                                                           \
-    switch (a->C) {                                                                           \
+    switch (specialised ? a->C : 0u) {                                                        \
       case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K>), grid, block, 0, st, t); break;           \
       case 19: hipLaunchKernelGGL((k_fuse_tri<19, K>), grid, block, 0, st, t); break;          \
       case 40: hipLaunchKernelGGL((k_fuse_tri<40, K>), grid, block, 0, st, t); break;          \
@@ -1901,7 +1909,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.F = F; t.C = a->C;
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
-  t.dbg = 0;
+  t.dbg = 0; t.prim_id = nullptr;
   t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count;
   const dim3 tgrid(t.tri_blocks), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave);
   {

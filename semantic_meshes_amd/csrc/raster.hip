@@ -22,6 +22,8 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <utility>
+#include <vector>
 
 #pragma clang fp contract(off)
 
@@ -32,10 +34,10 @@ struct smesh_aggregator;
 int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_idx, const float* d_probs,
                                        const float* d_w, uint64_t W, uint64_t H);
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
-int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* big_queue,
-                                    const uint32_t* big_len, uint32_t big_capacity, const uint32_t* d_idx,
-                                    const float* d_probs, const float* d_w, uint64_t W, uint64_t H);
-const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a);
+int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* prim_id,
+                                    const uint32_t* big_queue, const uint32_t* big_len, uint32_t big_capacity,
+                                    const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t W, uint64_t H);
+const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
 bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P);
 int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
                                  const uint32_t* tex_res, const uint32_t* big_queue, const uint32_t* big_len,
@@ -212,6 +214,7 @@ struct FragQueues {
 struct RasterArgs {
   const int32_t* faces;
   const ScreenVertex* sv;
+  const uint32_t* prim_id;    // [F] primitive id of the triangle at position f (null: id == f; the renderer re-orders badly ordered meshes)
   const uint32_t* tex_res;    // null for triangle primitives
   const uint32_t* tex_first;
   unsigned long long* keys;
@@ -245,7 +248,7 @@ __device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri&
   float z;
   double b1, b2;
   if (!shade(t, x, y, &z, a.tex_res ? &b1 : nullptr, &b2)) return;
-  uint32_t prim = (uint32_t)f;
+  uint32_t prim = a.prim_id ? a.prim_id[f] : (uint32_t)f;
   if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
   const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | prim;
   if (a.dbg & 1) { if (key == 12345ull) a.keys[0] = key; return; }
@@ -257,7 +260,7 @@ __device__ __forceinline__ bool shade_key(const RasterArgs& a, uint64_t f, const
   float z;
   double b1, b2;
   if (!shade(t, x, y, &z, a.tex_res ? &b1 : nullptr, &b2)) return false;
-  uint32_t prim = (uint32_t)f;
+  uint32_t prim = a.prim_id ? a.prim_id[f] : (uint32_t)f;
   if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
   *key = ((unsigned long long)__float_as_uint(z) << 32) | prim;
   return true;
@@ -386,6 +389,7 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   unsigned long long cover = 0ull;
   uint32_t n0 = 0u, n1 = 0u, n2 = 0u;   // sign-bit masks of the three edge functions
   bool medium = false;
+  const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // value written to the index image
   if (f < a.F && load_tri(a, f, t)) {
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
     rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
@@ -453,7 +457,7 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
     const float zf = (float)(num / den);
     unsigned long long key = kNullKey;
     if (zf > 0.0f && isfinite(zf)) {
-      uint32_t prim = (uint32_t)f;
+      uint32_t prim = pid;
       if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], w1 / num, w2 / num);
       key = ((unsigned long long)__float_as_uint(zf) << 32) | prim;
       mask |= 1ull << bit;
@@ -509,6 +513,7 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
     const uint32_t m0 = (uint32_t)bi((int)n0), m1 = (uint32_t)bi((int)n1), m2 = (uint32_t)bi((int)n2);
     const int owns = bi((t.own0 ? 1 : 0) | (t.own1 ? 2 : 0) | (t.own2 ? 4 : 0));
     const uint32_t fb = (uint32_t)wave0 + (uint32_t)src;
+    const uint32_t fbid = (uint32_t)bi((int)pid);
     uint32_t tfirst = 0u, tres = 0u;
     if (a.tex_res) { tfirst = a.tex_first[fb]; tres = a.tex_res[fb]; }
     const int tX0 = X0 / kQW, tY0 = Y0 / kQH, nty = Y1 / kQH - tY0 + 1;
@@ -530,7 +535,7 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
         const double den = (w0 * iz0 + w1 * iz1) + w2 * iz2;
         const float zf = (float)(num / den);
         if (zf > 0.0f && isfinite(zf)) {
-          uint32_t prim = fb;
+          uint32_t prim = fbid;
           if (a.tex_res) prim = tfirst + texel_of(tres, w1 / num, w2 / num);
           key = ((unsigned long long)__float_as_uint(zf) << 32) | prim;
         }
@@ -699,6 +704,7 @@ struct smesh_renderer {
   float* verts = nullptr;          // float32[V*3]
   int32_t* faces = nullptr;        // int32[F*3]
   ScreenVertex* sv = nullptr;      // per-view projected vertices [V]
+  uint32_t* prim_id = nullptr;     // [F] primitive id per triangle position, when the triangles were re-ordered (else null)
   uint32_t* huge_queue = nullptr;  // [big_capacity] triangles larger than kMedium x kMedium of the render in progress
   bool texels = false;
   uint32_t* tex_res = nullptr;     // [F]
@@ -824,6 +830,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   if (r->F) {
     RasterArgs a;
     a.faces = r->faces; a.sv = r->sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
+    a.prim_id = r->prim_id;
     a.keys = r->keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
     a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
     a.huge_queue = r->huge_queue;
@@ -925,6 +932,67 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
 
 }  // namespace
 
+// Decides whether the face order is spatially scattered and, if so, returns the Morton order of the face centroids
+// (position -> original face).  Metric: summed extent of the centroids of every 64 consecutive faces, against what
+// neighbours would span (a few mean edge lengths); SMESH_REORDER=0 / 1 forces the answer.
+static bool spatial_order(const float* v, uint64_t V, const int32_t* f, uint64_t F, std::vector<uint32_t>& order) {
+  const char* env = getenv("SMESH_REORDER");
+  if (env && atoi(env) == 0) return false;
+  const bool force = env && atoi(env) == 1;
+  if (F < 4096 && !force) return false;
+  std::vector<float> cx(F), cy(F), cz(F);
+  double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, edge_sum = 0.0;
+  uint64_t edges = 0;
+  for (uint64_t i = 0; i < F; i++) {
+    const int32_t a = f[3 * i], b = f[3 * i + 1], c = f[3 * i + 2];
+    if (a < 0 || b < 0 || c < 0 || (uint64_t)a >= V || (uint64_t)b >= V || (uint64_t)c >= V) { cx[i] = cy[i] = cz[i] = 0.f; continue; }
+    const float* pa = v + 3 * (uint64_t)a; const float* pb = v + 3 * (uint64_t)b; const float* pc = v + 3 * (uint64_t)c;
+    cx[i] = (pa[0] + pb[0] + pc[0]) / 3.f; cy[i] = (pa[1] + pb[1] + pc[1]) / 3.f; cz[i] = (pa[2] + pb[2] + pc[2]) / 3.f;
+    if (!std::isfinite(cx[i]) || !std::isfinite(cy[i]) || !std::isfinite(cz[i])) { cx[i] = cy[i] = cz[i] = 0.f; continue; }
+    const double c3[3] = {cx[i], cy[i], cz[i]};
+    for (int d = 0; d < 3; d++) { lo[d] = std::min(lo[d], c3[d]); hi[d] = std::max(hi[d], c3[d]); }
+    if ((i & 15) == 0) { edge_sum += std::sqrt((double)(pa[0] - pb[0]) * (pa[0] - pb[0]) + (double)(pa[1] - pb[1]) * (pa[1] - pb[1]) + (double)(pa[2] - pb[2]) * (pa[2] - pb[2])); edges++; }
+  }
+  if (!(lo[0] <= hi[0]) || !edges) return false;
+  auto spread = [&](const uint32_t* ord) {   // sum over groups of 64 consecutive faces of the extent of their centroids
+    double total = 0.0;
+    for (uint64_t g = 0; g < F; g += 64) {
+      float l0 = 1e30f, l1 = 1e30f, l2 = 1e30f, h0 = -1e30f, h1 = -1e30f, h2 = -1e30f;
+      const uint64_t e = std::min<uint64_t>(F, g + 64);
+      for (uint64_t i = g; i < e; i++) {
+        const uint64_t j = ord ? ord[i] : i;
+        l0 = std::min(l0, cx[j]); h0 = std::max(h0, cx[j]); l1 = std::min(l1, cy[j]); h1 = std::max(h1, cy[j]);
+        l2 = std::min(l2, cz[j]); h2 = std::max(h2, cz[j]);
+      }
+      total += (double)(h0 - l0) + (double)(h1 - l1) + (double)(h2 - l2);
+    }
+    return total;
+  };
+  const double before = spread(nullptr);
+  const double neighbours = (double)((F + 63) / 64) * 16.0 * (edge_sum / (double)edges);   // ~8 x 8 triangles, two tangential axes
+  if (!force && before <= 6.0 * neighbours) return false;
+  // Morton code of the centroid, 21 bits per axis
+  std::vector<std::pair<uint64_t, uint32_t>> keyed(F);
+  auto spread_bits = [](uint64_t x) {
+    x &= 0x1FFFFFull;
+    x = (x | x << 32) & 0x1F00000000FFFFull; x = (x | x << 16) & 0x1F0000FF0000FFull; x = (x | x << 8) & 0x100F00F00F00F00Full;
+    x = (x | x << 4) & 0x10C30C30C30C30C3ull; x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+  };
+  const double sx = hi[0] > lo[0] ? 2097151.0 / (hi[0] - lo[0]) : 0.0, sy = hi[1] > lo[1] ? 2097151.0 / (hi[1] - lo[1]) : 0.0,
+               sz = hi[2] > lo[2] ? 2097151.0 / (hi[2] - lo[2]) : 0.0;
+  for (uint64_t i = 0; i < F; i++) {
+    const uint64_t qx = (uint64_t)std::min(2097151.0, std::max(0.0, (cx[i] - lo[0]) * sx)), qy = (uint64_t)std::min(2097151.0, std::max(0.0, (cy[i] - lo[1]) * sy)),
+                   qz = (uint64_t)std::min(2097151.0, std::max(0.0, (cz[i] - lo[2]) * sz));
+    keyed[i] = {spread_bits(qx) | (spread_bits(qy) << 1) | (spread_bits(qz) << 2), (uint32_t)i};
+  }
+  std::sort(keyed.begin(), keyed.end());
+  order.resize(F);
+  for (uint64_t i = 0; i < F; i++) order[i] = keyed[i].second;
+  if (!force && spread(order.data()) * 2.0 > before) { order.clear(); return false; }   // not worth it
+  return true;
+}
+
 static thread_local const char* g_last_fuse_kernel = "none";
 
 // The fusion half of smesh_fuse_view / smesh_aggregator_add_rendered: `d_idx` is the index plane of the render
@@ -951,10 +1019,9 @@ static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const
   }
   if (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) {
     // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
-    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->side[slot].big_queue, r->side[slot].big_count,
-                                              r->big_capacity,
-                                              d_idx, d_probs, d_w, W, H));
-    g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a);
+    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->prim_id, r->side[slot].big_queue,
+                                              r->side[slot].big_count, r->big_capacity, d_idx, d_probs, d_w, W, H));
+    g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
   } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
     // texel primitives: a triangle owns its texel rows, its lane read-modify-writes them without atomics
     SMESH_TRY(smesh_aggregator_fuse_texels(a, r->side[slot].frags, r->F, r->tex_first, r->tex_res, r->side[slot].big_queue,
@@ -976,7 +1043,23 @@ int smesh_renderer_create_triangles(const float* vertices, uint64_t V, const int
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-  return create_common(vertices, V, faces, F, device, out);
+  if ((V && !vertices) || (F && !faces)) return fail(SMESH_ERR_INVALID, "NULL mesh arrays");
+  // The kernels take 64 consecutive triangles per wave and rely on them being neighbours in space (shared cache lines,
+  // few screen tiles per wave).  A mesh whose faces come in a scattered order is processed in Morton order instead;
+  // the index image and the accumulator rows keep the caller's numbering through the position -> id table.
+  std::vector<uint32_t> order;
+  if (!spatial_order(vertices, V, faces, F, order)) return create_common(vertices, V, faces, F, device, out);
+  std::vector<int32_t> hf(3 * F);
+  for (uint64_t i = 0; i < F; i++)
+    for (int k = 0; k < 3; k++) hf[3 * i + k] = faces[3 * (uint64_t)order[i] + k];
+  smesh_renderer* r = nullptr;
+  SMESH_TRY(create_common(vertices, V, hf.data(), F, device, &r));
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->prim_id), F * 4);
+  if (e == hipSuccess) e = hipMemcpyAsync(r->prim_id, order.data(), F * 4, hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) { smesh_renderer_destroy(r); return fail_hip(e, "primitive id table upload", __FILE__, __LINE__); }
+  *out = r;
+  return SMESH_OK;
 }
 
 int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F,
@@ -1065,7 +1148,7 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->raster_stream);
   (void)hipStreamSynchronize(r->ctx->stream);
-  for (void* p : {(void*)r->huge_queue, (void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
+  for (void* p : {(void*)r->prim_id, (void*)r->huge_queue, (void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
                   (void*)r->side[0].big_queue, (void*)r->side[0].big_count, (void*)r->side[0].frags, (void*)r->side[1].big_queue,
                   (void*)r->side[1].big_count, (void*)r->side[1].frags})
     if (p) (void)hipFree(p);

@@ -681,3 +681,50 @@ def test_fuse_view_small_and_big_triangles_interleaved(sm, oracle, C):
         assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
     finally:
         oracle.set_accum_double(False)
+
+
+@pytest.mark.parametrize("C", [19, 150])
+def test_shuffled_face_order_is_reordered_internally(sm, oracle, C):
+    """A mesh whose faces come in random order is processed in Morton order inside the library; the index image and the
+    accumulator rows keep the caller's numbering.  Everything must equal the oracle run on the same (shuffled) mesh."""
+    import os
+    base, cams = small_scene(120, 60, 320, 240, views=3)
+    rng = np.random.default_rng(42)
+    perm = rng.permutation(len(base.faces))
+    faces = np.ascontiguousarray(base.faces[perm])
+    mesh = sm.data.Mesh(base.vertices, faces)
+    P = len(faces)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(base.vertices, faces)
+    agg, oagg = sm.fusion.MeshAggregator(P, C, "sum", 0.5), oracle.OracleAggregator(P, C, "sum", 0.5)
+    for cam in cams:
+        idx, depth = r.render(cam)
+        oidx, odepth = o.render(cam)
+        np.testing.assert_array_equal(np.asarray(idx), oidx)
+        np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+        probs = random_probs(rng, *cam.resolution, C)
+        agg.fuse_view(r, cam, probs)
+        oagg.add(oidx, probs)
+    if os.environ.get("SMESH_FUSE") != "strip":
+        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == ("k_fuse_tri_any" if C == 19 else "k_fuse_tri_wide")
+        np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    # render() + add() on the re-ordered renderer, and bigger triangles (cooperative paths) with the id table
+    coarse, cams2 = small_scene(60, 30, 640, 480, views=2)
+    perm2 = rng.permutation(len(coarse.faces))
+    faces2 = np.ascontiguousarray(coarse.faces[perm2])
+    r2 = sm.render.triangles(sm.data.Mesh(coarse.vertices, faces2))
+    o2 = oracle.OracleRenderer(coarse.vertices, faces2)
+    agg2 = sm.fusion.MeshAggregator(len(faces2), C)
+    oracle.set_accum_double(True)
+    try:
+        oagg2 = oracle.OracleAggregator(len(faces2), C)
+        for cam in cams2:
+            probs = random_probs(rng, *cam.resolution, C)
+            idx, _ = r2.render(cam)
+            np.testing.assert_array_equal(np.asarray(idx), o2.render(cam)[0])
+            agg2.add(idx, probs)
+            oagg2.add(np.asarray(idx), probs)
+        assert_fused_close(agg2.get(), oagg2.get(), rtol=2e-5)
+    finally:
+        oracle.set_accum_double(False)

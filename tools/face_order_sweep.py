@@ -1,4 +1,4 @@
-"""Scratch: how much does the triangle ORDER of the mesh matter?  cfg2 mesh with faces in grid order, shuffled inside
+"""Development check: how much does the triangle ORDER of the mesh matter?  cfg2 mesh with faces in grid order, shuffled inside
 windows of 4096 faces, and fully shuffled."""
 import sys, os, time
 import numpy as np
