@@ -725,7 +725,7 @@ struct TriFuseArgs {
   uint32_t C, H;
   float iew;
   const uint32_t* big_queue;
-  const uint32_t* big_len;    // queue length of this render (kept by k_resolve)
+  const uint32_t* big_len;    // queue length of this render (emptied by the next render's vertex kernel)
   uint32_t big_capacity;
   uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the rest the big-triangle queue
   int dbg;                    // development ablation (SMESH_FDBG): 1 stop after pass 1, 2 no stores, 4 no row loads, 8 no probs loads

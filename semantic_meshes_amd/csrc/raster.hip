@@ -2,9 +2,13 @@
 //
 // Replaces (citations relative to /root/reference):
 //   include/semantic_meshes/render/TriangleRenderer.h:30-39   mesh upload            -> smesh_renderer_create_triangles
-//   include/semantic_meshes/render/TriangleRenderer.h:75-78   clear {+inf, -1}       -> fused into k_resolve (keys are re-armed while being read)
-//   include/semantic_meshes/render/TriangleRenderer.h:81-88   DeviceMutexRasterizer  -> k_project_vertices + k_raster_*
-//   python/semantic_meshes/include/Renderer.h:32-35           AoS -> SoA split       -> k_resolve writes both planes
+//   include/semantic_meshes/render/TriangleRenderer.h:75-78   clear {+inf, -1}       -> nothing to clear: k_tile_resolve starts every tile from the background key
+//   include/semantic_meshes/render/TriangleRenderer.h:81-88   DeviceMutexRasterizer  -> k_project_vertices + k_raster_frag + k_tile_resolve
+//   python/semantic_meshes/include/Renderer.h:32-35           AoS -> SoA split       -> k_tile_resolve writes the two planes directly
+//
+// Default path: per-tile fragment queues + depth test in LDS (k_raster_frag / k_tile_resolve, see the banner further
+// down).  Kept beside it: the direct path (k_raster_small / k_raster_big / k_resolve: one global 64-bit atomicMin per
+// fragment on a key image), used for images with too many tiles for the queues and with SMESH_RASTER=direct.
 //
 // The rasteriser's arithmetic is NOT in the reference tree (template-tensors submodule is empty), so the
 // sampling / fill / depth / tie rules are this project's documented decisions (DESIGN.md "Raster spec",
@@ -266,7 +270,7 @@ __device__ __forceinline__ bool shade_key(const RasterArgs& a, uint64_t f, const
   return true;
 }
 
-// One lane per triangle; triangles whose bounding box exceeds 8 x 8 pixels are queued for k_raster_big.
+// Direct path.  One lane per triangle; triangles whose bounding box exceeds 8 x 8 pixels are queued for k_raster_big.
 // Besides the depth-tested keys, each triangle leaves a TriFrag record (which pixels it emitted).
 __global__ void k_raster_small(RasterArgs a) {
   const uint64_t f = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,9 +333,10 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a, uint32_t chunk
 // (key, pixel-in-tile) to the queue of its 32 x 64 pixel screen tile -- slots are reserved with ONE atomic per
 // (wave, distinct tile), the stores of neighbouring lanes land next to each other -- and k_tile_resolve runs
 // the depth test of a tile in LDS (ds_min_u64) and writes the output planes once, coalesced: no global atomic
-// per fragment, no key image to clear or split.  Fragments beyond a queue's capacity and the fragments of big
-// triangles (k_raster_big) still go through the global key image; the tiles they touch are flagged and merge
-// (and re-arm) their part of it.
+// per fragment, no key image to clear or split.  Triangles with a box larger than 8 x 8 are rasterised by the whole
+// wave (boxes up to 64 x 64) or by the tile workgroups they overlap (larger).  Only fragments beyond a queue's
+// capacity still go through the global key image: the tiles they touch are flagged and merge (and re-arm) their
+// part of it.
 // ------------------------------------------------------------------------------------------------
 
 // wave64 inclusive scan in registers: DPP row_shr 1,2,4,8 inside the 16-lane rows, then row_bcast:15 / row_bcast:31
@@ -372,7 +377,7 @@ __device__ __forceinline__ double flip_sign(double v, uint32_t hi_mask) {
   return __hiloint2double(__double2hiint(v) ^ (int)hi_mask, __double2loint(v));
 }
 
-// One lane per triangle (bounding box <= 8 x 8, else queued for k_raster_big): coverage walk, slot
+// One lane per triangle (bounding box <= 8 x 8; larger ones: see the end of the kernel): coverage walk, slot
 // reservation in the (at most 2 x 2) tiles the box overlaps, then depth per covered sample and the queue stores.
 // The edge functions are shade()'s, regrouped: s * (sign * (a - b)) is +-(a - b) exactly, so the two sign
 // multiplications become one XOR of the sign bit, and b = dy * (px - lx) is hoisted out of the row loop.
