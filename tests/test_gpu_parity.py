@@ -728,3 +728,86 @@ def test_shuffled_face_order_is_reordered_internally(sm, oracle, C):
         assert_fused_close(agg2.get(), oagg2.get(), rtol=2e-5)
     finally:
         oracle.set_accum_double(False)
+
+
+def test_render_and_add_from_two_threads(sm, oracle):
+    """The reference's harness renders on the main thread while a worker thread adds the previous view
+    (python/scripts/eval_scannet.py:189-238); the GIL is released inside every entry point.  Same result as the
+    sequential oracle, no deadlock."""
+    import queue
+    import threading
+    mesh, cams = small_scene(120, 60, 320, 240, views=3)
+    cams = cams * 4
+    P, C = len(mesh.faces), 19
+    rng = np.random.default_rng(9)
+    all_probs = [random_probs(rng, *cam.resolution, C) for cam in cams]
+    r = sm.render.triangles(mesh)
+    agg = sm.fusion.MeshAggregator(P, C)
+    q = queue.Queue(maxsize=2)
+    errors = []
+
+    def worker():
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    return
+                idx, probs = item
+                agg.add(idx, probs)
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    t = threading.Thread(target=worker)
+    t.start()
+    for cam, probs in zip(cams, all_probs):
+        idx, depth = r.render(cam)
+        q.put((idx, probs))
+    q.put(None)
+    t.join(timeout=120)
+    assert not t.is_alive() and not errors
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C)
+        for cam, probs in zip(cams, all_probs):
+            oagg.add(o.render(cam)[0], probs)
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    finally:
+        oracle.set_accum_double(False)
+
+
+def test_degenerate_geometry(sm, oracle):
+    """Zero-area, duplicate, out-of-range-index, behind-the-camera and non-finite triangles next to valid ones."""
+    from semantic_meshes_amd import synth
+    mesh, cams = small_scene(30, 15, 200, 150, views=2)
+    v = mesh.vertices.copy()
+    extra_v = np.array([[0, 0, 0], [0, 0, 0], [1, 1, 1], [np.nan, 0, 0], [1e30, 1e30, 1e30], [0.1, 0.2, 50.0]], np.float32)
+    nv = len(v)
+    verts = np.concatenate([v, extra_v])
+    bad = np.array([[nv, nv + 1, nv + 2],          # two identical vertices: zero area
+                    [0, 0, 0],                     # one vertex three times
+                    [nv + 3, 1, 2],                # NaN coordinate
+                    [nv + 4, 1, 2],                # absurd coordinate
+                    [-1, 1, 2],                    # negative index
+                    [len(verts) + 5, 1, 2],        # index past the end
+                    [nv + 5, 3, 4]], np.int32)     # far behind / in front of nothing special
+    faces = np.concatenate([mesh.faces[:200], bad, mesh.faces[200:], mesh.faces[:50]]).astype(np.int32)   # + exact duplicates
+    with pytest.raises(ValueError):
+        sm.data.Mesh(verts, faces)                 # the host-side mesh type refuses out-of-range indices ...
+    import types
+    r = sm.render.triangles(types.SimpleNamespace(vertices=verts, faces=faces))   # ... the library itself just skips such faces
+    o = oracle.OracleRenderer(verts, faces)
+    P, C = len(faces), 5
+    rng = np.random.default_rng(3)
+    agg, oagg = sm.fusion.MeshAggregator(P, C), oracle.OracleAggregator(P, C)
+    for cam in cams:
+        idx, depth = r.render(cam)
+        oidx, odepth = o.render(cam)
+        np.testing.assert_array_equal(np.asarray(idx), oidx)
+        np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+        probs = random_probs(rng, *cam.resolution, C)
+        agg.fuse_view(r, cam, probs)
+        oagg.add(oidx, probs)
+    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    # duplicates: the lower id wins everywhere (B-4), so the re-appended copies of faces 0..49 never show up
+    assert not np.isin(np.asarray(idx), np.arange(P - 50, P)).any()
