@@ -204,15 +204,19 @@ __device__ __forceinline__ uint32_t texel_of(uint32_t res, double b1, double b2)
 
 // Fragment queues of the default path: one queue per 32 x 64 pixel screen tile (see k_raster_frag / k_tile_resolve).
 constexpr int kQW = 32, kQH = 64, kQPixels = kQW * kQH;
+constexpr int kQSub = 4;      // sub-queues per tile: a wave appends to sub-queue (wave id % kQSub).  Returning atomics on ONE address are
+                              // served one after the other: with a single counter per tile the ~70 reservations a cfg2 tile receives per
+                              // view cost k_raster_frag 19 of its 44 us.  Measured 2 / 4 / 8 / 16 sub-queues: k_raster_frag 34.5 / 33.1 /
+                              // 32.7 / 32.0 us, k_tile_resolve (which reads them back) 8.2 / 9.0 / 10.7 / 15.1 us.
 constexpr int kMedium = 64;   // boxes up to kMedium x kMedium (and larger than 8 x 8) are rasterised by a whole wave inside k_raster_frag
 constexpr unsigned long long kNullKey = ~0ull;   // loses every depth test, including against the background key
 
 struct FragQueues {
-  unsigned long long* key = nullptr;   // [ntiles * cap] depth-test keys
-  uint16_t* pix = nullptr;             // [ntiles * cap] pixel inside the tile: (x - tile_x0) * kQH + (y - tile_y0)
-  uint32_t* count = nullptr;           // [ntiles] fragments queued (may exceed cap: the excess went to the key image)
+  unsigned long long* key = nullptr;   // [ntiles * kQSub * cap] depth-test keys
+  uint16_t* pix = nullptr;             // [ntiles * kQSub * cap] pixel inside the tile: (x - tile_x0) * kQH + (y - tile_y0)
+  uint32_t* count = nullptr;           // [ntiles * kQSub] fragments queued per sub-queue (may exceed cap: the excess went to the key image)
   uint32_t* flag = nullptr;            // [ntiles] nonzero: the global key image holds fragments of this tile
-  uint32_t cap = 0, tiles_y = 0;
+  uint32_t cap = 0, tiles_y = 0;       // cap: slots per SUB-queue
 };
 
 struct RasterArgs {
@@ -385,7 +389,9 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   // a.tpw triangles per wave (64 for large meshes; fewer for small ones, so that the cooperative medium-triangle
   // loop below has enough waves to spread over the chip)
   const int lane = threadIdx.x & 63;
-  const uint64_t wave0 = (((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * a.tpw;   // first triangle of this wave
+  const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const uint64_t wave0 = wave_id * a.tpw;   // first triangle of this wave
+  const uint32_t sub = (uint32_t)wave_id & (kQSub - 1);   // this wave's sub-queue in every tile
   const uint64_t f = lane < (int)a.tpw ? wave0 + lane : a.F;
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
@@ -427,6 +433,7 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
       }
     }
   }
+  if (a.dbg & 4) { if (a.frags && f < a.F) { rec.mask = cover; a.frags[f] = rec; } return; }   // ablation: setup + coverage only
   // split the box at the tile borders: columns dx < bx / rows dy < by belong to tile (tx0, ty0)
   const uint32_t tx0 = (uint32_t)t.x0 / kQW, ty0 = (uint32_t)t.y0 / kQH;
   const int bx = (int)(tx0 + 1) * kQW - t.x0, by = (int)(ty0 + 1) * kQH - t.y0;
@@ -440,15 +447,18 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   const Claim c2 = wave_claim_prepare(T0 + 1u, (uint32_t)__popcll(cover & lox & ~loy));
   const Claim c3 = wave_claim_prepare(T0 + a.q.tiles_y + 1u, (uint32_t)__popcll(cover & ~lox & ~loy));
   uint32_t g0 = 0u, g1 = 0u, g2 = 0u, g3 = 0u;
-  if (c0.total && lane == c0.leader) g0 = atomicAdd(&a.q.count[T0], c0.total);
-  if (c1.total && lane == c1.leader) g1 = atomicAdd(&a.q.count[T0 + a.q.tiles_y], c1.total);
-  if (c2.total && lane == c2.leader) g2 = atomicAdd(&a.q.count[T0 + 1u], c2.total);
-  if (c3.total && lane == c3.leader) g3 = atomicAdd(&a.q.count[T0 + a.q.tiles_y + 1u], c3.total);
+  if (!(a.dbg & 16)) {   // (ablation bit 16: grouping without the reservations)
+    if (c0.total && lane == c0.leader) g0 = atomicAdd(&a.q.count[T0 * kQSub + sub], c0.total);
+    if (c1.total && lane == c1.leader) g1 = atomicAdd(&a.q.count[(T0 + a.q.tiles_y) * kQSub + sub], c1.total);
+    if (c2.total && lane == c2.leader) g2 = atomicAdd(&a.q.count[(T0 + 1u) * kQSub + sub], c2.total);
+    if (c3.total && lane == c3.leader) g3 = atomicAdd(&a.q.count[(T0 + a.q.tiles_y + 1u) * kQSub + sub], c3.total);
+  }
   uint32_t off0 = (uint32_t)__shfl((int)g0, c0.leader) + c0.prefix;
   uint32_t off1 = (uint32_t)__shfl((int)g1, c1.leader) + c1.prefix;
   uint32_t off2 = (uint32_t)__shfl((int)g2, c2.leader) + c2.prefix;
   uint32_t off3 = (uint32_t)__shfl((int)g3, c3.leader) + c3.prefix;
   unsigned long long mask = 0ull;
+  if (a.dbg & 8) cover = 0ull;   // ablation: setup + coverage + slot reservation, no depth / stores
   for (unsigned long long m = cover; m; m &= m - 1ull) {
     const int bit = __ffsll((long long)m) - 1;
     const int dx = bit >> 3, dy = bit & 7;
@@ -475,7 +485,7 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
     const uint32_t tile = tx * a.q.tiles_y + ty;
     if (a.dbg & 1) continue;
     if (slot < a.q.cap) {
-      const uint64_t e = (uint64_t)tile * a.q.cap + slot;
+      const uint64_t e = ((uint64_t)tile * kQSub + sub) * a.q.cap + slot;
       a.q.key[e] = key;
       a.q.pix[e] = (uint16_t)(((uint32_t)x - tx * kQW) * kQH + ((uint32_t)y - ty * kQH));
     } else if (key != kNullKey) {
@@ -500,7 +510,7 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
       if (j >= ntx * nty) return 0u;
       const int jx = tX0 + j / nty, jy = tY0 + j % nty;
       const int wx = min(t.x1, jx * kQW + kQW - 1) - max(t.x0, jx * kQW) + 1, hy = min(t.y1, jy * kQH + kQH - 1) - max(t.y0, jy * kQH) + 1;
-      return atomicAdd(&a.q.count[(uint32_t)jx * a.q.tiles_y + (uint32_t)jy], (uint32_t)(wx * hy));
+      return atomicAdd(&a.q.count[((uint32_t)jx * a.q.tiles_y + (uint32_t)jy) * kQSub + sub], (uint32_t)(wx * hy));
     };
     rb0 = reserve(0); rb1 = reserve(1); rb2 = reserve(2); rb3 = reserve(3); rb4 = reserve(4); rb5 = reserve(5);   // in flight together
   }
@@ -554,7 +564,7 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
       const uint32_t tile = (uint32_t)jx * a.q.tiles_y + (uint32_t)jy;
       if (!in_box || (a.dbg & 1)) continue;
       if (slot < a.q.cap) {
-        const uint64_t e = (uint64_t)tile * a.q.cap + slot;
+        const uint64_t e = ((uint64_t)tile * kQSub + sub) * a.q.cap + slot;
         a.q.key[e] = key;
         a.q.pix[e] = (uint16_t)((x - jx * kQW) * kQH + (y - jy * kQH));
       } else if (key != kNullKey) {
@@ -578,7 +588,21 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
   const uint32_t W = a.W, H = a.H;
   const uint32_t tx = tile / q.tiles_y, ty = tile - tx * q.tiles_y;
   const uint32_t x0 = tx * kQW, y0 = ty * kQH;
-  const uint32_t n = min(q.count[tile], q.cap);
+  // 256 / kQSub threads per sub-queue (the sub-queues of a tile fill evenly: waves pick theirs by wave id).  The first
+  // kSpec entries of every thread are requested together with the fill count (they exist in memory whether or not they
+  // are valid): one memory round trip instead of two for the typical tile.
+  constexpr uint32_t kGroup = 256u / kQSub, kSpec = 6;
+  const uint32_t sq = (uint32_t)t / kGroup, sq_lane = (uint32_t)t % kGroup;
+  const uint64_t qbase = ((uint64_t)tile * kQSub + sq) * q.cap;
+  unsigned long long spec_key[kSpec];
+  uint16_t spec_pix[kSpec];
+#pragma unroll
+  for (uint32_t k = 0; k < kSpec; k++) {
+    const uint32_t i = min(sq_lane + k * kGroup, q.cap - 1u);
+    spec_key[k] = q.key[qbase + i];
+    spec_pix[k] = q.pix[qbase + i];
+  }
+  const uint32_t n = min(q.count[tile * kQSub + sq], q.cap);
   const bool merge = q.flag[tile] != 0u;
   const uint32_t nbig = min(a.big_count[2], a.big_capacity);   // triangles larger than kMedium x kMedium
   for (int p = t; p < kQPixels; p += 256) {
@@ -593,8 +617,10 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
   }
   if (t == 0) s_nhits = 0u;
   __syncthreads();
-  const uint64_t base = (uint64_t)tile * q.cap;
-  for (uint32_t i = (uint32_t)t; i < n; i += 256u) atomicMin(&skeys[q.pix[base + i]], q.key[base + i]);
+#pragma unroll
+  for (uint32_t k = 0; k < kSpec; k++)
+    if (sq_lane + k * kGroup < n) atomicMin(&skeys[spec_pix[k]], spec_key[k]);
+  for (uint32_t i = sq_lane + kSpec * kGroup; i < n; i += kGroup) atomicMin(&skeys[q.pix[qbase + i]], q.key[qbase + i]);
   const int tx1 = (int)min(x0 + kQW, W) - 1, ty1 = (int)min(y0 + kQH, H) - 1;   // last pixel of the tile inside the image
   for (uint32_t qb = 0; qb < nbig; qb += 256u) {
     const uint32_t qi = qb + (uint32_t)t;
@@ -633,7 +659,8 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
       if (depth_out) depth_out[g] = __uint_as_float((uint32_t)(k >> 32));
     }
   }
-  if (t == 0) { q.count[tile] = 0u; q.flag[tile] = 0u; }
+  if (t < kQSub) q.count[tile * kQSub + t] = 0u;
+  if (t == 0) q.flag[tile] = 0u;
 }
 
 // Split the key image into the two output planes and re-arm the keys for the next render.
@@ -770,18 +797,19 @@ RasterPath raster_path() {
   return p;
 }
 
-// Per-tile fragment queues.  Capacity per tile: 16 fragments per pixel of the tile (SMESH_FRAG_CAP overrides it;
-// fragments beyond it fall back to the global key image), shrunk if the whole set would exceed 8 GiB.
-// Returns false (queues unusable -> direct path) for images with so many tiles that the capacity would drop under 1024.
+// Per-tile fragment queues (kQSub sub-queues each).  Capacity per tile: 16 fragments per pixel of the tile
+// (SMESH_FRAG_CAP overrides the capacity of a sub-queue; fragments beyond it fall back to the global key image), shrunk
+// if the whole set would exceed 8 GiB.  Returns false (queues unusable -> direct path) for images with so many tiles
+// that a sub-queue would drop under 256 slots.
 bool ensure_queues(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st, int* status) {
   *status = SMESH_OK;
   const uint64_t tiles_x = div_up(W, kQW), tiles_y = div_up(H, kQH), ntiles = tiles_x * tiles_y;
-  uint64_t cap = 16ull * kQPixels;
+  uint64_t cap = 16ull * kQPixels / kQSub;   // per sub-queue
   if (const char* e = getenv("SMESH_FRAG_CAP")) cap = std::max<uint64_t>(1, (uint64_t)atoll(e));
   else {
     const uint64_t budget = 8ull << 30;
-    if (ntiles * cap * 10 > budget) cap = budget / (ntiles * 10);
-    if (cap < 1024) return false;
+    if (ntiles * kQSub * cap * 10 > budget) cap = budget / (ntiles * kQSub * 10);
+    if (cap < 256) return false;
   }
   if (ntiles > r->fq_tiles || (uint32_t)cap != r->fq.cap) {
     (void)hipStreamSynchronize(r->ctx->stream);
@@ -790,11 +818,11 @@ bool ensure_queues(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st, in
       if (p) (void)hipFree(p);
     r->fq = FragQueues();
     r->fq_tiles = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->fq.key), ntiles * cap * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.pix), ntiles * cap * 2);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.count), ntiles * 4);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->fq.key), ntiles * kQSub * cap * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.pix), ntiles * kQSub * cap * 2);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.count), ntiles * kQSub * 4);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.flag), ntiles * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(r->fq.count, 0, ntiles * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(r->fq.count, 0, ntiles * kQSub * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(r->fq.flag, 0, ntiles * 4, st);
     if (e != hipSuccess) { *status = fail_hip(e, "fragment queue allocation", __FILE__, __LINE__); return false; }
     r->fq.cap = (uint32_t)cap;
