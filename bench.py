@@ -105,7 +105,8 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # device_id: the communicator is bound to this GPU and created now, not inside the timed region
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = local_rank
 
     cfg = synth.CONFIGS[args.workload]
