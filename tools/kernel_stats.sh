@@ -1,4 +1,4 @@
-# usage: bash tools/_run.sh <tag> [test]   -- scratch driver for gpurun calls (per-kernel averages of a bench run)
+# usage: bash tools/kernel_stats.sh <tag> [test]   -- bench.py under rocprofv3 --kernel-trace --stats, per-kernel averages; "test" runs the GPU test suite first
 tag=$1; mkdir -p gpurun_out/$tag
 if [ "$2" = "test" ]; then timeout 1500 python -m pytest tests -m gpu -x -q > gpurun_out/$tag/pytest.log 2>&1; tail -3 gpurun_out/$tag/pytest.log; fi
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT

@@ -1,3 +1,4 @@
+# usage: bash tools/pipeline_timeline.sh <tag>  -- kernel start/end times of a SMESH_FUSE_PIPELINE=1 bench run (do the two streams overlap?)
 tag=$1; mkdir -p gpurun_out/$tag; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 SMESH_FUSE_PIPELINE=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/$tag/kt -o bench -- python bench.py --no-cpu-baseline --steps 50 > gpurun_out/$tag/bench_kt.log 2>&1
 python - <<PY

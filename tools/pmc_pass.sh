@@ -1,4 +1,4 @@
-# usage: bash tools/_pmc.sh <tag> "<counters>"  -- scratch driver: one rocprofv3 --pmc pass over a short bench run, per-kernel averages
+# usage: bash tools/pmc_pass.sh <tag> "<counters>"  -- one rocprofv3 --pmc pass over a short bench run, per-kernel averages
 tag=$1; mkdir -p gpurun_out/$tag; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 timeout 600 rocprofv3 --pmc $2 --output-format csv -d gpurun_out/$tag/pmc -o bench -- python bench.py --no-cpu-baseline --steps 20 --warmup 2 > gpurun_out/$tag/pmc.log 2>&1
 python - <<PY

@@ -1,5 +1,5 @@
 # Collects what profiles/ holds for a round: bench line, rocprofv3 kernel stats of the same command, HBM counters
-# (separate --pmc passes).  usage: bash tools/_profile_round.sh <tag>   (run on the GPU box through gpurun)
+# (separate --pmc passes).  usage: bash tools/profile_round.sh <tag>   (run on the GPU box through gpurun)
 tag=$1; out=gpurun_out/$tag; mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 python bench.py > $out/bench.log 2>&1; tail -1 $out/bench.log | cut -c1-400
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python bench.py --no-cpu-baseline > $out/bench_kt.log 2>&1
