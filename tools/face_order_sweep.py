@@ -16,8 +16,11 @@ win = np.arange(F).reshape(-1, 4000).copy()
 for row in win: rng.shuffle(row)
 orders["shuffled in windows of 4000"] = win.reshape(-1)
 orders["fully shuffled"] = rng.permutation(F)
-for name, perm in orders.items():
-    mesh = data.Mesh(base.vertices, base.faces[perm])
+vperm = rng.permutation(len(base.vertices))          # new position of every vertex
+vinv = np.empty_like(vperm); vinv[vperm] = np.arange(len(vperm))
+meshes = {name: data.Mesh(base.vertices, base.faces[perm]) for name, perm in orders.items()}
+meshes["grid faces, shuffled VERTEX numbering"] = data.Mesh(base.vertices[vinv], vperm[base.faces].astype(np.int32))
+for name, mesh in meshes.items():
     r = render.triangles(mesh); agg = fusion.MeshAggregator(F, C)
     for cam in cams[:2]: agg.fuse_view(r, cam, probs)
     _lib.synchronize(0)
