@@ -811,3 +811,31 @@ def test_degenerate_geometry(sm, oracle):
     assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
     # duplicates: the lower id wins everywhere (B-4), so the re-appended copies of faces 0..49 never show up
     assert not np.isin(np.asarray(idx), np.arange(P - 50, P)).any()
+
+
+@pytest.mark.parametrize("res", [(1, 1), (7, 3), (33, 65), (64, 64), (65, 129), (1000, 9), (9, 1000)])
+def test_odd_image_sizes(sm, oracle, res):
+    """Images smaller than, equal to and not a multiple of the 32 x 64 screen tiles; extreme aspect ratios."""
+    from semantic_meshes_amd import synth
+    mesh = synth.grid_mesh(20, 10)
+    W, H = res
+    cams = [synth.ring_camera(k, 3, W, H) for k in range(3)]
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    P, C = len(mesh.faces), 5
+    rng = np.random.default_rng(W * 1000 + H)
+    agg = sm.fusion.MeshAggregator(P, C)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C)
+        for cam in cams:
+            idx, depth = r.render(cam)
+            oidx, odepth = o.render(cam)
+            np.testing.assert_array_equal(np.asarray(idx), oidx)
+            np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+            probs = random_probs(rng, W, H, C)
+            agg.fuse_view(r, cam, probs)
+            oagg.add(oidx, probs)
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    finally:
+        oracle.set_accum_double(False)
