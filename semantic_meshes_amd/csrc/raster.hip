@@ -127,10 +127,12 @@ struct Tri {
   int x0, x1, y0, y1;
 };
 
+// Tie rule: a sample exactly on the edge belongs to the triangle whose edge normal (A, B) = s * sign * (-dy, dx) satisfies
+// A > 0 || (A == 0 && B > 0).  s and sign are +-1, so only the signs of dy / dx and of s * sign matter (no multiplications).
 __device__ __forceinline__ bool owns(double s, const EdgeEq& e) {
-  const double A = s * (e.sign * (-e.dy));
-  const double B = s * (e.sign * e.dx);
-  return (A > 0.0) || (A == 0.0 && B > 0.0);
+  const bool pos = (s > 0.0) == (e.sign > 0.0);   // s * sign == +1
+  if (e.dy != 0.0) return (e.dy < 0.0) == pos;     // A = s * sign * (-dy) > 0
+  return e.dx != 0.0 && (e.dx > 0.0) == pos;       // A == 0: B = s * sign * dx > 0
 }
 
 __device__ __forceinline__ bool setup_tri(const ScreenVertex& a, const ScreenVertex& b, const ScreenVertex& c,
@@ -138,14 +140,10 @@ __device__ __forceinline__ bool setup_tri(const ScreenVertex& a, const ScreenVer
   if (a.iz == 0.0 || b.iz == 0.0 || c.iz == 0.0) return false;
   const double minu = fmin(a.u, fmin(b.u, c.u)), maxu = fmax(a.u, fmax(b.u, c.u));
   const double minv = fmin(a.v, fmin(b.v, c.v)), maxv = fmax(a.v, fmax(b.v, c.v));
-  double fx0 = ceil(minu - 0.5), fx1 = floor(maxu - 0.5);
-  double fy0 = ceil(minv - 0.5), fy1 = floor(maxv - 0.5);
-  if (fx0 < 0.0) fx0 = 0.0;
-  if (fy0 < 0.0) fy0 = 0.0;
-  if (fx1 > (double)(W - 1)) fx1 = (double)(W - 1);
-  if (fy1 > (double)(H - 1)) fy1 = (double)(H - 1);
-  if (!(fx0 <= fx1) || !(fy0 <= fy1)) return false;
-  t.x0 = (int)fx0; t.x1 = (int)fx1; t.y0 = (int)fy0; t.y1 = (int)fy1;
+  // first / last sample column and row, clamped to the image (the conversions saturate: coordinates are finite here)
+  t.x0 = max((int)ceil(minu - 0.5), 0); t.x1 = min((int)floor(maxu - 0.5), (int)W - 1);
+  t.y0 = max((int)ceil(minv - 0.5), 0); t.y1 = min((int)floor(maxv - 0.5), (int)H - 1);
+  if (t.x0 > t.x1 || t.y0 > t.y1) return false;
   t.e0 = make_edge(b.u, b.v, c.u, c.v);
   t.e1 = make_edge(c.u, c.v, a.u, a.v);
   t.e2 = make_edge(a.u, a.v, b.u, b.v);
@@ -235,7 +233,8 @@ struct RasterArgs {
   TriFrag* frags;             // per-triangle fragment records for the triangle-order fusion (may be null)
   FragQueues q;               // fragment-queue path only
   uint32_t tpw;               // k_raster_frag: triangles per wave (power of two <= 64)
-  int dbg;                    // development ablation (SMESH_RDBG): 1 = no atomics, 2 = setup only
+  int dbg;                    // development ablation (SMESH_RDBG) of k_raster_frag: 1 = no stores, 2 = setup only, 4 = + coverage,
+                              // 8 = + slot reservation, 16 = grouping without the reservation atomics
 };
 
 // Key image layout: same (W,H) y-fastest order as the output planes.  (A 4 x 4 blocked layout was tried to
@@ -404,9 +403,10 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   if (f < a.F && load_tri(a, f, t)) {
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
     rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
-    n0 = (t.s * t.e0.sign < 0.0) ? 0x80000000u : 0u;
-    n1 = (t.s * t.e1.sign < 0.0) ? 0x80000000u : 0u;
-    n2 = (t.s * t.e2.sign < 0.0) ? 0x80000000u : 0u;
+    const uint32_t shi = (uint32_t)__double2hiint(t.s);   // s and sign are +-1.0: their product is negative iff the sign bits differ
+    n0 = (shi ^ (uint32_t)__double2hiint(t.e0.sign)) & 0x80000000u;
+    n1 = (shi ^ (uint32_t)__double2hiint(t.e1.sign)) & 0x80000000u;
+    n2 = (shi ^ (uint32_t)__double2hiint(t.e2.sign)) & 0x80000000u;
     if (bw > 8 || bh > 8) {
       const uint32_t slot = atomicAdd(a.big_count, 1u);          // every such triangle: the fusion walks this queue
       if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
@@ -421,15 +421,17 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
       // one flattened loop over the box (trip count bw * bh, not max bw x max bh over the wave's lanes)
       const int area = bw * bh;
       int dx = 0, dy = 0;
+      const double py0 = (double)t.y0 + 0.5;
+      double px = (double)t.x0 + 0.5, py = py0;   // advanced by exact steps of 1.0
       for (int k = 0; k < area; k++) {
-        const double px = (double)(t.x0 + dx) + 0.5, py = (double)(t.y0 + dy) + 0.5;
         const double w0 = flip_sign(t.e0.dx * (py - t.e0.ly) - t.e0.dy * (px - t.e0.lx), n0);
         const double w1 = flip_sign(t.e1.dx * (py - t.e1.ly) - t.e1.dy * (px - t.e1.lx), n1);
         const double w2 = flip_sign(t.e2.dx * (py - t.e2.ly) - t.e2.dy * (px - t.e2.lx), n2);
         const bool in = (w0 > 0.0 || (w0 == 0.0 && t.own0)) & (w1 > 0.0 || (w1 == 0.0 && t.own1)) &
                         (w2 > 0.0 || (w2 == 0.0 && t.own2));
         if (in) cover |= 1ull << (dx * 8 + dy);
-        if (++dy == bh) { dy = 0; dx++; }
+        py += 1.0;
+        if (++dy == bh) { dy = 0; dx++; py = py0; px += 1.0; }
       }
     }
   }
@@ -453,10 +455,13 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
     if (c2.total && lane == c2.leader) g2 = atomicAdd(&a.q.count[(T0 + 1u) * kQSub + sub], c2.total);
     if (c3.total && lane == c3.leader) g3 = atomicAdd(&a.q.count[(T0 + a.q.tiles_y + 1u) * kQSub + sub], c3.total);
   }
-  uint32_t off0 = (uint32_t)__shfl((int)g0, c0.leader) + c0.prefix;
-  uint32_t off1 = (uint32_t)__shfl((int)g1, c1.leader) + c1.prefix;
-  uint32_t off2 = (uint32_t)__shfl((int)g2, c2.leader) + c2.prefix;
-  uint32_t off3 = (uint32_t)__shfl((int)g3, c3.leader) + c3.prefix;
+  // entry index (into key[] / pix[]) of this lane's next fragment in each quadrant, and the end of that sub-queue
+  const uint32_t sq0 = (T0 * kQSub + sub) * a.q.cap, sq1 = ((T0 + a.q.tiles_y) * kQSub + sub) * a.q.cap,
+                 sq2 = ((T0 + 1u) * kQSub + sub) * a.q.cap, sq3 = ((T0 + a.q.tiles_y + 1u) * kQSub + sub) * a.q.cap;
+  uint32_t e0 = sq0 + (uint32_t)__shfl((int)g0, c0.leader) + c0.prefix;
+  uint32_t e1 = sq1 + (uint32_t)__shfl((int)g1, c1.leader) + c1.prefix;
+  uint32_t e2 = sq2 + (uint32_t)__shfl((int)g2, c2.leader) + c2.prefix;
+  uint32_t e3 = sq3 + (uint32_t)__shfl((int)g3, c3.leader) + c3.prefix;
   unsigned long long mask = 0ull;
   if (a.dbg & 8) cover = 0ull;   // ablation: setup + coverage + slot reservation, no depth / stores
   for (unsigned long long m = cover; m; m &= m - 1ull) {
@@ -478,19 +483,19 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
       mask |= 1ull << bit;
     }
     const bool hx = dx >= bx, hy = dy >= by;
-    uint32_t slot;
-    if (hy) { if (hx) slot = off3++; else slot = off2++; }
-    else    { if (hx) slot = off1++; else slot = off0++; }
-    const uint32_t tx = tx0 + (hx ? 1u : 0u), ty = ty0 + (hy ? 1u : 0u);
-    const uint32_t tile = tx * a.q.tiles_y + ty;
+    uint32_t e, lim;   // this fragment's entry, and one past the last entry of its sub-queue
+    if (hy) { if (hx) { e = e3++; lim = sq3; } else { e = e2++; lim = sq2; } }
+    else    { if (hx) { e = e1++; lim = sq1; } else { e = e0++; lim = sq0; } }
+    lim += a.q.cap;
     if (a.dbg & 1) continue;
-    if (slot < a.q.cap) {
-      const uint64_t e = ((uint64_t)tile * kQSub + sub) * a.q.cap + slot;
+    // pixel inside its tile: (x mod 32) * 64 + (y mod 64)
+    const uint16_t pin = (uint16_t)((((uint32_t)x & (kQW - 1)) * kQH) | ((uint32_t)y & (kQH - 1)));
+    if (e < lim) {
       a.q.key[e] = key;
-      a.q.pix[e] = (uint16_t)(((uint32_t)x - tx * kQW) * kQH + ((uint32_t)y - ty * kQH));
+      a.q.pix[e] = pin;
     } else if (key != kNullKey) {
       atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
-      a.q.flag[tile] = 1u;
+      a.q.flag[(tx0 + (hx ? 1u : 0u)) * a.q.tiles_y + ty0 + (hy ? 1u : 0u)] = 1u;
     }
   }
   if (mask) rec.kind = 1;
