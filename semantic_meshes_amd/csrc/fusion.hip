@@ -752,10 +752,20 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
     const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
     const int bh = y1 - y0 + 1;
     const long long npx = (long long)(x1 - x0 + 1) * bh;
+    // U pixels per lane and step: their index loads, then their class vectors, are in flight together
+    constexpr int U = CT <= 24 ? 4 : 2;
+    auto pix_of = [&](long long i) -> uint64_t { return (uint64_t)(x0 + (int)(i / bh)) * a.H + (uint64_t)(y0 + (int)(i % bh)); };
     uint32_t n = 0;
-    for (long long i = l; i < npx; i += kWave) {
-      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
-      n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
+    for (long long base = 0; base < npx; base += (long long)kWave * U) {
+      uint32_t v[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const long long i = base + (long long)u * kWave + l;
+        v[u] = a.idx[i < npx ? pix_of(i) : pix_of(0)];
+        if (!(i < npx)) v[u] = ~f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) n += v[u] == f ? 1u : 0u;
     }
     n = wave_sum_u(n);
     if (n == 0) continue;
@@ -763,26 +773,42 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
     float part[CT];
 #pragma unroll
     for (int c = 0; c < C; c++) part[c] = 0.0f;
-    for (long long i = l; i < npx; i += kWave) {
-      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
-      const uint64_t pix = (uint64_t)x * a.H + y;
-      if (a.idx[pix] != f) continue;
-      const float* __restrict__ pr = a.probs + pix * C;
-      float p[CT];
-      float sum = 0.0f;
+    for (long long base = 0; base < npx; base += (long long)kWave * U) {
+      uint64_t pix[U];
+      bool hit[U];
 #pragma unroll
-      for (int c = 0; c < C; c++) { p[c] = pr[c]; sum = sum + p[c]; }
-      if (!(sum > 0.5f)) continue;
-      const float w = w0 * (a.weights ? a.weights[pix] : 1.0f);
-      if (KIND == SMESH_AGG_SUMMAX) {
-        int am = 0;
+      for (int u = 0; u < U; u++) {
+        const long long i = base + (long long)u * kWave + l;
+        pix[u] = i < npx ? pix_of(i) : pix_of(0);
+        hit[u] = a.idx[pix[u]] == f && i < npx;
+      }
+      float p[U][CT];
+      float wt[U];
 #pragma unroll
-        for (int c = 1; c < C; c++) if (p[c] > p[am]) am = c;
+      for (int u = 0; u < U; u++) {
+        const float* __restrict__ pr = a.probs + (hit[u] ? pix[u] : pix_of(0)) * C;   // unconditional: the loads overlap
 #pragma unroll
-        for (int c = 0; c < C; c++) if (c == am) part[c] += p[c] * w;
-      } else {
+        for (int c = 0; c < C; c++) p[u][c] = pr[c];
+        wt[u] = (a.weights && hit[u]) ? a.weights[pix[u]] : 1.0f;
+      }
 #pragma unroll
-        for (int c = 0; c < C; c++) part[c] += contribution<KIND>(p[c], w);
+      for (int u = 0; u < U; u++) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; c++) sum = sum + p[u][c];
+        if (!(hit[u] && sum > 0.5f)) continue;
+        const float w = w0 * wt[u];
+        if (KIND == SMESH_AGG_SUMMAX) {
+          float best = p[u][0];
+          int am = 0;
+#pragma unroll
+          for (int c = 1; c < C; c++) if (p[u][c] > best) { best = p[u][c]; am = c; }
+#pragma unroll
+          for (int c = 0; c < C; c++) part[c] = (c == am) ? part[c] + p[u][c] * w : part[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; c++) part[c] += contribution<KIND>(p[u][c], w);
+        }
       }
     }
     float mine = 0.0f;
@@ -892,8 +918,9 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
         const float w = w0 * wt[j];                                         // :103
         if (KIND == SMESH_AGG_SUMMAX) {
           int am = 0;
+          float best = p[j][0];   // (not p[j][am]: a run-time register index would go through scratch)
 #pragma unroll
-          for (int c = 1; c < C; c++) if (p[j][c] > p[j][am]) am = c;
+          for (int c = 1; c < C; c++) if (p[j][c] > best) { best = p[j][c]; am = c; }
 #pragma unroll
           for (int c = 0; c < C; c++) if (c == am) accr[c] = accr[c] + p[j][c] * w;
         } else {

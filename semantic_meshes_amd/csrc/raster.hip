@@ -158,21 +158,24 @@ __device__ __forceinline__ bool setup_tri(const ScreenVertex& a, const ScreenVer
 }
 
 // Coverage + depth of one sample; returns false if the sample is not covered.
-__device__ __forceinline__ bool shade(const Tri& t, int x, int y, float* z, double* b1, double* b2) {
+// Values (no out-pointers: address-taken locals ended up in scratch memory).
+struct Shaded { bool ok; float z; double b1, b2; };
+__device__ __forceinline__ Shaded shade(const Tri& t, int x, int y, bool want_bary) {
+  Shaded r; r.ok = false; r.z = 0.0f; r.b1 = 0.0; r.b2 = 0.0;
   const double px = (double)x + 0.5, py = (double)y + 0.5;
   const double w0 = t.s * eval_edge(t.e0, px, py);
-  if (!(w0 > 0.0 || (w0 == 0.0 && t.own0))) return false;
+  if (!(w0 > 0.0 || (w0 == 0.0 && t.own0))) return r;
   const double w1 = t.s * eval_edge(t.e1, px, py);
-  if (!(w1 > 0.0 || (w1 == 0.0 && t.own1))) return false;
+  if (!(w1 > 0.0 || (w1 == 0.0 && t.own1))) return r;
   const double w2 = t.s * eval_edge(t.e2, px, py);
-  if (!(w2 > 0.0 || (w2 == 0.0 && t.own2))) return false;
+  if (!(w2 > 0.0 || (w2 == 0.0 && t.own2))) return r;
   const double num = (w0 + w1) + w2;
   const double den = (w0 * t.iz0 + w1 * t.iz1) + w2 * t.iz2;
   const float zf = (float)(num / den);
-  if (!(zf > 0.0f) || !isfinite(zf)) return false;
-  *z = zf;
-  if (b1) { *b1 = w1 / num; *b2 = w2 / num; }
-  return true;
+  if (!(zf > 0.0f) || !isfinite(zf)) return r;
+  r.ok = true; r.z = zf;
+  if (want_bary) { r.b1 = w1 / num; r.b2 = w2 / num; }
+  return r;
 }
 
 // The coverage part of shade() alone (same expressions, same order).
@@ -251,26 +254,20 @@ __device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t
   return setup_tri(va, vb, vc, a.W, a.H, t);
 }
 
-__device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y) {
-  float z;
-  double b1, b2;
-  if (!shade(t, x, y, &z, a.tex_res ? &b1 : nullptr, &b2)) return;
+// Depth-test key of triangle f at sample (x, y), or kNullKey if the sample is not covered.
+__device__ __forceinline__ unsigned long long shade_key(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y) {
+  const Shaded sh = shade(t, x, y, a.tex_res != nullptr);
+  if (!sh.ok) return kNullKey;
   uint32_t prim = a.prim_id ? a.prim_id[f] : (uint32_t)f;
-  if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
-  const unsigned long long key = ((unsigned long long)__float_as_uint(z) << 32) | prim;
-  if (a.dbg & 1) { if (key == 12345ull) a.keys[0] = key; return; }
-  atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
+  if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], sh.b1, sh.b2);
+  return ((unsigned long long)__float_as_uint(sh.z) << 32) | prim;
 }
 
-__device__ __forceinline__ bool shade_key(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y,
-                                          unsigned long long* key) {
-  float z;
-  double b1, b2;
-  if (!shade(t, x, y, &z, a.tex_res ? &b1 : nullptr, &b2)) return false;
-  uint32_t prim = a.prim_id ? a.prim_id[f] : (uint32_t)f;
-  if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
-  *key = ((unsigned long long)__float_as_uint(z) << 32) | prim;
-  return true;
+__device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y) {
+  const unsigned long long key = shade_key(a, f, t, x, y);
+  if (key == kNullKey) return;
+  if (a.dbg & 1) { if (key == 12345ull) a.keys[0] = key; return; }
+  atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
 }
 
 // Direct path.  One lane per triangle; triangles whose bounding box exceeds 8 x 8 pixels are queued for k_raster_big.
@@ -293,8 +290,8 @@ __global__ void k_raster_small(RasterArgs a) {
       unsigned long long mask = 0ull;
       for (int dx = 0; dx < bw; dx++)
         for (int dy = 0; dy < bh; dy++) {
-          unsigned long long key;
-          if (shade_key(a, f, t, t.x0 + dx, t.y0 + dy, &key)) {
+          const unsigned long long key = shade_key(a, f, t, t.x0 + dx, t.y0 + dy);
+          if (key != kNullKey) {
             mask |= 1ull << (dx * 8 + dy);
             if (!(a.dbg & 1)) atomicMin(&a.keys[key_index((uint32_t)(t.x0 + dx), (uint32_t)(t.y0 + dy), a.H)], key);
           }
@@ -646,8 +643,8 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
       const int hh = yb - ya + 1, area = (xb - xa + 1) * hh;
       for (int i = t; i < area; i += 256) {
         const int x = xa + i / hh, y = ya + i % hh;
-        unsigned long long key;
-        if (shade_key(a, f, tr, x, y, &key)) atomicMin(&skeys[(x - (int)x0) * kQH + (y - (int)y0)], key);
+        const unsigned long long key = shade_key(a, f, tr, x, y);
+        if (key != kNullKey) atomicMin(&skeys[(x - (int)x0) * kQH + (y - (int)y0)], key);
       }
     }
     __syncthreads();
