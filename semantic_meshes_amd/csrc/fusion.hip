@@ -739,9 +739,35 @@ struct TriFuseArgs {
 // Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle, lanes over the box;
 // per-lane partial sums are combined by a butterfly over the wave (so, unlike the small-triangle path, the
 // summation order is a tree) and lane c owns class c of the row.  Runs in the tail blocks of k_fuse_tri.
-template <int CT, int KIND>
+// float4 at 4-byte alignment: rows are only float-aligned; gfx950 global memory takes dwordx4 at any dword address.
+// (A packed struct gets scalarised: its stores became one write request per lane and dword.)
+typedef float fvec4 __attribute__((ext_vector_type(4)));
+typedef fvec4 fvec4_a4 __attribute__((aligned(4)));
+
+// k_fuse_tri comes in two flavours: EXACT (the class count is the template parameter: cfg 5 / 19 / 40) and run-time C <= CT
+// (CT = 8, 16 .. 40: the register arrays are sized CT, loops are predicated with c < C).
+template <int CT, bool EXACT>
+__device__ __forceinline__ void load_row(const float* __restrict__ pr, int C, float (&p)[CT]) {
+  if (EXACT) {
+#pragma unroll
+    for (int c = 0; c < CT; c++) p[c] = pr[c];
+  } else {
+#pragma unroll
+    for (int c = 0; c < CT; c += 4) {
+      if (c + 4 <= C) {
+        const fvec4 q = *reinterpret_cast<const fvec4_a4*>(pr + c);
+        p[c] = q.x; p[c + 1] = q.y; p[c + 2] = q.z; p[c + 3] = q.w;
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; t++) if (c + t < CT) p[c + t] = (c + t < C) ? pr[c + t] : 0.0f;
+      }
+    }
+  }
+}
+
+template <int CT, int KIND, bool EXACT>
 __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers) {
-  constexpr int C = CT;
+  const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
   const int l = threadIdx.x;
   const uint32_t nbig = min(*a.big_len, a.big_capacity);
   for (uint32_t q = worker; q < nbig; q += nworkers) {
@@ -772,7 +798,7 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
     const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
     float part[CT];
 #pragma unroll
-    for (int c = 0; c < C; c++) part[c] = 0.0f;
+    for (int c = 0; c < CT; c++) part[c] = 0.0f;
     for (long long base = 0; base < npx; base += (long long)kWave * U) {
       uint64_t pix[U];
       bool hit[U];
@@ -787,33 +813,32 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
 #pragma unroll
       for (int u = 0; u < U; u++) {
         const float* __restrict__ pr = a.probs + (hit[u] ? pix[u] : pix_of(0)) * C;   // unconditional: the loads overlap
-#pragma unroll
-        for (int c = 0; c < C; c++) p[u][c] = pr[c];
+        load_row<CT, EXACT>(pr, C, p[u]);
         wt[u] = (a.weights && hit[u]) ? a.weights[pix[u]] : 1.0f;
       }
 #pragma unroll
       for (int u = 0; u < U; u++) {
         float sum = 0.0f;
 #pragma unroll
-        for (int c = 0; c < C; c++) sum = sum + p[u][c];
+        for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[u][c];
         if (!(hit[u] && sum > 0.5f)) continue;
         const float w = w0 * wt[u];
         if (KIND == SMESH_AGG_SUMMAX) {
           float best = p[u][0];
           int am = 0;
 #pragma unroll
-          for (int c = 1; c < C; c++) if (p[u][c] > best) { best = p[u][c]; am = c; }
+          for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[u][c] > best) { best = p[u][c]; am = c; }
 #pragma unroll
-          for (int c = 0; c < C; c++) part[c] = (c == am) ? part[c] + p[u][c] * w : part[c];
+          for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] = (c == am) ? part[c] + p[u][c] * w : part[c];
         } else {
 #pragma unroll
-          for (int c = 0; c < C; c++) part[c] += contribution<KIND>(p[u][c], w);
+          for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] += contribution<KIND>(p[u][c], w);
         }
       }
     }
     float mine = 0.0f;
 #pragma unroll
-    for (int c = 0; c < C; c++) {
+    for (int c = 0; c < CT; c++) if (EXACT || c < C) {
       const float v = wave_sum(part[c]);
       if (l == c) mine = v;
     }
@@ -821,15 +846,15 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
   }
 }
 
-template <int CT, int KIND>
+template <int CT, int KIND, bool EXACT>
 __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
-  constexpr int C = CT;
+  const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
   constexpr int PB = CT <= 24 ? 2 : 1;        // pixels whose class vectors are in flight together
   constexpr int KV = (kWave * CT / 4 + kWave - 1) / kWave;   // float4 per lane of the 64-row block
   __shared__ __attribute__((aligned(16))) float srow[kWave * CT + 4];   // the wave's 64 accumulator rows
   const int l = threadIdx.x;
   if (blockIdx.x >= a.tri_blocks) {   // tail blocks: the queued big triangles
-    fuse_big_triangles<CT, KIND>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
+    fuse_big_triangles<CT, KIND, EXACT>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
     return;
   }
   const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
@@ -889,8 +914,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
       if (m) { k = __ffsll((long long)m) - 1; m &= m - 1ull; }
       const uint64_t pix = have[j] ? pixel(k) : 0;
       const float* __restrict__ pr = a.probs + pix * C;
-#pragma unroll
-      for (int c = 0; c < C; c++) p[j][c] = pr[c];
+      load_row<CT, EXACT>(pr, C, p[j]);
       wt[j] = a.weights ? a.weights[pix] : 1.0f;
     }
     if (!rows_loaded) {
@@ -905,7 +929,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
       }
       wave_sync();
 #pragma unroll
-      for (int c = 0; c < C; c++) accr[c] = srow[l * C + c];
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = srow[l * C + c];
       rows_loaded = true;
     }
     // Mesh.h:94-106 for this primitive's pixels, in image order (x, then y)
@@ -913,19 +937,19 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
     for (int j = 0; j < PB; j++) {
       float sum = 0.0f;
 #pragma unroll
-      for (int c = 0; c < C; c++) sum = sum + p[j][c];                      // tt::sum, sequential float32
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[j][c];                      // tt::sum, sequential float32
       if (have[j] && sum > 0.5f) {                                          // :98
         const float w = w0 * wt[j];                                         // :103
         if (KIND == SMESH_AGG_SUMMAX) {
           int am = 0;
           float best = p[j][0];   // (not p[j][am]: a run-time register index would go through scratch)
 #pragma unroll
-          for (int c = 1; c < C; c++) if (p[j][c] > best) { best = p[j][c]; am = c; }
+          for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[j][c] > best) { best = p[j][c]; am = c; }
 #pragma unroll
-          for (int c = 0; c < C; c++) if (c == am) accr[c] = accr[c] + p[j][c] * w;
+          for (int c = 0; c < CT; c++) if (EXACT || c < C) if (c == am) accr[c] = accr[c] + p[j][c] * w;
         } else {
 #pragma unroll
-          for (int c = 0; c < C; c++) accr[c] = accr[c] + contribution<KIND>(p[j][c], w);
+          for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = accr[c] + contribution<KIND>(p[j][c], w);
         }
       }
     }
@@ -935,12 +959,12 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
     // writing the whole block back would overwrite their sums.  Every other lane stores its own row.
     if (rec.kind != 2 && f < a.F) {
 #pragma unroll
-      for (int c = 0; c < C; c++) blk[l * C + c] = accr[c];
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) blk[l * C + c] = accr[c];
     }
     return;
   }
 #pragma unroll
-  for (int c = 0; c < C; c++) srow[l * C + c] = accr[c];
+  for (int c = 0; c < CT; c++) if (EXACT || c < C) srow[l * C + c] = accr[c];
   wave_sync();
   if (nrows == kWave) {
     f4* b4 = reinterpret_cast<f4*>(blk);
@@ -964,10 +988,6 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
 constexpr int kSlice = 40;
 constexpr uint32_t kSkipPixel = 0x7FC00001u;   // NaN payload in `pw`: pixel dropped by the don't-care test
 
-// float4 at 4-byte alignment: rows are only float-aligned; gfx950 global memory takes dwordx4 at any dword address.
-// (A packed struct gets scalarised: its stores became one write request per lane and dword.)
-typedef float fvec4 __attribute__((ext_vector_type(4)));
-typedef fvec4 fvec4_a4 __attribute__((aligned(4)));
 
 // Loads n <= kSlice floats at src into dst; 16-byte loads as long as four floats remain.
 __device__ __forceinline__ void load_slice(const float* __restrict__ src, int n, float (&dst)[kSlice]) {
@@ -1841,7 +1861,7 @@ static bool fuse_wide_enabled() {
   return !off;
 }
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered) {
-  if (!reordered && (a->C == 5 || a->C == 19 || a->C == 40)) return "k_fuse_tri";
+  if (!reordered && a->C <= 40u) return "k_fuse_tri";
   if (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) return "k_fuse_tri_wide";
   return "k_fuse_tri_any";
 }
@@ -1860,8 +1880,15 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
   { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; t.dbg = fdbg; }
   t.tex_first = nullptr; t.tex_res = nullptr; t.count = nullptr;
   t.prim_id = prim_id;
-  // row held in registers, block staged through LDS: needs consecutive primitive ids per wave (no re-ordered mesh)
-  const bool specialised = !prim_id && (a->C == 5 || a->C == 19 || a->C == 40);
+  // k_fuse_tri (row in registers, the wave's 64-row block staged through LDS) needs consecutive primitive ids per wave
+  // (no re-ordered mesh) and C <= 40: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 40 for the rest
+  // (tri_ct 41 = the run-time instance with 40 slots).
+  int tri_ct = 0;
+  if (!prim_id && a->C <= 40u) {
+    if (a->C == 5 || a->C == 13 || a->C == 19 || a->C == 20 || a->C == 21 || a->C == 40) tri_ct = (int)a->C;   // common label sets
+    else tri_ct = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : 41;
+  }
+  const bool specialised = tri_ct != 0;
   float* pw = nullptr;
   uint32_t* amax = nullptr;
   int G = 1;
@@ -1899,10 +1926,18 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
       default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4>), tgrid, block, 0, st, t); break; \
     }
 #define SMESH_FT(K)                                                                           \
-    switch (specialised ? a->C : 0u) {                                                        \
-      case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K>), grid, block, 0, st, t); break;           \
-      case 19: hipLaunchKernelGGL((k_fuse_tri<19, K>), grid, block, 0, st, t); break;          \
-      case 40: hipLaunchKernelGGL((k_fuse_tri<40, K>), grid, block, 0, st, t); break;          \
+    switch (tri_ct) {                                                                         \
+      case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K, true>), grid, block, 0, st, t); break;     \
+      case 13: hipLaunchKernelGGL((k_fuse_tri<13, K, true>), grid, block, 0, st, t); break;    \
+      case 19: hipLaunchKernelGGL((k_fuse_tri<19, K, true>), grid, block, 0, st, t); break;    \
+      case 20: hipLaunchKernelGGL((k_fuse_tri<20, K, true>), grid, block, 0, st, t); break;    \
+      case 21: hipLaunchKernelGGL((k_fuse_tri<21, K, true>), grid, block, 0, st, t); break;    \
+      case 40: hipLaunchKernelGGL((k_fuse_tri<40, K, true>), grid, block, 0, st, t); break;    \
+      case 8:  hipLaunchKernelGGL((k_fuse_tri<8, K, false>), grid, block, 0, st, t); break;    \
+      case 16: hipLaunchKernelGGL((k_fuse_tri<16, K, false>), grid, block, 0, st, t); break;   \
+      case 24: hipLaunchKernelGGL((k_fuse_tri<24, K, false>), grid, block, 0, st, t); break;   \
+      case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false>), grid, block, 0, st, t); break;   \
+      case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false>), grid, block, 0, st, t); break;   \
       default:                                                                                \
         if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                               \
         hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, pw, amax);             \

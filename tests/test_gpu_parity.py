@@ -381,8 +381,8 @@ def test_dlpack_export_feeds_add(sm, oracle):
 @pytest.mark.parametrize("kind", ["sum", "summax"])
 @pytest.mark.parametrize("C", [5, 19, 40, 1, 7, 32, 33, 64, 127, 150, 258])
 def test_fuse_view_triangle_order_is_bit_exact(sm, oracle, kind, C):
-    """smesh_fuse_view on a triangle renderer takes the triangle-order path (k_fuse_tri for C in {5, 19, 40}, the
-    chunked k_fuse_tri_any for every other class count): every accumulator row has one owner and the reference's
+    """smesh_fuse_view on a triangle renderer takes the triangle-order path (k_fuse_tri for C <= 40 -- exact instances for
+    5 / 19 / 40, run-time-C instances otherwise --, k_fuse_tri_any up to 127, k_fuse_tri_wide beyond): every accumulator row has one owner and the reference's
     float32 operation order is kept, so the raw accumulator equals the float32 single-threaded oracle bit for bit
     (small triangles only; large ones are tree-reduced, see next test)."""
     mesh, cams = small_scene(120, 60, 320, 240, views=3)     # ~1.5 px triangles: all bounding boxes <= 8 x 8
@@ -461,7 +461,8 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
             oagg.add(o.render(cam)[0], probs)
         import os
         if os.environ.get("SMESH_FUSE") != "strip":
-            assert sm._lib.lib().smesh_last_fuse_kernel().decode() == ("k_fuse_tri_wide" if C >= 128 else "k_fuse_tri_any")
+            assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
+                "k_fuse_tri_wide" if C >= 128 else "k_fuse_tri_any" if C > 40 else "k_fuse_tri")
         mul_tol = 1e-2 if os.environ.get("SMESH_FUSE") == "strip" else 3e-3
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
