@@ -1855,13 +1855,17 @@ bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F) {
   return !off && a->P == F && a->S == a->C && a->C <= 64u * 40u;   // 64 lanes x kSlice classes per row
 }
 
+// Largest class count the LDS-block kernel k_fuse_tri takes (a 64-slot instance needs 292 VGPRs and is no faster than
+// k_fuse_tri_any: C = 64 0.311 vs 0.292 ms/view; 48 slots: C = 48 0.184 vs 0.252).
+constexpr uint32_t kFuseTriMaxC = 48;
+
 // Which kernel smesh_aggregator_fuse_triangles dispatches for this aggregator (reporting only).
 static bool fuse_wide_enabled() {
   static const bool off = getenv("SMESH_FUSE_WIDE") && atoi(getenv("SMESH_FUSE_WIDE")) == 0;
   return !off;
 }
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered) {
-  if (!reordered && a->C <= 40u) return "k_fuse_tri";
+  if (!reordered && a->C <= kFuseTriMaxC) return "k_fuse_tri";
   if (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) return "k_fuse_tri_wide";
   return "k_fuse_tri_any";
 }
@@ -1881,12 +1885,12 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
   t.tex_first = nullptr; t.tex_res = nullptr; t.count = nullptr;
   t.prim_id = prim_id;
   // k_fuse_tri (row in registers, the wave's 64-row block staged through LDS) needs consecutive primitive ids per wave
-  // (no re-ordered mesh) and C <= 40: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 40 for the rest
+  // (no re-ordered mesh) and C <= 48: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 48 for the rest
   // (tri_ct 41 = the run-time instance with 40 slots).
   int tri_ct = 0;
-  if (!prim_id && a->C <= 40u) {
+  if (!prim_id && a->C <= kFuseTriMaxC) {
     if (a->C == 5 || a->C == 13 || a->C == 19 || a->C == 20 || a->C == 21 || a->C == 40) tri_ct = (int)a->C;   // common label sets
-    else tri_ct = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : 41;
+    else tri_ct = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : a->C <= 40 ? 41 : 48;
   }
   const bool specialised = tri_ct != 0;
   float* pw = nullptr;
@@ -1938,6 +1942,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
       case 24: hipLaunchKernelGGL((k_fuse_tri<24, K, false>), grid, block, 0, st, t); break;   \
       case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false>), grid, block, 0, st, t); break;   \
       case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false>), grid, block, 0, st, t); break;   \
+      case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false>), grid, block, 0, st, t); break;   \
       default:                                                                                \
         if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                               \
         hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, pw, amax);             \

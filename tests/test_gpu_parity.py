@@ -379,7 +379,7 @@ def test_dlpack_export_feeds_add(sm, oracle):
 
 
 @pytest.mark.parametrize("kind", ["sum", "summax"])
-@pytest.mark.parametrize("C", [5, 19, 40, 1, 7, 32, 33, 64, 127, 150, 258])
+@pytest.mark.parametrize("C", [5, 19, 40, 1, 7, 13, 21, 32, 33, 41, 48, 49, 64, 127, 150, 258])
 def test_fuse_view_triangle_order_is_bit_exact(sm, oracle, kind, C):
     """smesh_fuse_view on a triangle renderer takes the triangle-order path (k_fuse_tri for C <= 40 -- exact instances for
     5 / 19 / 40, run-time-C instances otherwise --, k_fuse_tri_any up to 127, k_fuse_tri_wide beyond): every accumulator row has one owner and the reference's
@@ -462,7 +462,7 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
         import os
         if os.environ.get("SMESH_FUSE") != "strip":
             assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
-                "k_fuse_tri_wide" if C >= 128 else "k_fuse_tri_any" if C > 40 else "k_fuse_tri")
+                "k_fuse_tri_wide" if C >= 128 else "k_fuse_tri_any" if C > 48 else "k_fuse_tri")
         mul_tol = 1e-2 if os.environ.get("SMESH_FUSE") == "strip" else 3e-3
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
