@@ -977,22 +977,24 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
 
 // ------------------------------------------------------------------------------------------------
 // Triangle-order fusion for ANY class count (run-time C).  Same ownership scheme as k_fuse_tri, but a row is
-// split over a GROUP of G adjacent lanes (G = 1, 2, 4 .. 64: the smallest power of two with C / G <= kSlice), each
-// lane holding a contiguous slice of at most kSlice classes of the accumulator row and of the pixel's class vector
+// split over a GROUP of G adjacent lanes (G = 1, 2, 4 .. 64: the smallest power of two with C / G <= kSliceAny), each
+// lane holding a contiguous slice of at most kSliceAny classes of the accumulator row and of the pixel's class vector
 // in registers: one pass over the probabilities whatever C is.  The don't-care test needs the float32 row sum in
 // class order (Mesh.h:98, tt::sum): the running sum (and the running arg-max for Summax) is handed from lane to
 // lane through the group, each lane adding its own classes one by one, so the order of operations -- and the
 // result -- is the single-threaded reference's.  Loads are 16 bytes wide at 4-byte alignment (rows are only
 // float-aligned).  Big triangles: tail blocks, chunked over kSlice classes (fuse_big_triangles_any).
 // ------------------------------------------------------------------------------------------------
-constexpr int kSlice = 40;
+constexpr int kSlice = 40;      // texel kernel (C <= 40) and the class chunks of the big-triangle waves
+constexpr int kSliceAny = 32;   // k_fuse_tri_any: classes per lane (40 cost 170 VGPRs = 2 waves per SIMD)
 constexpr uint32_t kSkipPixel = 0x7FC00001u;   // NaN payload in `pw`: pixel dropped by the don't-care test
 
 
-// Loads n <= kSlice floats at src into dst; 16-byte loads as long as four floats remain.
-__device__ __forceinline__ void load_slice(const float* __restrict__ src, int n, float (&dst)[kSlice]) {
+// Loads n <= N floats at src into dst; 16-byte loads as long as four floats remain.
+template <int N>
+__device__ __forceinline__ void load_slice(const float* __restrict__ src, int n, float (&dst)[N]) {
 #pragma unroll
-  for (int j = 0; j < kSlice; j += 4) {
+  for (int j = 0; j < N; j += 4) {
     if (j + 4 <= n) {
       const fvec4 q = *reinterpret_cast<const fvec4_a4*>(src + j);
       dst[j] = q.x; dst[j + 1] = q.y; dst[j + 2] = q.z; dst[j + 3] = q.w;
@@ -1003,9 +1005,10 @@ __device__ __forceinline__ void load_slice(const float* __restrict__ src, int n,
   }
 }
 
-__device__ __forceinline__ void store_slice(float* __restrict__ dst, int n, const float (&src)[kSlice]) {
+template <int N>
+__device__ __forceinline__ void store_slice(float* __restrict__ dst, int n, const float (&src)[N]) {
 #pragma unroll
-  for (int j = 0; j < kSlice; j += 4) {
+  for (int j = 0; j < N; j += 4) {
     if (j + 4 <= n) {
       fvec4 q;
       q.x = src[j]; q.y = src[j + 1]; q.z = src[j + 2]; q.w = src[j + 3];
@@ -1018,14 +1021,14 @@ __device__ __forceinline__ void store_slice(float* __restrict__ dst, int n, cons
 }
 
 // acc slice += contribution of one pixel's class slice
-template <int KIND>
-__device__ __forceinline__ void accumulate_slice(float (&accr)[kSlice], const float (&p)[kSlice], int cw, float w, int am_local) {
+template <int KIND, int N>
+__device__ __forceinline__ void accumulate_slice(float (&accr)[N], const float (&p)[N], int cw, float w, int am_local) {
   if (KIND == SMESH_AGG_SUMMAX) {
 #pragma unroll
-    for (int j = 0; j < kSlice; j++) accr[j] = (j == am_local) ? accr[j] + p[j] * w : accr[j];   // select, not an indexed update
+    for (int j = 0; j < N; j++) accr[j] = (j == am_local) ? accr[j] + p[j] * w : accr[j];   // select, not an indexed update
   } else {
 #pragma unroll
-    for (int j = 0; j < kSlice; j++) if (j < cw) accr[j] = accr[j] + contribution<KIND>(p[j], w);
+    for (int j = 0; j < N; j++) if (j < cw) accr[j] = accr[j] + contribution<KIND>(p[j], w);
   }
 }
 
@@ -1138,16 +1141,16 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a) {
   if (__ballot(win != 0ull) == 0ull) return;
   const float w0 = n ? a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f : 0.0f;      // Mesh.h:100-102
   float* __restrict__ row = a.acc + f * C + c_lo;
-  float accr[kSlice];
+  float accr[kSliceAny];
   if (win) load_slice(row, cw, accr);
   else {
 #pragma unroll
-    for (int j = 0; j < kSlice; j++) accr[j] = 0.0f;
+    for (int j = 0; j < kSliceAny; j++) accr[j] = 0.0f;
   }
   for (m = win; __ballot(m != 0ull) != 0ull; m &= m - 1ull) {   // wave-uniform trip count: shuffles inside
     const bool have = m != 0ull;
     const uint64_t pix = have ? pixel(__ffsll((long long)m) - 1) : 0;
-    float p[kSlice];
+    float p[kSliceAny];
     load_slice(a.probs + pix * C + c_lo, have ? cw : 0, p);
     const float wt = (have && a.weights) ? a.weights[pix] : 1.0f;
     // row sum (and arg-max) in class order: the running values travel through the group's lanes
@@ -1163,7 +1166,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a) {
       }
       if (g == ph) {
 #pragma unroll
-        for (int j = 0; j < kSlice; j++)
+        for (int j = 0; j < kSliceAny; j++)
           if (j < cw) {
             s = s + p[j];
             if (KIND == SMESH_AGG_SUMMAX && ((ph == 0 && j == 0) || p[j] > best)) { best = p[j]; am = c_lo + (uint32_t)j; }
@@ -1852,7 +1855,7 @@ int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_id
 // Triangle-order fusion entry used by raster.hip's smesh_fuse_view; see k_fuse_tri.
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F) {
   static const bool off = getenv("SMESH_FUSE") && std::string(getenv("SMESH_FUSE")) == "strip";
-  return !off && a->P == F && a->S == a->C && a->C <= 64u * 40u;   // 64 lanes x kSlice classes per row
+  return !off && a->P == F && a->S == a->C && a->C <= 64u * (uint32_t)kSliceAny;   // 64 lanes x kSliceAny classes per row
 }
 
 // Largest class count the LDS-block kernel k_fuse_tri takes (a 64-slot instance needs 292 VGPRs and is no faster than
@@ -1898,7 +1901,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
   int G = 1;
   const int wide_chunks = (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) ? (a->C <= 256 ? 1 : a->C <= 512 ? 2 : 4) : 0;   // k_fuse_tri_wide
   if (!specialised) {
-    while ((((a->C + G - 1) / G + 3u) & ~3u) > (uint32_t)kSlice) G *= 2;   // lanes per accumulator row (can_fuse_triangles: G <= 64)
+    while ((((a->C + G - 1) / G + 3u) & ~3u) > (uint32_t)kSliceAny) G *= 2;   // lanes per accumulator row (can_fuse_triangles: G <= 64)
     // the big-triangle waves park per-pixel weights (and arg-max) here
     SMESH_TRY(a->pw.reserve(N * 4));
     pw = static_cast<float*>(a->pw.ptr);

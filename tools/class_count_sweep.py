@@ -6,7 +6,7 @@ cfg = synth.CONFIGS["cfg2"]; W, H = cfg["width"], cfg["height"]
 mesh = synth.grid_mesh(cfg["a"], cfg["b"])
 r = render.triangles(mesh)
 cams = [synth.ring_camera(k, 40, W, H) for k in range(40)]
-for C in (5, 13, 19, 21, 27, 32, 40, 41, 48, 64, 100, 150, 256):
+for C in (5, 13, 19, 21, 27, 32, 40, 41, 48, 49, 64, 100, 127, 150, 256):
     probs = synth.device_probs(W, H, C, 1, 0.0)
     agg = fusion.MeshAggregator(len(mesh.faces), C)
     for cam in cams[:4]: agg.fuse_view(r, cam, probs)
