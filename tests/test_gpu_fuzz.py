@@ -1,0 +1,126 @@
+"""Randomised differential test of the HIP path against the CPU oracle: triangle soups (overlapping, intersecting,
+degenerate and partly behind-the-camera triangles of every size class), random cameras, resolutions, class counts and
+aggregators.  Indices and depth must be bit-equal; fused distributions within the float tolerance."""
+import numpy as np
+import pytest
+
+from helpers import assert_fused_close, random_probs
+
+pytestmark = pytest.mark.gpu
+
+
+def _soup(rng, nverts, nfaces, spread):
+    """Random triangles: each face picks a centre and three vertices within `spread` of it (so sizes vary with spread)."""
+    centres = rng.uniform(-1.0, 1.0, (nfaces, 3)).astype(np.float32)
+    verts = (centres[:, None, :] + rng.normal(0.0, spread, (nfaces, 3, 3))).astype(np.float32).reshape(-1, 3)
+    faces = np.arange(3 * nfaces, dtype=np.int32).reshape(nfaces, 3)
+    # share some vertices between faces (watertight edges are where the tie rule matters)
+    share = rng.integers(0, 3 * nfaces, nfaces // 2)
+    faces.reshape(-1)[rng.integers(0, 3 * nfaces, nfaces // 2)] = share
+    # a few exactly duplicated faces and zero-area faces
+    faces[rng.integers(0, nfaces, 3)] = faces[rng.integers(0, nfaces, 3)]
+    z = rng.integers(0, nfaces, 3)
+    faces[z, 2] = faces[z, 1]
+    return verts, faces
+
+
+def _camera(sm, rng, W, H):
+    from semantic_meshes_amd import synth
+    eye = rng.uniform(-2.5, 2.5, 3)
+    if rng.random() < 0.3:
+        eye *= 0.2                                    # inside the soup: triangles cross the near limit
+    target = rng.uniform(-0.5, 0.5, 3)
+    R, t = synth.look_at(tuple(eye), tuple(target), up=(0, 0, 1))
+    f = float(rng.uniform(0.4, 1.5)) * W
+    return sm.data.Camera(R, t, np.array([W, H]), np.array([f, f * rng.uniform(0.8, 1.2)]),
+                          np.array([W * rng.uniform(0.3, 0.7), H * rng.uniform(0.3, 0.7)]))
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_soup_against_oracle(sm, oracle, seed):
+    import types
+    rng = np.random.default_rng(1000 + seed)
+    nfaces = int(rng.choice([50, 400, 3000, 6000]))
+    spread = float(rng.choice([0.004, 0.02, 0.08, 0.4]))            # sub-pixel ... larger than 64 x 64 boxes
+    verts, faces = _soup(rng, 0, nfaces, spread)
+    W, H = int(rng.choice([37, 160, 333])), int(rng.choice([29, 120, 257]))
+    C = int(rng.choice([1, 3, 5, 19, 21, 40, 47, 70, 130]))
+    kind = str(rng.choice(["sum", "summax", "mul"]))
+    iew = float(rng.choice([0.0, 0.5, 1.0]))
+    mesh = types.SimpleNamespace(vertices=verts, faces=faces)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(verts, faces)
+    P = len(faces)
+    agg = sm.fusion.MeshAggregator(P, C, kind, iew)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, iew)
+        for view in range(3):
+            cam = _camera(sm, rng, W, H)
+            idx, depth = r.render(cam)
+            oidx, odepth = o.render(cam)
+            np.testing.assert_array_equal(np.asarray(idx), oidx)
+            np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+            probs = random_probs(rng, W, H, C, zero_fraction=0.1)
+            if kind == "mul":
+                probs = np.where(probs.sum(-1, keepdims=True) > 0, np.maximum(probs, 1e-3), 0).astype(np.float32)
+            weights = rng.random((W, H), dtype=np.float32) if view == 1 else None
+            if view == 2:
+                agg.add(idx, probs)                                   # render() + add(): same kernels as fuse_view
+            else:
+                agg.fuse_view(r, cam, probs, weights)
+            oagg.add(oidx, probs, weights)
+        # Mul keeps float32 log-domain sums: one ulp of a sum of magnitude 1e3-1e4 is 1e-4..1e-3 relative after exp()
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5 if kind != "mul" else 5e-3, atol=1e-6)
+    finally:
+        oracle.set_accum_double(False)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_texel_soup_against_oracle(sm, oracle, seed):
+    import types
+    rng = np.random.default_rng(5000 + seed)
+    nfaces = int(rng.choice([60, 500, 2500]))
+    spread = float(rng.choice([0.01, 0.05, 0.3]))
+    verts, faces = _soup(rng, 0, nfaces, spread)
+    W, H = int(rng.choice([64, 200])), int(rng.choice([48, 150]))
+    C = int(rng.choice([2, 7, 40, 45]))
+    kind = str(rng.choice(["sum", "summax"]))
+    cams = [_camera(sm, rng, W, H) for _ in range(3)]
+    tpp = float(rng.choice([0.1, 0.5, 1.5]))
+    mesh = types.SimpleNamespace(vertices=verts, faces=faces)
+    r = sm.render.texels(mesh, cams, tpp)
+    o = oracle.OracleRenderer(verts, faces, cams, tpp)
+    P = r.getPrimitivesNum()
+    assert P == o.getPrimitivesNum()
+    if P == 0:
+        return
+    agg = sm.fusion.MeshAggregator(P, C, kind)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind)
+        for cam in cams:
+            idx, depth = r.render(cam)
+            oidx, odepth = o.render(cam)
+            np.testing.assert_array_equal(np.asarray(idx), oidx)
+            np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+            probs = random_probs(rng, W, H, C, zero_fraction=0.1)
+            agg.fuse_view(r, cam, probs)
+            oagg.add(oidx, probs)
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
+    finally:
+        oracle.set_accum_double(False)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_soup_forced_reorder(seed):
+    """The same differential test with SMESH_REORDER=1 (every mesh processed in Morton order behind a position -> id table)."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, SMESH_REORDER="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    sel = "test_random_soup_against_oracle and (%s)" % " or ".join("[%d]" % (seed * 10 + k) for k in range(10))
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_fuzz.py"), "-q", "-x", "-m", "gpu",
+                          "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
