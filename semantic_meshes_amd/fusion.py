@@ -93,6 +93,15 @@ class _MeshAggregator:
             _lib.check(_lib.lib().smesh_aggregator_get(self._h, out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
         return out
 
+    def get_device(self):
+        """`get()` without the trip to the host: the normalised float32[P,C] result as a device-resident `DeviceArray`
+        (`__cuda_array_interface__` / DLPack) in a fresh HBM allocation owned by the returned object."""
+        from .device import DeviceBuffer
+        buf = DeviceBuffer(max(self.primitives * self.classes * 4, 4), self.device)
+        if self.primitives * self.classes:
+            _lib.check(_lib.lib().smesh_aggregator_get(self._h, ctypes.c_void_p(buf.ptr), _lib.MEM_DEVICE))
+        return buf.view((self.primitives, self.classes), np.float32)
+
     # ---- new functionality (SURVEY.md 8e): raw accumulator access for the cross-GPU sum ----------
     def get_raw(self):
         out = np.empty((self.primitives, self.classes), np.float32)

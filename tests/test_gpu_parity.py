@@ -840,3 +840,17 @@ def test_odd_image_sizes(sm, oracle, res):
         assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
     finally:
         oracle.set_accum_double(False)
+
+
+def test_get_device_matches_get(sm):
+    mesh, cams = small_scene()
+    P, C = len(mesh.faces), 19
+    rng = np.random.default_rng(8)
+    r = sm.render.triangles(mesh)
+    agg = sm.fusion.MeshAggregator(P, C, "mul")
+    for cam in cams:
+        agg.fuse_view(r, cam, np.maximum(random_probs(rng, *cam.resolution, C), 1e-3).astype(np.float32))
+    host = agg.get()
+    dev = agg.get_device()
+    assert dev.shape == (P, C) and dev.dtype == np.float32
+    np.testing.assert_array_equal(np.asarray(dev).view(np.uint32), host.view(np.uint32))
