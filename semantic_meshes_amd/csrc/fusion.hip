@@ -862,6 +862,10 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   if (f < a.F) rec = a.frags[f];
+  // Re-ordered mesh (renderer's position -> primitive id table): the id is what the index image holds and which row to
+  // update; the 64 rows of a wave are then scattered, so every lane loads / stores its own row instead of the LDS block.
+  const bool scattered = a.prim_id != nullptr;
+  const uint32_t pid = (scattered && f < a.F) ? a.prim_id[f] : (uint32_t)f;
   auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
 
   // ---- pass 1: which emitted fragments won the depth test?  n = pixels of this primitive in this view.
@@ -880,7 +884,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < 4; j++)
-      if (k[j] >= 0 && got[j] == (uint32_t)f) { n++; win |= 1ull << k[j]; }
+      if (k[j] >= 0 && got[j] == pid) { n++; win |= 1ull << k[j]; }
   }
   if (__ballot(win != 0ull) == 0ull) return;   // nothing of these 64 triangles is visible: rows untouched
 
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
   const int nrows = (int)min((uint64_t)kWave, a.F - f0);
   float* __restrict__ blk = a.acc + f0 * C;
   f4 br[KV];
-  if (nrows == kWave) {
+  if (nrows == kWave && !scattered) {
     const f4* b4 = reinterpret_cast<const f4*>(blk);
 #pragma unroll
     for (int q = 0; q < KV; q++) br[q] = b4[min(l + q * kWave, kWave * C / 4 - 1)];
@@ -916,6 +920,10 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
       const float* __restrict__ pr = a.probs + pix * C;
       load_row<CT, EXACT>(pr, C, p[j]);
       wt[j] = a.weights ? a.weights[pix] : 1.0f;
+    }
+    if (!rows_loaded && scattered) {
+      if (win) load_row<CT, EXACT>(a.acc + (uint64_t)pid * C, C, accr);
+      rows_loaded = true;
     }
     if (!rows_loaded) {
       // park the block in LDS (flat, coalesced) and pick up this lane's row
@@ -953,6 +961,13 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
         }
       }
     }
+  }
+  if (scattered) {
+    if (win) {
+#pragma unroll
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) a.acc[(uint64_t)pid * C + c] = accr[c];
+    }
+    return;
   }
   if (__ballot(rec.kind == 2) != 0ull) {
     // Some of these 64 rows belong to big triangles, which the tail blocks of this launch update concurrently:
@@ -1868,7 +1883,8 @@ static bool fuse_wide_enabled() {
   return !off;
 }
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered) {
-  if (!reordered && a->C <= kFuseTriMaxC) return "k_fuse_tri";
+  if (a->C <= kFuseTriMaxC) return "k_fuse_tri";
+  (void)reordered;
   if (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) return "k_fuse_tri_wide";
   return "k_fuse_tri_any";
 }
@@ -1887,11 +1903,10 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
   { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; t.dbg = fdbg; }
   t.tex_first = nullptr; t.tex_res = nullptr; t.count = nullptr;
   t.prim_id = prim_id;
-  // k_fuse_tri (row in registers, the wave's 64-row block staged through LDS) needs consecutive primitive ids per wave
-  // (no re-ordered mesh) and C <= 48: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 48 for the rest
+  // k_fuse_tri (row in registers; the wave's 64-row block staged through LDS unless the mesh was re-ordered) takes C <= 48: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 48 for the rest
   // (tri_ct 41 = the run-time instance with 40 slots).
   int tri_ct = 0;
-  if (!prim_id && a->C <= kFuseTriMaxC) {
+  if (a->C <= kFuseTriMaxC) {
     if (a->C == 5 || a->C == 13 || a->C == 19 || a->C == 20 || a->C == 21 || a->C == 40) tri_ct = (int)a->C;   // common label sets
     else tri_ct = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : a->C <= 40 ? 41 : 48;
   }

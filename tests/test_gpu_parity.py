@@ -707,7 +707,7 @@ def test_shuffled_face_order_is_reordered_internally(sm, oracle, C):
         agg.fuse_view(r, cam, probs)
         oagg.add(oidx, probs)
     if os.environ.get("SMESH_FUSE") != "strip":
-        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == ("k_fuse_tri_any" if C == 19 else "k_fuse_tri_wide")
+        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == ("k_fuse_tri" if C == 19 else "k_fuse_tri_wide")
         np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
     assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
     # render() + add() on the re-ordered renderer, and bigger triangles (cooperative paths) with the id table
