@@ -80,3 +80,23 @@ def test_product_never_imports_the_oracle():
                 assert "oracle" not in text.replace("the oracle", "").replace("CPU oracle", "").replace("oracle/", "ORACLEDIR/") or \
                     "import oracle" not in text and "from oracle" not in text and "libsmesh_oracle" not in text, f
                 assert "libsmesh_oracle" not in text and "from oracle" not in text and "import oracle" not in text, f
+
+
+def test_c99_client_compiles_and_runs_against_the_oracle(tmp_path):
+    """include/smesh.h is plain C: tests/abi_smoke.c (what a cgo / JNI / C++ host would write) compiles with
+    gcc -std=c99 -pedantic, and -- linked against the CPU oracle, which exports the same ABI -- runs."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = os.path.join(root, "tests", "abi_smoke.c")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(root, "include"),
+                           "-fsyntax-only", src])
+    from oracle import oracle
+    oracle.build()
+    exe = str(tmp_path / "abi_smoke_oracle")
+    subprocess.check_call(["gcc", "-std=c99", "-DABI_SMOKE_SKIP_DEVICE_COUNT", "-I", os.path.join(root, "include"), src,
+                           "-L", os.path.join(root, "oracle"), "-lsmesh_oracle", "-lm",
+                           "-Wl,-rpath," + os.path.join(root, "oracle"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi smoke ok" in out.stdout

@@ -854,3 +854,17 @@ def test_get_device_matches_get(sm):
     dev = agg.get_device()
     assert dev.shape == (P, C) and dev.dtype == np.float32
     np.testing.assert_array_equal(np.asarray(dev).view(np.uint32), host.view(np.uint32))
+
+
+def test_c99_client_against_the_hip_library(tmp_path):
+    """tests/abi_smoke.c built with gcc against libsmesh_hip.so: the C ABI without any Python in between."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "semantic_meshes_amd", "csrc")
+    exe = str(tmp_path / "abi_smoke_hip")
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "abi_smoke.c"),
+                           "-L", libdir, "-lsmesh_hip", "-lm", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "abi smoke ok" in out.stdout and "hip-gfx950" in out.stdout
