@@ -73,9 +73,20 @@ __global__ void k_gather_probs(const float* __restrict__ in, int64_t s0, int64_t
 // ------------------------------------------------------------------------------------------------
 // aggregator input maps (Fusion.cu:51-56 Summax, :70-73 Sum, :83-87 Mul)
 // ------------------------------------------------------------------------------------------------
+// Mul: LogProb<float>(pow(p, w)) (Fusion.cu:83-87) = log(p^w).  Whenever p^w is a NORMAL float that is w * log(p) to within the
+// rounding the two-step form has itself (pow rounds p^w to 24 bits: 6e-8 absolute in the log; log rounds again), at an eighth of
+// the instructions -- powf made the Mul aggregator three times slower than Sum.  Where p^w leaves the normal range (underflow to
+// zero or denormals, overflow) or the inputs are not positive finite numbers, the two-step form decides: -inf, NaN and the
+// coarse denormal steps are part of the reference's behaviour.
+__device__ __forceinline__ float log_of_power(float p, float w) {
+  const float t = w * logf(p);
+  if (p > 0.0f && isfinite(p) && isfinite(w) && t > -87.0f && t < 88.0f) return t;   // e^-87 .. e^88 is inside float's normal range
+  return logf(powf(p, w));
+}
+
 template <int KIND>
 __device__ __forceinline__ float contribution(float p, float w) {
-  if (KIND == SMESH_AGG_MUL) return logf(powf(p, w));  // LogProb of p^w
+  if (KIND == SMESH_AGG_MUL) return log_of_power(p, w);
   return p * w;
 }
 

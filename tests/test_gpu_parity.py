@@ -868,3 +868,34 @@ def test_c99_client_against_the_hip_library(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "abi smoke ok" in out.stdout and "hip-gfx950" in out.stdout
+
+
+def test_mul_aggregator_edge_values(sm, oracle):
+    """Mul = sum of log(p^w) (Fusion.cu:83-87): zero probabilities, zero weights, and weights so large that p^w
+    underflows to zero must behave like the two-step pow -> log of the reference."""
+    mesh, cams = small_scene(60, 30, 200, 150, views=2)
+    P, C = len(mesh.faces), 5
+    rng = np.random.default_rng(77)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    agg = sm.fusion.MeshAggregator(P, C, "mul", 0.0)      # images_equal_weight 0: the pixel weight is the weights image
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, "mul", 0.0)
+        for cam in cams:
+            W, H = cam.resolution
+            probs = random_probs(rng, W, H, C, zero_fraction=0.0)
+            probs[rng.random((W, H)) < 0.2, 0] = 0.0                     # p = 0 in one class: log(0^w) = -inf
+            probs[rng.random((W, H)) < 0.1, 1] = 1.0                     # p = 1: contributes exactly 0
+            probs[rng.random((W, H)) < 0.1, 2] = 1e-30                   # p^3 = 1e-90 underflows to zero: -inf
+            # (no weight that puts p^w of an ordinary p into float's DENORMAL range, 1e-45 .. 1e-38: the host's pow keeps
+            # denormals, the device's flushes them to zero -- the one place where the two-step form is platform-dependent)
+            weights = rng.choice(np.array([0.0, 0.5, 1.0, 3.0], np.float32), size=(W, H))
+            agg.fuse_view(r, cam, probs, weights)
+            oagg.add(o.render(cam)[0], probs, weights)
+        got, want = agg.get(), oagg.get()
+        assert np.isfinite(got).all()                                    # NaN / Inf -> 0 in get() (Fusion.h:79-95)
+        assert_fused_close(got, want, rtol=5e-3, atol=1e-6)
+        assert ((want == 0) == (got == 0)).mean() > 0.999                # the same classes are wiped out by -inf
+    finally:
+        oracle.set_accum_double(False)
