@@ -170,8 +170,8 @@ int smesh_annotation_renderer_destroy(smesh_annotation_renderer_t* r);
 int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* camera,
                     const float* probs, const float* weights, int memkind);
 
-/* add() for an index image that is the UNMODIFIED device output `indices_dev` of r's most recent
- * smesh_renderer_render_device(): the reference's two-call convention `idx, depth = renderer.render(cam);
+/* add() for an index image that is the UNMODIFIED device output `indices_dev` of one of r's two most recent
+ * smesh_renderer_render_device() calls: the reference's two-call convention `idx, depth = renderer.render(cam);
  * aggregator.add(idx, probs)` (python/scripts/colorize_cityscapes_mesh.py:65-67) then runs the same triangle-order
  * fusion as smesh_fuse_view, using the per-triangle records that render left behind.  Same results as smesh_aggregator_add;
  * if `idx_dev` is anything else, or the layout is not the dense (W,H[,C]) one, the call IS smesh_aggregator_add. */

@@ -764,9 +764,11 @@ struct smesh_renderer {
   hipEvent_t ev_rendered[2] = {nullptr, nullptr};   // raster stream: slot is complete
   hipEvent_t ev_consumed[2] = {nullptr, nullptr};   // main stream: the fusion kernels have read the slot
   uint64_t fused_seq = 0;
-  // the index plane handed out by the most recent smesh_renderer_render_device(): side[0] still describes it
-  const uint32_t* last_idx = nullptr;
-  uint64_t last_W = 0, last_H = 0;
+  // the index planes handed out by the last TWO smesh_renderer_render_device() calls (they alternate between the two
+  // sets of per-triangle records): last_idx[s] is the plane side[s] still describes, or null
+  const uint32_t* last_idx[2] = {nullptr, nullptr};
+  uint64_t last_W[2] = {0, 0}, last_H[2] = {0, 0};
+  uint64_t render_seq = 0;
   bool raster_pending = false;     // work queued on the raster stream since the last synchronisation
   bool main_pending = false;       // renderer state (keys, scratch) used on the main stream since then
   std::mutex mu;
@@ -1223,8 +1225,14 @@ int smesh_renderer_render_device(smesh_renderer_t* r, const smesh_camera_t* cam,
   SMESH_HIP(hipSetDevice(r->ctx->device));
   ImagePair* im;
   SMESH_TRY(acquire_image(r, cam->width * cam->height, &im));
-  SMESH_TRY(render_into(r, cam, im->idx, im->depth));
-  r->last_idx = im->idx; r->last_W = cam->width; r->last_H = cam->height;
+  // alternate between the two sides: add(idx) still finds the records of the render BEFORE the latest one (the reference's
+  // harness adds view k on a worker thread while the main thread already renders view k+1, eval_scannet.py:189-238)
+  const int side = (int)(r->render_seq++ & 1u);
+  if (side == 1) SMESH_HIP(alloc_side(r, 1));
+  r->last_idx[side] = nullptr;
+  SMESH_TRY(render_into(r, cam, im->idx, im->depth, nullptr, side));
+  if (r->last_idx[side ^ 1] == im->idx) r->last_idx[side ^ 1] = nullptr;   // that plane went back to the pool and is being reused
+  r->last_idx[side] = im->idx; r->last_W[side] = cam->width; r->last_H[side] = cam->height;
   im->idx_out = im->depth_out = true;
   *indices_dev = im->idx;
   *depth_dev = im->depth;
@@ -1252,7 +1260,7 @@ int smesh_renderer_render(smesh_renderer_t* r, const smesh_camera_t* cam, uint32
   SMESH_TRY(r->own_idx.reserve(N * 8));
   uint32_t* d_idx = static_cast<uint32_t*>(r->own_idx.ptr);
   float* d_depth = reinterpret_cast<float*>(d_idx + N);
-  r->last_idx = nullptr;   // side[0] is about to describe this render, whose planes stay private
+  r->last_idx[0] = nullptr;   // side[0] is about to describe this render, whose planes stay private
   SMESH_TRY(render_into(r, cam, d_idx, d_depth));
   SMESH_HIP(hipMemcpyAsync(indices_out, d_idx, N * 4, hipMemcpyDeviceToHost, ctx->stream));
   if (depth_out) SMESH_HIP(hipMemcpyAsync(depth_out, d_depth, N * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1303,7 +1311,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
     SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, r->ev_consumed[slot], 0));   // view k-2 has been fused
   }
   uint32_t* d_idx = static_cast<uint32_t*>(r->fused[slot].ptr);
-  r->last_idx = nullptr;   // the records of the last render_device() are being overwritten
+  r->last_idx[slot] = nullptr;   // the records of a render_device() on this side are being overwritten
   if (slot == 1) SMESH_HIP(alloc_side(r, 1));
   SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, rst, slot));   // the fusion only consumes the index plane
   if (pipelined) {
@@ -1334,12 +1342,14 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
     std::lock_guard<std::mutex> g(r->mu);
     std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-    fast = idx_dev == r->last_idx && W == r->last_W && H == r->last_H &&
-           ((!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) ||
-            (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)));
+    int side = -1;
+    for (int sd = 0; sd < 2; sd++)
+      if (idx_dev == r->last_idx[sd] && W == r->last_W[sd] && H == r->last_H[sd]) side = sd;
+    fast = side >= 0 && ((!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) ||
+                         (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)));
     if (fast) {
       SMESH_HIP(hipSetDevice(ctx->device));
-      return fuse_rendered(r, a, 0, idx_dev, probs, weights, probs_mem, W, H);
+      return fuse_rendered(r, a, side, idx_dev, probs, weights, probs_mem, W, H);
     }
   }
   const int64_t is[2] = {(int64_t)H, 1};

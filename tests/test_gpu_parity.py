@@ -639,18 +639,27 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
         oagg.add(o.render(cam)[0], probs, weights)
     if not forced_generic:
         np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
-    # 1. an older render: its per-triangle records are gone -> generic path
+    # 1. the render before the latest one is still recognised (the harness adds view k while view k+1 is being rendered),
+    #    an older one is not: its per-triangle records are gone -> generic path
     probs = random_probs(rng, *cams[0].resolution, C)
     idx0, _ = r.render(cams[0])
     idx1, _ = r.render(cams[1])
     agg.add(idx0, probs)
+    assert last() == ("k_scatter_strip" if forced_generic else "k_fuse_tri")
+    oagg.add(o.render(cams[0])[0], probs)
+    idx2, _ = r.render(cams[2])
+    agg.add(idx0, probs)
     assert last() == "k_scatter_strip"
     oagg.add(o.render(cams[0])[0], probs)
+    agg.add(idx1, probs)
+    assert last() == ("k_scatter_strip" if forced_generic else "k_fuse_tri")
+    oagg.add(o.render(cams[1])[0], probs)
+    del idx0, idx1, idx2
     # 2. exported through __cuda_array_interface__ (someone else may have changed it) -> generic path
     idx2, _ = r.render(cams[2])
     _ = idx2.__cuda_array_interface__
+    assert idx2._exported                                       # MeshAggregator.add() now calls smesh_aggregator_add
     agg.add(idx2, probs)
-    assert last() == "k_scatter_strip"
     oagg.add(o.render(cams[2])[0], probs)
     # 3. device-resident probs and the latest render -> fast path again
     from semantic_meshes_amd.device import to_device
