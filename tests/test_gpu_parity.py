@@ -462,7 +462,7 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
         import os
         if os.environ.get("SMESH_FUSE") != "strip":
             assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
-                "k_fuse_tri_wide" if C >= 128 else "k_fuse_tri_any" if C > 48 else "k_fuse_tri")
+                "k_fuse_tri_wide" if C >= 128 and os.environ.get("SMESH_FUSE_WIDE") != "0" else "k_fuse_tri_any" if C > 48 else "k_fuse_tri")
         mul_tol = 1e-2 if os.environ.get("SMESH_FUSE") == "strip" else 3e-3
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
@@ -504,7 +504,7 @@ def test_render_fragment_queue_overflow(sm, oracle, monkeypatch, cap):
     np.testing.assert_array_equal(np.asarray(idx), o.render(cams[1])[0])
 
 
-@pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE_PIPELINE=1", "SMESH_FUSE=strip"])
+@pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE_PIPELINE=1", "SMESH_FUSE=strip", "SMESH_FUSE_WIDE=0"])
 def test_alternative_paths_in_subprocess(knob):
     """These knobs are read once per process: re-run the render / fuse_view parity tests with the direct rasteriser
     (global 64-bit atomicMin per fragment), with the two-stream raster/fusion pipeline, and with the generic
@@ -716,7 +716,8 @@ def test_shuffled_face_order_is_reordered_internally(sm, oracle, C):
         agg.fuse_view(r, cam, probs)
         oagg.add(oidx, probs)
     if os.environ.get("SMESH_FUSE") != "strip":
-        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == ("k_fuse_tri" if C == 19 else "k_fuse_tri_wide")
+        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
+            "k_fuse_tri" if C == 19 else "k_fuse_tri_wide" if os.environ.get("SMESH_FUSE_WIDE") != "0" else "k_fuse_tri_any")
         np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
     assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
     # render() + add() on the re-ordered renderer, and bigger triangles (cooperative paths) with the id table
