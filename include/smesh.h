@@ -170,6 +170,14 @@ int smesh_annotation_renderer_destroy(smesh_annotation_renderer_t* r);
 int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* camera,
                     const float* probs, const float* weights, int memkind);
 
+/* A batch of `n` views: smesh_fuse_view(r, a, &cameras[i], probs[i], weights ? weights[i] : NULL, memkind) for i = 0 .. n-1, in
+ * that order (the loop of python/scripts/colorize_cityscapes_mesh.py:54-67 handed over whole).  `probs` / `weights` are arrays of n
+ * image pointers (weights, or single entries of it, may be NULL).  With a triangle renderer and device-resident images, consecutive
+ * views are fused two per launch -- each accumulator row makes one round trip for both -- with the additions in the order of n
+ * separate calls. */
+int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cameras, uint64_t n,
+                     const float* const* probs, const float* const* weights, int memkind);
+
 /* add() for an index image that is the UNMODIFIED device output `indices_dev` of one of r's two most recent
  * smesh_renderer_render_device() calls: the reference's two-call convention `idx, depth = renderer.render(cam);
  * aggregator.add(idx, probs)` (python/scripts/colorize_cityscapes_mesh.py:65-67) then runs the same triangle-order

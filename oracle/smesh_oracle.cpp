@@ -601,6 +601,16 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
                               weights, is, memkind, W, H);
 }
 
+int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cams, uint64_t n,
+                     const float* const* probs, const float* const* weights, int memkind) {
+  if (n && (!cams || !probs)) return fail(SMESH_ERR_INVALID, "NULL argument");
+  for (uint64_t i = 0; i < n; i++) {   // the reference's loop: one view after the other
+    const int st = smesh_fuse_view(r, a, &cams[i], probs[i], weights ? weights[i] : nullptr, memkind);
+    if (st) return st;
+  }
+  return SMESH_OK;
+}
+
 // --------------------------------------------------------------------------------------------
 const char* smesh_last_fuse_kernel(void) { return "oracle"; }
 int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, const uint32_t* idx, const float* probs,

@@ -84,4 +84,15 @@ struct TriFrag {
 };
 static_assert(sizeof(TriFrag) == 16, "TriFrag must be 16 bytes");
 
+// One rendered view as the triangle-order fusion consumes it (raster.hip -> fusion.hip).
+struct RenderedView {
+  const TriFrag* frags;         // per-triangle fragment records of the render
+  const uint32_t* big_queue;    // triangles with a bounding box over 8 x 8 pixels ...
+  const uint32_t* big_len;      // ... and how many (device counter)
+  const uint32_t* idx;          // index plane [W][H]
+  const float* probs;           // [W][H][C], device
+  const float* weights;         // [W][H] or null, device
+  uint64_t W, H;
+};
+
 }  // namespace smesh

@@ -733,7 +733,7 @@ struct TriFuseArgs {
   const float* weights;       // may be null
   float* acc;                 // [P][C] dense
   uint64_t F;
-  uint32_t C, H;
+  uint32_t C, W, H;
   float iew;
   const uint32_t* big_queue;
   const uint32_t* big_len;    // queue length of this render (emptied by the next render's vertex kernel)
@@ -747,9 +747,6 @@ struct TriFuseArgs {
   uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
 };
 
-// Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle, lanes over the box;
-// per-lane partial sums are combined by a butterfly over the wave (so, unlike the small-triangle path, the
-// summation order is a tree) and lane c owns class c of the row.  Runs in the tail blocks of k_fuse_tri.
 // float4 at 4-byte alignment: rows are only float-aligned; gfx950 global memory takes dwordx4 at any dword address.
 // (A packed struct gets scalarised: its stores became one write request per lane and dword.)
 typedef float fvec4 __attribute__((ext_vector_type(4)));
@@ -776,128 +773,179 @@ __device__ __forceinline__ void load_row(const float* __restrict__ pr, int C, fl
   }
 }
 
+// One triangle of one view, its pixels found by scanning the box [x0, x1] x [y0, y1] of the index image: one WAVE, lanes
+// over the box; per-lane partial sums are combined by a butterfly over the wave and lane c owns class c of the row.
 template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers) {
+__device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f, const int x0, const int y0, const int x1, const int y1) {
   const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
   const int l = threadIdx.x;
+  const int bh = y1 - y0 + 1;
+  const long long npx = (long long)(x1 - x0 + 1) * bh;
+  // U pixels per lane and step: their index loads, then their class vectors, are in flight together
+  constexpr int U = CT <= 24 ? 4 : 2;
+  auto pix_of = [&](long long i) -> uint64_t { return (uint64_t)(x0 + (int)(i / bh)) * a.H + (uint64_t)(y0 + (int)(i % bh)); };
+  uint32_t n = 0;
+  for (long long base = 0; base < npx; base += (long long)kWave * U) {
+    uint32_t v[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long long i = base + (long long)u * kWave + l;
+      v[u] = a.idx[i < npx ? pix_of(i) : pix_of(0)];
+      if (!(i < npx)) v[u] = ~f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) n += v[u] == f ? 1u : 0u;
+  }
+  n = wave_sum_u(n);
+  if (n == 0) return;
+  const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
+  float part[CT];
+#pragma unroll
+  for (int c = 0; c < CT; c++) part[c] = 0.0f;
+  for (long long base = 0; base < npx; base += (long long)kWave * U) {
+    uint64_t pix[U];
+    bool hit[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const long long i = base + (long long)u * kWave + l;
+      pix[u] = i < npx ? pix_of(i) : pix_of(0);
+      hit[u] = a.idx[pix[u]] == f && i < npx;
+    }
+    float p[U][CT];
+    float wt[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const float* __restrict__ pr = a.probs + (hit[u] ? pix[u] : pix_of(0)) * C;   // unconditional: the loads overlap
+      load_row<CT, EXACT>(pr, C, p[u]);
+      wt[u] = (a.weights && hit[u]) ? a.weights[pix[u]] : 1.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      float sum = 0.0f;
+#pragma unroll
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[u][c];
+      if (!(hit[u] && sum > 0.5f)) continue;
+      const float w = w0 * wt[u];
+      if (KIND == SMESH_AGG_SUMMAX) {
+        float best = p[u][0];
+        int am = 0;
+#pragma unroll
+        for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[u][c] > best) { best = p[u][c]; am = c; }
+#pragma unroll
+        for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] = (c == am) ? part[c] + p[u][c] * w : part[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] += contribution<KIND>(p[u][c], w);
+      }
+    }
+  }
+  float mine = 0.0f;
+#pragma unroll
+  for (int c = 0; c < CT; c++) if (EXACT || c < C) {
+    const float v = wave_sum(part[c]);
+    if (l == c) mine = v;
+  }
+  if (l < C) a.acc[(uint64_t)f * C + l] += mine;   // this wave owns the row: plain read-modify-write
+}
+
+// Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle (so, unlike the small-triangle
+// path, the summation order is a tree).  Runs in the tail blocks of k_fuse_tri.
+template <int CT, int KIND, bool EXACT>
+__device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers) {
   const uint32_t nbig = min(*a.big_len, a.big_capacity);
   for (uint32_t q = worker; q < nbig; q += nworkers) {
     const uint32_t fi = a.big_queue[q];                       // position in the renderer's triangle order
     const TriFrag rec = a.frags[fi];
     if (rec.kind != 2) continue;
     const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
-    const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
-    const int bh = y1 - y0 + 1;
-    const long long npx = (long long)(x1 - x0 + 1) * bh;
-    // U pixels per lane and step: their index loads, then their class vectors, are in flight together
-    constexpr int U = CT <= 24 ? 4 : 2;
-    auto pix_of = [&](long long i) -> uint64_t { return (uint64_t)(x0 + (int)(i / bh)) * a.H + (uint64_t)(y0 + (int)(i % bh)); };
-    uint32_t n = 0;
-    for (long long base = 0; base < npx; base += (long long)kWave * U) {
-      uint32_t v[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const long long i = base + (long long)u * kWave + l;
-        v[u] = a.idx[i < npx ? pix_of(i) : pix_of(0)];
-        if (!(i < npx)) v[u] = ~f;
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) n += v[u] == f ? 1u : 0u;
-    }
-    n = wave_sum_u(n);
-    if (n == 0) continue;
-    const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
-    float part[CT];
-#pragma unroll
-    for (int c = 0; c < CT; c++) part[c] = 0.0f;
-    for (long long base = 0; base < npx; base += (long long)kWave * U) {
-      uint64_t pix[U];
-      bool hit[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const long long i = base + (long long)u * kWave + l;
-        pix[u] = i < npx ? pix_of(i) : pix_of(0);
-        hit[u] = a.idx[pix[u]] == f && i < npx;
-      }
-      float p[U][CT];
-      float wt[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const float* __restrict__ pr = a.probs + (hit[u] ? pix[u] : pix_of(0)) * C;   // unconditional: the loads overlap
-        load_row<CT, EXACT>(pr, C, p[u]);
-        wt[u] = (a.weights && hit[u]) ? a.weights[pix[u]] : 1.0f;
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[u][c];
-        if (!(hit[u] && sum > 0.5f)) continue;
-        const float w = w0 * wt[u];
-        if (KIND == SMESH_AGG_SUMMAX) {
-          float best = p[u][0];
-          int am = 0;
-#pragma unroll
-          for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[u][c] > best) { best = p[u][c]; am = c; }
-#pragma unroll
-          for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] = (c == am) ? part[c] + p[u][c] * w : part[c];
-        } else {
-#pragma unroll
-          for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] += contribution<KIND>(p[u][c], w);
-        }
-      }
-    }
-    float mine = 0.0f;
-#pragma unroll
-    for (int c = 0; c < CT; c++) if (EXACT || c < C) {
-      const float v = wave_sum(part[c]);
-      if (l == c) mine = v;
-    }
-    if (l < C) a.acc[(uint64_t)f * C + l] += mine;   // this wave owns the row: plain read-modify-write
+    fuse_box<CT, KIND, EXACT>(a, f, rec.x0, rec.y0, (int)(rec.mask & 0xFFFFu), (int)((rec.mask >> 16) & 0xFFFFu));
   }
 }
 
+// Two views in one launch: a triangle that is big in EITHER view is left to one tail wave for BOTH views (first view
+// first, as two calls would do it), so that no other wave touches its row; its small view is scanned as an 8 x 8 box.
+// A triangle queued by both views is taken from the first view's queue only.
 template <int CT, int KIND, bool EXACT>
-__global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
+__device__ __forceinline__ void fuse_big_triangles_pair(const TriFuseArgs& a, const TriFuseArgs& b, uint32_t worker, uint32_t nworkers) {
+  const uint32_t na = min(*a.big_len, a.big_capacity), nb = min(*b.big_len, b.big_capacity);
+  for (uint32_t q = worker; q < na + nb; q += nworkers) {
+    const bool second = q >= na;
+    const uint32_t fi = second ? b.big_queue[q - na] : a.big_queue[q];
+    const TriFrag ra = a.frags[fi], rb = b.frags[fi];
+    if (second ? (rb.kind != 2 || ra.kind == 2) : (ra.kind != 2)) continue;
+    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;
+    for (int j = 0; j < 2; j++) {
+      const TriFrag rec = j ? rb : ra;
+      if (rec.kind == 0) continue;
+      TriFuseArgs v = a;                  // wave-uniform selection of the view
+      if (j) { v.idx = b.idx; v.probs = b.probs; v.weights = b.weights; v.H = b.H; v.W = b.W; }
+      int x1, y1;
+      if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
+      else { x1 = min((int)rec.x0 + 7, (int)v.W - 1); y1 = min((int)rec.y0 + 7, (int)v.H - 1); }
+      fuse_box<CT, KIND, EXACT>(v, f, rec.x0, rec.y0, x1, y1);
+    }
+  }
+}
+
+// NV = 1: one view (a).  NV = 2: views a then b of the same mesh into the same accumulator -- the 64-row block makes ONE
+// round trip for both, and the additions happen in the order two launches would have made them.
+template <int CT, int KIND, bool EXACT, int NV>
+__global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b) {
   const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
   constexpr int PB = CT <= 24 ? 2 : 1;        // pixels whose class vectors are in flight together
   constexpr int KV = (kWave * CT / 4 + kWave - 1) / kWave;   // float4 per lane of the 64-row block
   __shared__ __attribute__((aligned(16))) float srow[kWave * CT + 4];   // the wave's 64 accumulator rows
   const int l = threadIdx.x;
   if (blockIdx.x >= a.tri_blocks) {   // tail blocks: the queued big triangles
-    fuse_big_triangles<CT, KIND, EXACT>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
+    if (NV == 2) fuse_big_triangles_pair<CT, KIND, EXACT>(a, b, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
+    else fuse_big_triangles<CT, KIND, EXACT>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
     return;
   }
   const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
   const uint64_t f = f0 + l;
-  TriFrag rec;
-  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
-  if (f < a.F) rec = a.frags[f];
+  TriFrag rec[NV];
+#pragma unroll
+  for (int v = 0; v < NV; v++) { rec[v].x0 = 0; rec[v].y0 = 0; rec[v].kind = 0; rec[v].pad = 0; rec[v].mask = 0ull; }
+  if (f < a.F) {
+    rec[0] = a.frags[f];
+    if (NV == 2) rec[NV - 1] = b.frags[f];
+  }
+  const bool big = rec[0].kind == 2 || rec[NV - 1].kind == 2;   // this row belongs to a tail wave
   // Re-ordered mesh (renderer's position -> primitive id table): the id is what the index image holds and which row to
   // update; the 64 rows of a wave are then scattered, so every lane loads / stores its own row instead of the LDS block.
   const bool scattered = a.prim_id != nullptr;
   const uint32_t pid = (scattered && f < a.F) ? a.prim_id[f] : (uint32_t)f;
-  auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
+  auto pixel = [&](int v, int k) -> uint64_t {
+    return (uint64_t)(rec[v].x0 + (k >> 3)) * (v ? b.H : a.H) + rec[v].y0 + (k & 7);
+  };
 
   // ---- pass 1: which emitted fragments won the depth test?  n = pixels of this primitive in this view.
-  // Four candidates per lane are checked per round so that their index loads are in flight together.
-  unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
-  unsigned long long win = 0ull;
-  uint32_t n = 0;
-  while (__ballot(m != 0ull) != 0ull) {
-    int k[4];
-    uint32_t got[4];
+  // Four candidates per lane and view are checked per round so that their index loads are in flight together.
+  unsigned long long m[NV], win[NV];
+  uint32_t n[NV];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      k[j] = -1;
-      if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
-      got[j] = a.idx[k[j] >= 0 ? pixel(k[j]) : 0];   // unconditional (clamped) so that the four loads overlap
+  for (int v = 0; v < NV; v++) { m[v] = (rec[v].kind == 1 && !big) ? rec[v].mask : 0ull; win[v] = 0ull; n[v] = 0u; }
+  while (__ballot((m[0] | m[NV - 1]) != 0ull) != 0ull) {
+    int k[NV][4];
+    uint32_t got[NV][4];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const uint32_t* __restrict__ idx = v ? b.idx : a.idx;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        k[v][j] = -1;
+        if (m[v]) { k[v][j] = __ffsll((long long)m[v]) - 1; m[v] &= m[v] - 1ull; }
+        got[v][j] = idx[k[v][j] >= 0 ? pixel(v, k[v][j]) : 0];   // unconditional (clamped) so that the loads overlap
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (k[j] >= 0 && got[j] == pid) { n++; win |= 1ull << k[j]; }
+    for (int v = 0; v < NV; v++)
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (k[v][j] >= 0 && got[v][j] == pid) { n[v]++; win[v] |= 1ull << k[v][j]; }
   }
-  if (__ballot(win != 0ull) == 0ull) return;   // nothing of these 64 triangles is visible: rows untouched
+  const unsigned long long any_win = win[0] | win[NV - 1];
+  if (__ballot(any_win != 0ull) == 0ull) return;   // nothing of these 64 triangles is visible: rows untouched
 
   // ---- issue together: the wave's 64 accumulator rows (one contiguous block) and the first PB pixels'
   // class vectors of every lane
@@ -909,81 +957,86 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a) {
 #pragma unroll
     for (int q = 0; q < KV; q++) br[q] = b4[min(l + q * kWave, kWave * C / 4 - 1)];
   }
-  float w0 = 0.0f;
-  if (n) {
-    const float image_weight = 1.0f / ((float)n);                          // Mesh.h:100
-    const float pixel_w = 1.0f;                                            // :101
-    w0 = a.iew * image_weight + (1 - a.iew) * pixel_w;                     // :102
-  }
-  m = win;
   float accr[CT];
   bool rows_loaded = false;
-  while (__ballot(m != 0ull) != 0ull) {
-    float p[PB][CT];
-    float wt[PB];
-    bool have[PB];
 #pragma unroll
-    for (int j = 0; j < PB; j++) {
-      have[j] = m != 0ull;
-      int k = 0;
-      if (m) { k = __ffsll((long long)m) - 1; m &= m - 1ull; }
-      const uint64_t pix = have[j] ? pixel(k) : 0;
-      const float* __restrict__ pr = a.probs + pix * C;
-      load_row<CT, EXACT>(pr, C, p[j]);
-      wt[j] = a.weights ? a.weights[pix] : 1.0f;
+  for (int v = 0; v < NV; v++) {
+    const float* __restrict__ probs = v ? b.probs : a.probs;
+    const float* __restrict__ weights = v ? b.weights : a.weights;
+    float w0 = 0.0f;
+    if (n[v]) {
+      const float image_weight = 1.0f / ((float)n[v]);                       // Mesh.h:100
+      const float pixel_w = 1.0f;                                            // :101
+      w0 = a.iew * image_weight + (1 - a.iew) * pixel_w;                     // :102
     }
-    if (!rows_loaded && scattered) {
-      if (win) load_row<CT, EXACT>(a.acc + (uint64_t)pid * C, C, accr);
-      rows_loaded = true;
-    }
-    if (!rows_loaded) {
-      // park the block in LDS (flat, coalesced) and pick up this lane's row
-      if (nrows == kWave) {
-        f4* s4 = reinterpret_cast<f4*>(srow);
+    unsigned long long mm = win[v];
+    while (__ballot(mm != 0ull) != 0ull) {
+      float p[PB][CT];
+      float wt[PB];
+      bool have[PB];
 #pragma unroll
-        for (int q = 0; q < KV; q++)
-          if (l + q * kWave < kWave * C / 4) s4[l + q * kWave] = br[q];
-      } else {
-        for (int q = l; q < nrows * C; q += kWave) srow[q] = blk[q];
+      for (int j = 0; j < PB; j++) {
+        have[j] = mm != 0ull;
+        int k = 0;
+        if (mm) { k = __ffsll((long long)mm) - 1; mm &= mm - 1ull; }
+        const uint64_t pix = have[j] ? pixel(v, k) : 0;
+        const float* __restrict__ pr = probs + pix * C;
+        load_row<CT, EXACT>(pr, C, p[j]);
+        wt[j] = weights ? weights[pix] : 1.0f;
       }
-      wave_sync();
+      if (!rows_loaded && scattered) {
+        if (any_win) load_row<CT, EXACT>(a.acc + (uint64_t)pid * C, C, accr);
+        rows_loaded = true;
+      }
+      if (!rows_loaded) {
+        // park the block in LDS (flat, coalesced) and pick up this lane's row
+        if (nrows == kWave) {
+          f4* s4 = reinterpret_cast<f4*>(srow);
 #pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = srow[l * C + c];
-      rows_loaded = true;
-    }
-    // Mesh.h:94-106 for this primitive's pixels, in image order (x, then y)
-#pragma unroll
-    for (int j = 0; j < PB; j++) {
-      float sum = 0.0f;
-#pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[j][c];                      // tt::sum, sequential float32
-      if (have[j] && sum > 0.5f) {                                          // :98
-        const float w = w0 * wt[j];                                         // :103
-        if (KIND == SMESH_AGG_SUMMAX) {
-          int am = 0;
-          float best = p[j][0];   // (not p[j][am]: a run-time register index would go through scratch)
-#pragma unroll
-          for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[j][c] > best) { best = p[j][c]; am = c; }
-#pragma unroll
-          for (int c = 0; c < CT; c++) if (EXACT || c < C) if (c == am) accr[c] = accr[c] + p[j][c] * w;
+          for (int q = 0; q < KV; q++)
+            if (l + q * kWave < kWave * C / 4) s4[l + q * kWave] = br[q];
         } else {
+          for (int q = l; q < nrows * C; q += kWave) srow[q] = blk[q];
+        }
+        wave_sync();
 #pragma unroll
-          for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = accr[c] + contribution<KIND>(p[j][c], w);
+        for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = srow[l * C + c];
+        rows_loaded = true;
+      }
+      // Mesh.h:94-106 for this primitive's pixels, in image order (x, then y)
+#pragma unroll
+      for (int j = 0; j < PB; j++) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[j][c];                      // tt::sum, sequential float32
+        if (have[j] && sum > 0.5f) {                                          // :98
+          const float w = w0 * wt[j];                                         // :103
+          if (KIND == SMESH_AGG_SUMMAX) {
+            int am = 0;
+            float best = p[j][0];   // (not p[j][am]: a run-time register index would go through scratch)
+#pragma unroll
+            for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[j][c] > best) { best = p[j][c]; am = c; }
+#pragma unroll
+            for (int c = 0; c < CT; c++) if (EXACT || c < C) if (c == am) accr[c] = accr[c] + p[j][c] * w;
+          } else {
+#pragma unroll
+            for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = accr[c] + contribution<KIND>(p[j][c], w);
+          }
         }
       }
     }
   }
   if (scattered) {
-    if (win) {
+    if (any_win) {
 #pragma unroll
       for (int c = 0; c < CT; c++) if (EXACT || c < C) a.acc[(uint64_t)pid * C + c] = accr[c];
     }
     return;
   }
-  if (__ballot(rec.kind == 2) != 0ull) {
+  if (__ballot(big) != 0ull) {
     // Some of these 64 rows belong to big triangles, which the tail blocks of this launch update concurrently:
     // writing the whole block back would overwrite their sums.  Every other lane stores its own row.
-    if (rec.kind != 2 && f < a.F) {
+    if (!big && f < a.F) {
 #pragma unroll
       for (int c = 0; c < CT; c++) if (EXACT || c < C) blk[l * C + c] = accr[c];
     }
@@ -1900,20 +1953,29 @@ const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordere
   return "k_fuse_tri_any";
 }
 
-int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* prim_id,
-                                    const uint32_t* big_queue, const uint32_t* big_len, uint32_t big_capacity,
-                                    const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t W, uint64_t H) {
+bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a) { return a->C <= (uint32_t)kFuseTriMaxC; }
+
+// `nviews` = 1, or 2 (smesh_aggregator_can_fuse_pair): views[0] then views[1] of the same renderer in one launch.
+int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
+                                    const RenderedView* views, int nviews) {
   DeviceCtx* ctx = a->ctx;
   hipStream_t st = ctx->stream;
   if (F == 0) return SMESH_OK;
-  const uint64_t N = W * H;
-  TriFuseArgs t;
-  t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.F = F; t.C = a->C;
-  t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
-  t.tri_blocks = (uint32_t)div_up(F, kWave);
-  { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; t.dbg = fdbg; }
-  t.tex_first = nullptr; t.tex_res = nullptr; t.count = nullptr;
-  t.prim_id = prim_id;
+  if (nviews < 1 || nviews > 2 || (nviews == 2 && !smesh_aggregator_can_fuse_pair(a)))
+    return fail(SMESH_ERR_INVALID, "fuse_triangles: unsupported view count");
+  const uint64_t N = views[0].W * views[0].H;
+  TriFuseArgs t, tb;
+  for (int v = 0; v < 2; v++) {
+    const RenderedView& rv = views[v < nviews ? v : 0];
+    TriFuseArgs& x = v ? tb : t;
+    x.frags = rv.frags; x.idx = rv.idx; x.probs = rv.probs; x.weights = rv.weights; x.acc = a->acc; x.F = F; x.C = a->C;
+    x.W = (uint32_t)rv.W; x.H = (uint32_t)rv.H; x.iew = a->iew; x.big_queue = rv.big_queue; x.big_len = rv.big_len;
+    x.big_capacity = big_capacity;
+    x.tri_blocks = (uint32_t)div_up(F, kWave);
+    { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; x.dbg = fdbg; }
+    x.tex_first = nullptr; x.tex_res = nullptr; x.count = nullptr;
+    x.prim_id = prim_id;
+  }
   // k_fuse_tri (row in registers; the wave's 64-row block staged through LDS unless the mesh was re-ordered) takes C <= 48: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 48 for the rest
   // (tri_ct 41 = the run-time instance with 40 slots).
   int tri_ct = 0;
@@ -1960,18 +2022,18 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, u
     }
 #define SMESH_FT(K)                                                                           \
     switch (tri_ct) {                                                                         \
-      case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K, true>), grid, block, 0, st, t); break;     \
-      case 13: hipLaunchKernelGGL((k_fuse_tri<13, K, true>), grid, block, 0, st, t); break;    \
-      case 19: hipLaunchKernelGGL((k_fuse_tri<19, K, true>), grid, block, 0, st, t); break;    \
-      case 20: hipLaunchKernelGGL((k_fuse_tri<20, K, true>), grid, block, 0, st, t); break;    \
-      case 21: hipLaunchKernelGGL((k_fuse_tri<21, K, true>), grid, block, 0, st, t); break;    \
-      case 40: hipLaunchKernelGGL((k_fuse_tri<40, K, true>), grid, block, 0, st, t); break;    \
-      case 8:  hipLaunchKernelGGL((k_fuse_tri<8, K, false>), grid, block, 0, st, t); break;    \
-      case 16: hipLaunchKernelGGL((k_fuse_tri<16, K, false>), grid, block, 0, st, t); break;   \
-      case 24: hipLaunchKernelGGL((k_fuse_tri<24, K, false>), grid, block, 0, st, t); break;   \
-      case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false>), grid, block, 0, st, t); break;   \
-      case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false>), grid, block, 0, st, t); break;   \
-      case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false>), grid, block, 0, st, t); break;   \
+      case 5:  if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<5, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<5, K, true, 1>), grid, block, 0, st, t, t); break;     \
+      case 13: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<13, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<13, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 19: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<19, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<19, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 20: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<20, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<20, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 21: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<21, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<21, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 40: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<40, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<40, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 8:  if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<8, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<8, K, false, 1>), grid, block, 0, st, t, t); break;    \
+      case 16: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<16, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<16, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 24: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<24, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<24, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 32: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<32, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<32, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 41: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<40, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<40, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 48: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<48, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, t); break;   \
       default:                                                                                \
         if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                               \
         hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, pw, amax);             \

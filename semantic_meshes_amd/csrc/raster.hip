@@ -38,9 +38,9 @@ struct smesh_aggregator;
 int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_idx, const float* d_probs,
                                        const float* d_w, uint64_t W, uint64_t H);
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
-int smesh_aggregator_fuse_triangles(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* prim_id,
-                                    const uint32_t* big_queue, const uint32_t* big_len, uint32_t big_capacity,
-                                    const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t W, uint64_t H);
+bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a);
+int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
+                                    const RenderedView* views, int nviews);
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
 bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P);
 int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
@@ -1056,8 +1056,8 @@ static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const
   }
   if (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) {
     // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
-    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->side[slot].frags, r->F, r->prim_id, r->side[slot].big_queue,
-                                              r->side[slot].big_count, r->big_capacity, d_idx, d_probs, d_w, W, H));
+    const RenderedView rv{r->side[slot].frags, r->side[slot].big_queue, r->side[slot].big_count, d_idx, d_probs, d_w, W, H};
+    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, &rv, 1));
     g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
   } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
     // texel primitives: a triangle owns its texel rows, its lane read-modify-writes them without atomics
@@ -1322,6 +1322,64 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   SMESH_TRY(fuse_rendered(r, a, slot, d_idx, probs, weights, memkind, W, H));
   if (pipelined) SMESH_HIP(hipEventRecord(r->ev_consumed[slot], ctx->stream));
   r->fused_seq++;
+  return SMESH_OK;
+}
+
+// A batch of views: smesh_fuse_view for each of them, in order -- except that two consecutive views of a triangle renderer
+// with device-resident class vectors are fused by ONE launch (k_fuse_tri<.., 2>: every 64-row accumulator block makes one
+// round trip for both views; same additions in the same order as two calls).  Asynchronous like smesh_fuse_view.
+int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cams, uint64_t n,
+                     const float* const* probs, const float* const* weights, int memkind) {
+  if (!r || !a || (n && (!cams || !probs))) return fail(SMESH_ERR_INVALID, "NULL argument");
+  for (uint64_t i = 0; i < n; i++) {
+    SMESH_TRY(check_camera(&cams[i]));
+    if (!probs[i]) return fail(SMESH_ERR_INVALID, "NULL probs image");
+  }
+  DeviceCtx* ctx = r->ctx;
+  if (smesh_aggregator_ctx(a) != ctx) return fail(SMESH_ERR_INVALID, "renderer and aggregator live on different devices");
+  static const bool pairs_off = getenv("SMESH_FUSE_PAIRS") && atoi(getenv("SMESH_FUSE_PAIRS")) == 0;
+  bool pairable;
+  {
+    std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
+    pairable = !pairs_off && memkind == SMESH_MEM_DEVICE && !r->texels && r->F != 0 && smesh_aggregator_can_fuse_triangles(a, r->F) &&
+               smesh_aggregator_can_fuse_pair(a);
+  }
+  uint64_t i = 0;
+  while (i < n) {
+    if (!pairable || i + 1 >= n) {
+      SMESH_TRY(smesh_fuse_view(r, a, &cams[i], probs[i], weights ? weights[i] : nullptr, memkind));
+      i += 1;
+      continue;
+    }
+    std::lock_guard<std::mutex> g(r->mu);
+    std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    SMESH_HIP(hipSetDevice(ctx->device));
+    if (r->raster_pending) {
+      SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
+      r->raster_pending = false;
+    }
+    SMESH_HIP(alloc_side(r, 1));
+    r->main_pending = true;   // the renderer's scratch is in use on the main stream
+    RenderedView rv[2];
+    for (int v = 0; v < 2; v++) {
+      const smesh_camera_t* cam = &cams[i + v];
+      const uint64_t W = cam->width, H = cam->height, N = W * H;
+      if (r->fused[v].bytes < N * 8) {
+        SMESH_HIP(hipStreamSynchronize(ctx->stream));   // growing a slot frees the old buffer: nothing may still be reading it
+        SMESH_TRY(r->fused[v].reserve(N * 8));
+      }
+      uint32_t* d_idx = static_cast<uint32_t*>(r->fused[v].ptr);
+      r->last_idx[v] = nullptr;   // the records of a render_device() on this side are being overwritten
+      SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, ctx->stream, v));
+      rv[v] = RenderedView{r->side[v].frags, r->side[v].big_queue, r->side[v].big_count, d_idx, probs[i + v],
+                           weights ? weights[i + v] : nullptr, W, H};
+    }
+    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, 2));
+    g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
+    r->fused_seq += 2;
+    i += 2;
+  }
   return SMESH_OK;
 }
 

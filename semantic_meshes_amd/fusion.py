@@ -148,6 +148,43 @@ class _MeshAggregator:
             wp = ctypes.c_void_p(wp_)
         _lib.check(_lib.lib().smesh_fuse_view(renderer._h, self._h, ctypes.byref(camera._pod), ctypes.c_void_p(pp), wp, pmem))
 
+    def fuse_views(self, renderer, cameras, probs_images, weights_images=None):
+        """`fuse_view` for a whole batch, in order (the loop of colorize_cityscapes_mesh.py:54-67 as one call).  With a
+        triangle renderer and device-resident images the library fuses consecutive views two per launch: each accumulator
+        row is read and written once for both.  All images must live in the same memory (host or device)."""
+        cameras, probs_images = list(cameras), list(probs_images)
+        n = len(cameras)
+        if len(probs_images) != n or (weights_images is not None and len(weights_images) != n):
+            raise ValueError("fuse_views needs one probs image (and one weights image or None) per camera")
+        if n == 0:
+            return
+        pods = (_lib.CameraPOD * n)()
+        pptr, wptr = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+        keep, mem = [], None
+        for i, cam in enumerate(cameras):
+            W, H = cam.resolution
+            pods[i] = cam._pod
+            pp, pmem, pshape, pdt, pstr, k1 = describe(probs_images[i], 3, "probs image")
+            if tuple(pshape) != (W, H, self.classes) or pdt != np.float32:
+                raise ValueError("probs image %d must be float32 (W,H,C) = %s" % (i, (W, H, self.classes)))
+            if pstr != (H * self.classes, self.classes, 1):
+                raise ValueError("fuse_views needs contiguous (W,H,C) probs images")
+            if mem is None:
+                mem = pmem
+            if pmem != mem:
+                raise ValueError("fuse_views: all images must live in the same memory (host or device)")
+            pptr[i] = pp
+            keep.append(k1)
+            w = None if weights_images is None else weights_images[i]
+            if w is not None:
+                wp_, wmem, wshape, wdt, wstr, k2 = describe(w, 2, "weights image")
+                if tuple(wshape) != (W, H) or wdt != np.float32 or wstr != (H, 1) or wmem != mem:
+                    raise ValueError("weights image %d must be contiguous float32 (W,H) in the same memory as probs" % i)
+                wptr[i] = wp_
+                keep.append(k2)
+        _lib.check(_lib.lib().smesh_fuse_views(renderer._h, self._h, pods, n, pptr,
+                                               None if weights_images is None else wptr, mem))
+
 
 class ModelRenderer:
     """Fused annotations gathered back to an image: `ModelAggregator::renderer()` + `ModelRenderer::render`

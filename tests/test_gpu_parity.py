@@ -909,3 +909,107 @@ def test_mul_aggregator_edge_values(sm, oracle):
         assert ((want == 0) == (got == 0)).mean() > 0.999                # the same classes are wiped out by -inf
     finally:
         oracle.set_accum_double(False)
+
+
+# ---- smesh_fuse_views: a batch of views, consecutive views fused two per launch ----------------------------------
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C", [5, 19, 7, 40, 48])
+def test_fuse_views_pairs_equal_single_calls_bit_for_bit(sm, oracle, kind, C):
+    """fuse_views == fuse_view per view, in order: with small triangles only the two-views-per-launch kernel makes the
+    same float32 additions in the same order, so the raw accumulators agree bit for bit (and with the float32 oracle for
+    Sum / Summax).  Five views: two pairs and a single; weights on every view."""
+    import os
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(120, 60, 320, 240, views=3)      # ~1.5 px triangles: all bounding boxes <= 8 x 8
+    cams = cams + cams[:2]
+    P = len(mesh.faces)
+    rng = np.random.default_rng(100 + C)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    batch, single = sm.fusion.MeshAggregator(P, C, kind, 0.5), sm.fusion.MeshAggregator(P, C, kind, 0.5)
+    oagg = oracle.OracleAggregator(P, C, kind, 0.5)
+    probs = [random_probs(rng, *cam.resolution, C) for cam in cams]
+    if kind == "mul":
+        probs = [np.maximum(p, 1e-3).astype(np.float32) for p in probs]
+    weights = [rng.random(cam.resolution, dtype=np.float32) for cam in cams]
+    dp, dw = [to_device(p) for p in probs], [to_device(w) for w in weights]
+    batch.fuse_views(r, cams, dp, dw)
+    for k, cam in enumerate(cams):
+        single.fuse_view(r, cam, dp[k], dw[k])
+        oagg.add(o.render(cam)[0], probs[k], weights[k])
+    if os.environ.get("SMESH_FUSE") != "strip":
+        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri"
+        np.testing.assert_array_equal(batch.get_raw().view(np.uint32), single.get_raw().view(np.uint32))
+        if kind != "mul":
+            np.testing.assert_array_equal(batch.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+    assert_fused_close(batch.get(), oagg.get(), rtol=1e-5 if kind != "mul" else 3e-3)
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax"])
+def test_fuse_views_mixed_triangle_sizes_and_image_sizes(sm, oracle, kind):
+    """Pairs in which a triangle is small in one view and big (bounding box over 8 x 8) in the other, plus one huge
+    triangle: those rows are handed to one tail wave for both views.  The two views of a pair differ in resolution."""
+    from semantic_meshes_amd import synth
+    from semantic_meshes_amd.device import to_device
+    mesh = synth.grid_mesh(100, 50)
+    extra_v = np.array([[-6, -4, -0.5], [6, -4, -0.5], [0, 5, -0.5]], np.float32)
+    verts = np.concatenate([mesh.vertices, extra_v])
+    faces = np.concatenate([mesh.faces, [[len(mesh.vertices), len(mesh.vertices) + 1, len(mesh.vertices) + 2]]]).astype(np.int32)
+    big = sm.data.Mesh(verts, faces)
+    P, C = len(faces), 19
+    # 8-12 px triangles at 640x480 (both sides of the limit), ~3 px at 320x240, ~30 px at 1280x960
+    cams = [synth.ring_camera(k, 6, w, h) for k, (w, h) in enumerate([(640, 480), (320, 240), (1280, 960), (640, 480),
+                                                                        (320, 240), (640, 480)])]
+    rng = np.random.default_rng(7)
+    r = sm.render.triangles(big)
+    o = oracle.OracleRenderer(verts, faces)
+    agg = sm.fusion.MeshAggregator(P, C, kind)
+    probs = [random_probs(rng, *cam.resolution, C) for cam in cams]
+    agg.fuse_views(r, cams, [to_device(p) for p in probs])
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind)
+        for k, cam in enumerate(cams):
+            oagg.add(o.render(cam)[0], probs[k])
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    finally:
+        oracle.set_accum_double(False)
+
+
+def test_fuse_views_shuffled_faces_and_fallbacks(sm, oracle):
+    """Re-ordered mesh (per-lane rows) in pairs; host images, class counts beyond k_fuse_tri and texel renderers take the
+    one-view-at-a-time path behind the same call."""
+    import os
+    from semantic_meshes_amd.device import to_device
+    base, cams = small_scene(120, 60, 320, 240, views=4)
+    rng = np.random.default_rng(3)
+    faces = np.ascontiguousarray(base.faces[rng.permutation(len(base.faces))])
+    mesh = sm.data.Mesh(base.vertices, faces)
+    P = len(faces)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(base.vertices, faces)
+    oidx = [o.render(cam)[0] for cam in cams]
+    for C, on_device in ((19, True), (19, False), (64, True)):
+        agg, oagg = sm.fusion.MeshAggregator(P, C, "sum", 0.5), oracle.OracleAggregator(P, C, "sum", 0.5)
+        probs = [random_probs(rng, *cam.resolution, C) for cam in cams]
+        agg.fuse_views(r, cams, [to_device(p) for p in probs] if on_device else probs)
+        for k in range(len(cams)):
+            oagg.add(oidx[k], probs[k])
+        if os.environ.get("SMESH_FUSE") != "strip":
+            np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    # texel renderer
+    tmesh, tcams = small_scene(60, 30, 330, 250, views=3)
+    tr = sm.render.texels(tmesh, tcams, 0.6)
+    to = oracle.OracleRenderer(tmesh.vertices, tmesh.faces, tcams, 0.6)
+    TP = tr.getPrimitivesNum()
+    agg, oagg = sm.fusion.MeshAggregator(TP, 4), oracle.OracleAggregator(TP, 4)
+    probs = [random_probs(rng, *cam.resolution, 4) for cam in tcams]
+    agg.fuse_views(tr, tcams, [to_device(p) for p in probs])
+    for k, cam in enumerate(tcams):
+        oagg.add(to.render(cam)[0], probs[k])
+    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    # argument checks
+    with pytest.raises(ValueError):
+        agg.fuse_views(tr, tcams, probs[:2])
+    agg.fuse_views(tr, [], [])
