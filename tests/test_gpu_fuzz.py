@@ -124,3 +124,45 @@ def test_random_soup_forced_reorder(seed):
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_fuzz.py"), "-q", "-x", "-m", "gpu",
                           "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_soup_fuse_views_against_oracle(sm, oracle, seed):
+    """fuse_views on soups: the two views of a pair see every triangle at unrelated sizes (small in one, big or huge in the
+    other, culled in either), at different resolutions, with and without weights; device-resident images (pairs) and an odd
+    number of views."""
+    import types
+    from semantic_meshes_amd.device import to_device
+    rng = np.random.default_rng(9000 + seed)
+    nfaces = int(rng.choice([50, 400, 3000, 6000]))
+    spread = float(rng.choice([0.004, 0.02, 0.08, 0.4]))
+    verts, faces = _soup(rng, 0, nfaces, spread)
+    C = int(rng.choice([1, 3, 5, 19, 21, 40, 47, 48]))                # all within k_fuse_tri: pairs
+    kind = str(rng.choice(["sum", "summax", "mul"]))
+    iew = float(rng.choice([0.0, 0.5, 1.0]))
+    mesh = types.SimpleNamespace(vertices=verts, faces=faces)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(verts, faces)
+    P = len(faces)
+    nviews = int(rng.choice([2, 3, 5]))
+    cams, probs, weights = [], [], []
+    for v in range(nviews):
+        W, H = int(rng.choice([37, 160, 333])), int(rng.choice([29, 120, 257]))
+        cams.append(_camera(sm, rng, W, H))
+        p = random_probs(rng, W, H, C, zero_fraction=0.1)
+        if kind == "mul":
+            p = np.where(p.sum(-1, keepdims=True) > 0, np.maximum(p, 1e-3), 0).astype(np.float32)
+        probs.append(p)
+        weights.append(rng.random((W, H), dtype=np.float32) if rng.random() < 0.5 else None)
+    use_w = any(w is not None for w in weights)
+    agg = sm.fusion.MeshAggregator(P, C, kind, iew)
+    agg.fuse_views(r, cams, [to_device(p) for p in probs],
+                   [None if w is None else to_device(w) for w in weights] if use_w else None)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, iew)
+        for v in range(nviews):
+            oagg.add(o.render(cams[v])[0], probs[v], weights[v])
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5 if kind != "mul" else 5e-3, atol=1e-6)
+    finally:
+        oracle.set_accum_double(False)
