@@ -71,9 +71,8 @@ struct CameraArgs {
 
 // ---- vertex stage: float32 rigid transform, double pinhole projection (render/Camera.h:9-13) --------
 // Also opens the render: empties the big-triangle queue (its length stays readable until the next render).
-__global__ void k_project_vertices(const float* __restrict__ verts, uint64_t V, CameraArgs cam,
-                                   ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void project_vertex(const float* __restrict__ verts, uint64_t V, const CameraArgs& cam,
+                                               ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count, const uint64_t i) {
   if (i == 0) { big_count[0] = 0u; big_count[2] = 0u; }
   if (i >= V) return;
   const float X = verts[3 * i + 0], Y = verts[3 * i + 1], Z = verts[3 * i + 2];
@@ -91,6 +90,20 @@ __global__ void k_project_vertices(const float* __restrict__ verts, uint64_t V, 
     }
   }
   sv[i] = s;
+}
+
+__global__ void k_project_vertices(const float* __restrict__ verts, uint64_t V, CameraArgs cam,
+                                   ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count) {
+  project_vertex(verts, V, cam, sv, big_count, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Two views of the same mesh in one launch (smesh_fuse_views): blocks [0, blocks_a) project for the first camera.
+__global__ void k_project_vertices2(const float* __restrict__ verts, uint64_t V, CameraArgs cam_a, CameraArgs cam_b,
+                                    ScreenVertex* __restrict__ sv_a, ScreenVertex* __restrict__ sv_b,
+                                    uint32_t* __restrict__ big_count_a, uint32_t* __restrict__ big_count_b, uint32_t blocks_a) {
+  const bool first = blockIdx.x < blocks_a;
+  project_vertex(verts, V, first ? cam_a : cam_b, first ? sv_a : sv_b, first ? big_count_a : big_count_b,
+                 (uint64_t)(blockIdx.x - (first ? 0u : blocks_a)) * blockDim.x + threadIdx.x);
 }
 
 // ---- triangle setup --------------------------------------------------------------------------------
@@ -381,11 +394,10 @@ __device__ __forceinline__ double flip_sign(double v, uint32_t hi_mask) {
 // reservation in the (at most 2 x 2) tiles the box overlaps, then depth per covered sample and the queue stores.
 // The edge functions are shade()'s, regrouped: s * (sign * (a - b)) is +-(a - b) exactly, so the two sign
 // multiplications become one XOR of the sign bit, and b = dy * (px - lx) is hoisted out of the row loop.
-__global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
+__device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint64_t wave_id) {
   // a.tpw triangles per wave (64 for large meshes; fewer for small ones, so that the cooperative medium-triangle
   // loop below has enough waves to spread over the chip)
   const int lane = threadIdx.x & 63;
-  const uint64_t wave_id = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const uint64_t wave0 = wave_id * a.tpw;   // first triangle of this wave
   const uint32_t sub = (uint32_t)wave_id & (kQSub - 1);   // this wave's sub-queue in every tile
   const uint64_t f = lane < (int)a.tpw ? wave0 + lane : a.F;
@@ -577,16 +589,27 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
+  raster_frag_wave(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+}
+
+// Two views in one launch: blocks [0, blocks_a) rasterise the first view.
+__global__ __launch_bounds__(256) void k_raster_frag2(RasterArgs a, RasterArgs b, uint32_t blocks_a) {
+  const bool first = blockIdx.x < blocks_a;
+  const RasterArgs& v = first ? a : b;   // block-uniform
+  raster_frag_wave(v, ((uint64_t)(blockIdx.x - (first ? 0u : blocks_a)) * blockDim.x + threadIdx.x) >> 6);
+}
+
 // One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
 // > 8 x 8: the workgroup scans their queue, keeps those whose box overlaps the tile and shades the overlap, 256
 // samples at a time), then the output planes are written once.  "Big" here means larger than kMedium x kMedium.
-__global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out) {
+__device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out,
+                                                   const uint32_t tile) {
   __shared__ unsigned long long skeys[kQPixels];
   __shared__ uint32_t s_hits[256];
   __shared__ uint32_t s_nhits;
   const FragQueues& q = a.q;
   const int t = threadIdx.x;
-  const uint32_t tile = blockIdx.x;
   const uint32_t W = a.W, H = a.H;
   const uint32_t tx = tile / q.tiles_y, ty = tile - tx * q.tiles_y;
   const uint32_t x0 = tx * kQW, y0 = ty * kQH;
@@ -665,6 +688,18 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
   if (t == 0) q.flag[tile] = 0u;
 }
 
+__global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out) {
+  tile_resolve_block(a, idx_out, depth_out, blockIdx.x);
+}
+
+// Two views in one launch: blocks [0, tiles_a) are the tiles of the first view.
+__global__ __launch_bounds__(256) void k_tile_resolve2(RasterArgs a, RasterArgs b, uint32_t* __restrict__ idx_a, uint32_t* __restrict__ idx_b,
+                                                        uint32_t tiles_a) {
+  const bool first = blockIdx.x < tiles_a;
+  const RasterArgs& v = first ? a : b;   // block-uniform
+  tile_resolve_block(v, first ? idx_a : idx_b, nullptr, blockIdx.x - (first ? 0u : tiles_a));
+}
+
 // Split the key image into the two output planes and re-arm the keys for the next render.
 __global__ void k_resolve(unsigned long long* __restrict__ keys, uint32_t* __restrict__ idx, float* __restrict__ depth,
                           uint32_t W, uint32_t H) {
@@ -737,16 +772,22 @@ struct smesh_renderer {
   uint64_t V = 0, F = 0, num_primitives = 0;
   float* verts = nullptr;          // float32[V*3]
   int32_t* faces = nullptr;        // int32[F*3]
-  ScreenVertex* sv = nullptr;      // per-view projected vertices [V]
   uint32_t* prim_id = nullptr;     // [F] primitive id per triangle position, when the triangles were re-ordered (else null)
-  uint32_t* huge_queue = nullptr;  // [big_capacity] triangles larger than kMedium x kMedium of the render in progress
+  // What a render in flight needs besides the per-triangle records.  Two sets: smesh_fuse_views rasterises two views in the
+  // same launches (the second set is allocated on first use); every other entry point uses set 0.
+  struct ViewScratch {
+    ScreenVertex* sv = nullptr;      // projected vertices [V]
+    uint32_t* huge_queue = nullptr;  // [big_capacity] triangles larger than kMedium x kMedium
+    unsigned long long* keys = nullptr;   // global key image (direct path; overflow of the fragment queues)
+    uint64_t keys_pixels = 0;
+    FragQueues fq;                   // fragment-queue path: per-tile queues, sized for the largest image seen
+    uint64_t fq_tiles = 0;
+  } vs[2];
   bool texels = false;
   uint32_t* tex_res = nullptr;     // [F]
   uint32_t* tex_first = nullptr;   // [F]
   std::vector<int32_t> h_faces;    // texel renderers: re-ordered faces
   std::vector<uint32_t> h_res, h_first;
-  unsigned long long* keys = nullptr;
-  uint64_t keys_pixels = 0;
   // What a render leaves behind for the triangle-order fusion.  Two sets: with SMESH_FUSE_PIPELINE the rasteriser of
   // view k+1 (raster stream) fills one while the fusion of view k (main stream) still reads the other.
   struct Side {
@@ -755,8 +796,6 @@ struct smesh_renderer {
     TriFrag* frags = nullptr;        // [F] per-triangle fragment records
   } side[2];
   uint32_t big_capacity = 0;
-  FragQueues fq;                   // fragment-queue path: per-tile queues, sized for the largest image seen
-  uint64_t fq_tiles = 0;
   std::vector<ImagePair> images;   // pooled output planes
   Scratch own_idx;                 // for the host-output entry point
   // smesh_fuse_view pipeline: two index/depth slots, rasterised on ctx->raster_stream
@@ -776,15 +815,15 @@ struct smesh_renderer {
 
 namespace {
 
-int ensure_keys(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st) {
+int ensure_keys(smesh_renderer::ViewScratch& vs, uint64_t W, uint64_t H, hipStream_t st) {
   const uint64_t N = div_up(W, 4) * div_up(H, 4) * 16;   // 4 x 4 blocked layout, padded
-  if (N <= r->keys_pixels) return SMESH_OK;
-  if (r->keys) SMESH_HIP(hipFree(r->keys));
-  r->keys = nullptr;
-  r->keys_pixels = 0;
-  SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&r->keys), N * 8));
-  r->keys_pixels = N;
-  hipLaunchKernelGGL(k_fill_keys, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, N);
+  if (N <= vs.keys_pixels) return SMESH_OK;
+  if (vs.keys) SMESH_HIP(hipFree(vs.keys));
+  vs.keys = nullptr;
+  vs.keys_pixels = 0;
+  SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&vs.keys), N * 8));
+  vs.keys_pixels = N;
+  hipLaunchKernelGGL(k_fill_keys, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, vs.keys, N);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
@@ -805,7 +844,7 @@ RasterPath raster_path() {
 // (SMESH_FRAG_CAP overrides the capacity of a sub-queue; fragments beyond it fall back to the global key image), shrunk
 // if the whole set would exceed 8 GiB.  Returns false (queues unusable -> direct path) for images with so many tiles
 // that a sub-queue would drop under 256 slots.
-bool ensure_queues(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st, int* status) {
+bool ensure_queues(smesh_renderer* r, smesh_renderer::ViewScratch& vs, uint64_t W, uint64_t H, hipStream_t st, int* status) {
   *status = SMESH_OK;
   const uint64_t tiles_x = div_up(W, kQW), tiles_y = div_up(H, kQH), ntiles = tiles_x * tiles_y;
   uint64_t cap = 16ull * kQPixels / kQSub;   // per sub-queue
@@ -815,25 +854,50 @@ bool ensure_queues(smesh_renderer* r, uint64_t W, uint64_t H, hipStream_t st, in
     if (ntiles * kQSub * cap * 10 > budget) cap = budget / (ntiles * kQSub * 10);
     if (cap < 256) return false;
   }
-  if (ntiles > r->fq_tiles || (uint32_t)cap != r->fq.cap) {
+  if (ntiles > vs.fq_tiles || (uint32_t)cap != vs.fq.cap) {
     (void)hipStreamSynchronize(r->ctx->stream);
     (void)hipStreamSynchronize(r->ctx->raster_stream);
-    for (void* p : {(void*)r->fq.key, (void*)r->fq.pix, (void*)r->fq.count, (void*)r->fq.flag})
+    for (void* p : {(void*)vs.fq.key, (void*)vs.fq.pix, (void*)vs.fq.count, (void*)vs.fq.flag})
       if (p) (void)hipFree(p);
-    r->fq = FragQueues();
-    r->fq_tiles = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->fq.key), ntiles * kQSub * cap * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.pix), ntiles * kQSub * cap * 2);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.count), ntiles * kQSub * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->fq.flag), ntiles * 4);
-    if (e == hipSuccess) e = hipMemsetAsync(r->fq.count, 0, ntiles * kQSub * 4, st);
-    if (e == hipSuccess) e = hipMemsetAsync(r->fq.flag, 0, ntiles * 4, st);
+    vs.fq = FragQueues();
+    vs.fq_tiles = 0;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&vs.fq.key), ntiles * kQSub * cap * 8);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&vs.fq.pix), ntiles * kQSub * cap * 2);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&vs.fq.count), ntiles * kQSub * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&vs.fq.flag), ntiles * 4);
+    if (e == hipSuccess) e = hipMemsetAsync(vs.fq.count, 0, ntiles * kQSub * 4, st);
+    if (e == hipSuccess) e = hipMemsetAsync(vs.fq.flag, 0, ntiles * 4, st);
     if (e != hipSuccess) { *status = fail_hip(e, "fragment queue allocation", __FILE__, __LINE__); return false; }
-    r->fq.cap = (uint32_t)cap;
-    r->fq_tiles = ntiles;
+    vs.fq.cap = (uint32_t)cap;
+    vs.fq_tiles = ntiles;
   }
-  r->fq.tiles_y = (uint32_t)tiles_y;
+  vs.fq.tiles_y = (uint32_t)tiles_y;
   return true;
+}
+
+CameraArgs camera_args(const smesh_camera_t* cam) {
+  CameraArgs ca;
+  memcpy(ca.R, cam->rotation, sizeof ca.R);
+  memcpy(ca.t, cam->translation, sizeof ca.t);
+  ca.fx = cam->focal[0]; ca.fy = cam->focal[1]; ca.cx = cam->principal[0]; ca.cy = cam->principal[1];
+  ca.W = (uint32_t)cam->width; ca.H = (uint32_t)cam->height;
+  return ca;
+}
+
+// Kernel arguments of a render of a W x H view with scratch set `vs`, leaving its records in side `side` (queues: a.q).
+RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int side, uint64_t W, uint64_t H) {
+  RasterArgs a;
+  a.faces = r->faces; a.sv = vs.sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
+  a.prim_id = r->prim_id;
+  a.keys = vs.keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
+  a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
+  a.huge_queue = vs.huge_queue;
+  a.frags = r->side[side].frags;
+  { static const int rdbg = getenv("SMESH_RDBG") ? atoi(getenv("SMESH_RDBG")) : 0; a.dbg = rdbg; }
+  a.q = FragQueues();
+  a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~2048 waves
+  while (a.tpw > 1 && r->F / a.tpw < 2048) a.tpw >>= 1;
+  return a;
 }
 
 // Rasterise into caller-provided device planes (d_depth may be null: index plane only).
@@ -850,35 +914,23 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     r->main_pending = true;
   }
   const uint64_t W = cam->width, H = cam->height, N = W * H;
-  SMESH_TRY(ensure_keys(r, W, H, st));
+  smesh_renderer::ViewScratch& vs = r->vs[0];
+  SMESH_TRY(ensure_keys(vs, W, H, st));
   ProfScope prof(ctx, SMESH_PROF_RASTER, st);
-  CameraArgs ca;
-  memcpy(ca.R, cam->rotation, sizeof ca.R);
-  memcpy(ca.t, cam->translation, sizeof ca.t);
-  ca.fx = cam->focal[0]; ca.fy = cam->focal[1]; ca.cx = cam->principal[0]; ca.cy = cam->principal[1];
-  ca.W = (uint32_t)W; ca.H = (uint32_t)H;
+  const CameraArgs ca = camera_args(cam);
   if (r->V) {
-    hipLaunchKernelGGL(k_project_vertices, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, r->verts, r->V, ca, r->sv,
+    hipLaunchKernelGGL(k_project_vertices, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, r->verts, r->V, ca, vs.sv,
                        r->side[side].big_count);
     SMESH_HIP(hipGetLastError());
   } else {
     SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 4, st));
   }
   if (r->F) {
-    RasterArgs a;
-    a.faces = r->faces; a.sv = r->sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
-    a.prim_id = r->prim_id;
-    a.keys = r->keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
-    a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
-    a.huge_queue = r->huge_queue;
-    a.frags = r->side[side].frags;
-    { static const int rdbg = getenv("SMESH_RDBG") ? atoi(getenv("SMESH_RDBG")) : 0; a.dbg = rdbg; }
+    RasterArgs a = raster_args(r, vs, side, W, H);
     const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
     int qs = SMESH_OK;
-    if (raster_path() == RasterPath::Frag && ensure_queues(r, W, H, st, &qs)) {
-      a.q = r->fq;
-      a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~2048 waves
-      while (a.tpw > 1 && r->F / a.tpw < 2048) a.tpw >>= 1;
+    if (raster_path() == RasterPath::Frag && ensure_queues(r, vs, W, H, st, &qs)) {
+      a.q = vs.fq;
       hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(div_up(r->F, a.tpw), 4)), dim3(256), 0, st, a);
       SMESH_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_tile_resolve, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a, d_idx, d_depth);
@@ -891,8 +943,53 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     hipLaunchKernelGGL(k_raster_big, dim3(big_grid), dim3(256), 0, st, a, 0u);
     SMESH_HIP(hipGetLastError());
   }
-  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, r->keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H);
+  hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, vs.keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H);
   SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
+}
+
+// The second scratch set (smesh_fuse_views rasterises two views per launch).
+hipError_t alloc_second_scratch(smesh_renderer* r) {
+  smesh_renderer::ViewScratch& vs = r->vs[1];
+  hipError_t e = hipSuccess;
+  if (!vs.sv) e = hipMalloc(reinterpret_cast<void**>(&vs.sv), std::max<uint64_t>(r->V * sizeof(ScreenVertex), 16));
+  if (e == hipSuccess && !vs.huge_queue) e = hipMalloc(reinterpret_cast<void**>(&vs.huge_queue), (size_t)r->big_capacity * 4);
+  return e;
+}
+
+// Two views (cams[0] -> side 0, cams[1] -> side 1) through the fragment-queue rasteriser with ONE launch per stage: the
+// vertex stage and the tile resolve are short, latency-bound kernels that fill a fraction of the chip, so two views'
+// worth of blocks take barely longer than one.  Index planes only.  *done = false (nothing launched): the fragment queues
+// are not usable for one of the views and the caller renders them one after the other.
+int render_pair_into(smesh_renderer* r, const smesh_camera_t* cams, uint32_t* const d_idx[2], hipStream_t st, bool* done) {
+  DeviceCtx* ctx = r->ctx;
+  *done = false;
+  if (raster_path() != RasterPath::Frag || r->F == 0 || r->V == 0) return SMESH_OK;
+  SMESH_HIP(alloc_second_scratch(r));
+  RasterArgs a[2];
+  CameraArgs ca[2];
+  uint32_t tiles[2];
+  for (int v = 0; v < 2; v++) {
+    const uint64_t W = cams[v].width, H = cams[v].height;
+    smesh_renderer::ViewScratch& vs = r->vs[v];
+    SMESH_TRY(ensure_keys(vs, W, H, st));
+    int qs = SMESH_OK;
+    if (!ensure_queues(r, vs, W, H, st, &qs)) { SMESH_TRY(qs); return SMESH_OK; }
+    ca[v] = camera_args(&cams[v]);
+    a[v] = raster_args(r, vs, v, W, H);
+    a[v].q = vs.fq;
+    tiles[v] = (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
+  }
+  ProfScope prof(ctx, SMESH_PROF_RASTER, st);
+  const uint32_t vb = (uint32_t)div_up(r->V, 256), rb = (uint32_t)div_up(div_up(r->F, a[0].tpw), 4);
+  hipLaunchKernelGGL(k_project_vertices2, dim3(2 * vb), dim3(256), 0, st, r->verts, r->V, ca[0], ca[1], r->vs[0].sv, r->vs[1].sv,
+                     r->side[0].big_count, r->side[1].big_count, vb);
+  SMESH_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_raster_frag2, dim3(2 * rb), dim3(256), 0, st, a[0], a[1], rb);
+  SMESH_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_tile_resolve2, dim3(tiles[0] + tiles[1]), dim3(256), 0, st, a[0], a[1], d_idx[0], d_idx[1], tiles[0]);
+  SMESH_HIP(hipGetLastError());
+  *done = true;
   return SMESH_OK;
 }
 
@@ -953,9 +1050,9 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   r->big_capacity = (uint32_t)std::max<uint64_t>(F, 1);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->verts), std::max<uint64_t>(V * 12, 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->faces), std::max<uint64_t>(F * 12, 16));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->vs[0].sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
   if (e == hipSuccess) e = alloc_side(r, 0);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->huge_queue), (size_t)r->big_capacity * 4);
+  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->vs[0].huge_queue), (size_t)r->big_capacity * 4);
   if (e == hipSuccess && V) e = hipMemcpyAsync(r->verts, vertices, V * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1185,12 +1282,13 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->raster_stream);
   (void)hipStreamSynchronize(r->ctx->stream);
-  for (void* p : {(void*)r->prim_id, (void*)r->huge_queue, (void*)r->verts, (void*)r->faces, (void*)r->sv, (void*)r->tex_res, (void*)r->tex_first, (void*)r->keys,
+  for (void* p : {(void*)r->prim_id, (void*)r->verts, (void*)r->faces, (void*)r->tex_res, (void*)r->tex_first,
                   (void*)r->side[0].big_queue, (void*)r->side[0].big_count, (void*)r->side[0].frags, (void*)r->side[1].big_queue,
                   (void*)r->side[1].big_count, (void*)r->side[1].frags})
     if (p) (void)hipFree(p);
-  for (void* p : {(void*)r->fq.key, (void*)r->fq.pix, (void*)r->fq.count, (void*)r->fq.flag})
-    if (p) (void)hipFree(p);
+  for (auto& vs : r->vs)
+    for (void* p : {(void*)vs.sv, (void*)vs.huge_queue, (void*)vs.keys, (void*)vs.fq.key, (void*)vs.fq.pix, (void*)vs.fq.count, (void*)vs.fq.flag})
+      if (p) (void)hipFree(p);
   for (auto& im : r->images) { (void)hipFree(im.idx); (void)hipFree(im.depth); }
   r->own_idx.release();
   for (int i = 0; i < 2; i++) {
@@ -1362,18 +1460,24 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
     SMESH_HIP(alloc_side(r, 1));
     r->main_pending = true;   // the renderer's scratch is in use on the main stream
     RenderedView rv[2];
+    uint32_t* d_idx[2];
     for (int v = 0; v < 2; v++) {
-      const smesh_camera_t* cam = &cams[i + v];
-      const uint64_t W = cam->width, H = cam->height, N = W * H;
+      const uint64_t N = (uint64_t)cams[i + v].width * cams[i + v].height;
       if (r->fused[v].bytes < N * 8) {
         SMESH_HIP(hipStreamSynchronize(ctx->stream));   // growing a slot frees the old buffer: nothing may still be reading it
         SMESH_TRY(r->fused[v].reserve(N * 8));
       }
-      uint32_t* d_idx = static_cast<uint32_t*>(r->fused[v].ptr);
+      d_idx[v] = static_cast<uint32_t*>(r->fused[v].ptr);
       r->last_idx[v] = nullptr;   // the records of a render_device() on this side are being overwritten
-      SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, ctx->stream, v));
-      rv[v] = RenderedView{r->side[v].frags, r->side[v].big_queue, r->side[v].big_count, d_idx, probs[i + v],
-                           weights ? weights[i + v] : nullptr, W, H};
+    }
+    bool both = false;
+    static const bool raster_pairs_off = getenv("SMESH_RASTER_PAIRS") && atoi(getenv("SMESH_RASTER_PAIRS")) == 0;
+    if (!raster_pairs_off) SMESH_TRY(render_pair_into(r, &cams[i], d_idx, ctx->stream, &both));   // one launch per stage for both views
+    for (int v = 0; v < 2; v++) {
+      const smesh_camera_t* cam = &cams[i + v];
+      if (!both) SMESH_TRY(render_into(r, cam, d_idx[v], /*d_depth=*/nullptr, ctx->stream, v));
+      rv[v] = RenderedView{r->side[v].frags, r->side[v].big_queue, r->side[v].big_count, d_idx[v], probs[i + v],
+                           weights ? weights[i + v] : nullptr, cam->width, cam->height};
     }
     SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, 2));
     g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
