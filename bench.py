@@ -4,8 +4,10 @@
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched through
 `python -m torch.distributed.run`, one rank per GPU.  A "step" is one pass of the hot path over one view:
-render(camera) -> add(indices, probs) via smesh_fuse_view, with the view's class-probability image already
-resident in HBM (generated on the device before the timed region).  After the K steps of every rank the
+render(camera) -> add(indices, probs), with the view's class-probability image already resident in HBM (generated on
+the device before the timed region).  The views are handed to the library `--views-per-call` at a time
+(smesh_fuse_views: same results as one smesh_fuse_view call per view, but the two views of a pair share their kernel
+launches; `--views-per-call 1` makes one smesh_fuse_view call per view).  After the K steps of every rank the
 raw accumulators are summed with ONE all-reduce (RCCL), inside the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -95,6 +97,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("SMESH_BENCH_VIEWS_PER_CALL", "8")),
+                    help="views handed to the library per call (fuse_views; 1 = one fuse_view call per view)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,8 +149,20 @@ def main():
             import torch
             torch.cuda.synchronize(device)
 
-    for i in range(args.warmup):
-        agg.fuse_view(renderer, cams[i], probs[i])
+    B = max(1, args.views_per_call)
+
+    def fuse_range(first, last):
+        """views [first, last) in order: one fuse_view call per view, or fuse_views on batches of B (the library then
+        shares launches between the two views of a pair)"""
+        if B == 1:
+            for i in range(first, last):
+                agg.fuse_view(renderer, cams[i], probs[i])
+        else:
+            for i in range(first, last, B):
+                j = min(i + B, last)
+                agg.fuse_views(renderer, cams[i:j], probs[i:j])
+
+    fuse_range(0, args.warmup)
     if dist is not None:   # untimed: RCCL builds its communicator / channels for this message size on first use
         _lib.synchronize(device)
         smdist.allreduce_raw(agg)
@@ -162,8 +178,7 @@ def main():
     _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.warmup, total_views):
-        agg.fuse_view(renderer, cams[i], probs[i])
+    fuse_range(args.warmup, total_views)
     if dist is not None:
         _lib.synchronize(device)
         smdist.allreduce_raw(agg)
@@ -183,6 +198,9 @@ def main():
 
     fuse_kernel = _lib.lib().smesh_last_fuse_kernel().decode()
     scatter_ms, scatter_n = prof_read(device, _lib.PROF_FUSE_SCATTER)
+    regions = ctypes.c_uint64()
+    _lib.check(_lib.lib().smesh_profile_regions(device, _lib.PROF_FUSE_SCATTER, ctypes.byref(regions)))
+    views_per_launch = args.steps / max(int(regions.value), 1) if prof_mask else 1.0   # 2 when fuse_views pairs the views
     hist_ms, hist_n = prof_read(device, _lib.PROF_FUSE_HIST)
     raster_ms, raster_n = prof_read(device, _lib.PROF_RASTER)
 
@@ -190,12 +208,14 @@ def main():
         N = W * H
         bytes_per_view = 4 * N + 4 * N * C + 8 * C * T_mean       # idx + probs + accumulator RMW
         t_kernel = scatter_ms * 1e-3 / max(scatter_n, 1)
-        achieved = bytes_per_view / t_kernel / 1e9 if t_kernel > 0 else 0.0
+        bytes_per_launch = bytes_per_view * views_per_launch
+        achieved = bytes_per_launch / t_kernel / 1e9 if t_kernel > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "fusion_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(fuse_kernel, {}).get("hbm_bytes_per_launch")
+                tkey = fuse_kernel + ("_pair" if views_per_launch > 1.5 else "")
+                traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -214,6 +234,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%s: %d-triangle grid mesh, %d views/GPU at %dx%d, %d classes, probs resident in HBM"
                                    % (args.workload, P, args.steps, W, H, C),
+                       "views_per_call": B,
                        "sharding": "views dp%d, one RCCL all-reduce of float32[P,C]" % world,
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
             "roofline": {"kernel": {"k_fuse_tri": "k_fuse_tri (triangle-order fusion: gather + accumulate, one owner per accumulator row)",
@@ -222,11 +243,12 @@ def main():
                          "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_per_view),
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
+                         "views_per_launch": round(views_per_launch, 3),
                          "avg_launch_us": round(1e6 * t_kernel, 2), "launches_timed": scatter_n,
                          "distinct_primitives_per_view": int(T_mean),
                          "other_kernels_us_per_view": ({"histogram+pixel_weights": round(1e3 * hist_ms / max(args.steps, 1), 2),
-                                                        "raster": round(1e3 * raster_ms / max(raster_n, 1), 2)}
+                                                        "raster": round(1e3 * raster_ms / max(raster_n, 1) / views_per_launch, 2)}
                                                        if hist_n or raster_n else None)},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -622,6 +622,7 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, cons
 int smesh_profile_enable(int, int) { return SMESH_OK; }
 int smesh_profile_sample_every(int, uint32_t) { return SMESH_OK; }
 int smesh_profile_read(int, int, double* ms, uint64_t* n) { if (ms) *ms = 0; if (n) *n = 0; return SMESH_OK; }
+int smesh_profile_regions(int, int, uint64_t* n) { if (n) *n = 0; return SMESH_OK; }
 int smesh_profile_reset(int) { return SMESH_OK; }
 
 // Synthetic probabilities.  Arithmetic is chosen so that CPU and GPU produce the same

@@ -69,6 +69,7 @@ SIGNATURES = {
     "smesh_profile_enable": (c_int, [c_int, c_int]),
     "smesh_profile_sample_every": (c_int, [c_int, ctypes.c_uint32]),
     "smesh_profile_read": (c_int, [c_int, c_int, P(ctypes.c_double), P(c_u64)]),
+    "smesh_profile_regions": (c_int, [c_int, c_int, P(c_u64)]),
     "smesh_profile_reset": (c_int, [c_int]),
     "smesh_synth_probs": (c_int, [c_void_p, c_u64, c_u32, c_u64, c_float, c_int, c_int]),
     "smesh_device_malloc": (c_int, [c_int, c_u64, P(c_void_p)]),

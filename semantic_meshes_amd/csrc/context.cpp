@@ -167,6 +167,15 @@ int smesh_profile_read(int device, int slot, double* total_ms, uint64_t* launche
   return SMESH_OK;
 }
 
+int smesh_profile_regions(int device, int slot, uint64_t* entered) {
+  if (slot < 0 || slot >= SMESH_PROF_SLOTS) return fail(SMESH_ERR_INVALID, "bad profile slot");
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  if (entered) *entered = ctx->slots[slot].seen;
+  return SMESH_OK;
+}
+
 int smesh_profile_reset(int device) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));
