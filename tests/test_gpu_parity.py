@@ -499,12 +499,28 @@ def test_render_fragment_queue_overflow(sm, oracle, monkeypatch, cap):
         oidx, odepth = o.render(cam)
         np.testing.assert_array_equal(np.asarray(idx), oidx)
         np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+    # the paired rasteriser launches of fuse_views (each view of a pair has its own queues, flags and key image)
+    from semantic_meshes_amd.device import to_device
+    P, C = len(faces), 19
+    rng = np.random.default_rng(cap)
+    agg = sm.fusion.MeshAggregator(P, C)
+    probs = [random_probs(rng, *cam.resolution, C) for cam in cams]
+    agg.fuse_views(r, cams + cams[:1], [to_device(p) for p in probs + probs[:1]])
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C)
+        for cam, p in zip(cams + cams[:1], probs + probs[:1]):
+            oagg.add(o.render(cam)[0], p)
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    finally:
+        oracle.set_accum_double(False)
     monkeypatch.delenv("SMESH_FRAG_CAP")
     idx, depth = r.render(cams[1])                              # back to the default capacity (queues re-allocated)
     np.testing.assert_array_equal(np.asarray(idx), o.render(cams[1])[0])
 
 
-@pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE_PIPELINE=1", "SMESH_FUSE=strip", "SMESH_FUSE_WIDE=0"])
+@pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE_PIPELINE=1", "SMESH_FUSE=strip", "SMESH_FUSE_WIDE=0",
+                                  "SMESH_RASTER_PAIRS=0", "SMESH_FUSE_PAIRS=0"])
 def test_alternative_paths_in_subprocess(knob):
     """These knobs are read once per process: re-run the render / fuse_view parity tests with the direct rasteriser
     (global 64-bit atomicMin per fragment), with the two-stream raster/fusion pipeline, and with the generic
@@ -518,6 +534,8 @@ def test_alternative_paths_in_subprocess(knob):
     sel = "render_small_scene or render_cfg1 or overlap or mixed_triangle or texel or fuse_view_cfg2"
     if k != "SMESH_FUSE":
         sel += " or triangle_order"
+    if k in ("SMESH_RASTER", "SMESH_RASTER_PAIRS", "SMESH_FUSE_PAIRS", "SMESH_FUSE"):
+        sel = "fuse_views" if k.endswith("PAIRS") else sel + " or fuse_views"
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
                           "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
