@@ -129,8 +129,8 @@ def test_random_soup_forced_reorder(seed):
 @pytest.mark.parametrize("seed", range(40))
 def test_random_soup_fuse_views_against_oracle(sm, oracle, seed):
     """fuse_views on soups: the two views of a pair see every triangle at unrelated sizes (small in one, big or huge in the
-    other, culled in either), at different resolutions, with and without weights; device-resident images (pairs) and an odd
-    number of views."""
+    other, culled in either), at different resolutions, with and without weights; device-resident images (pairs) and odd numbers
+    of views."""
     import types
     from semantic_meshes_amd.device import to_device
     rng = np.random.default_rng(9000 + seed)
@@ -144,7 +144,7 @@ def test_random_soup_fuse_views_against_oracle(sm, oracle, seed):
     r = sm.render.triangles(mesh)
     o = oracle.OracleRenderer(verts, faces)
     P = len(faces)
-    nviews = int(rng.choice([2, 3, 5]))
+    nviews = int(rng.choice([2, 3, 5, 8, 9]))                         # up to five pairs in one call
     cams, probs, weights = [], [], []
     for v in range(nviews):
         W, H = int(rng.choice([37, 160, 333])), int(rng.choice([29, 120, 257]))
