@@ -97,13 +97,20 @@ __global__ void k_project_vertices(const float* __restrict__ verts, uint64_t V, 
   project_vertex(verts, V, cam, sv, big_count, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// Two views of the same mesh in one launch (smesh_fuse_views): blocks [0, blocks_a) project for the first camera.
-__global__ void k_project_vertices2(const float* __restrict__ verts, uint64_t V, CameraArgs cam_a, CameraArgs cam_b,
-                                    ScreenVertex* __restrict__ sv_a, ScreenVertex* __restrict__ sv_b,
-                                    uint32_t* __restrict__ big_count_a, uint32_t* __restrict__ big_count_b, uint32_t blocks_a) {
-  const bool first = blockIdx.x < blocks_a;
-  project_vertex(verts, V, first ? cam_a : cam_b, first ? sv_a : sv_b, first ? big_count_a : big_count_b,
-                 (uint64_t)(blockIdx.x - (first ? 0u : blocks_a)) * blockDim.x + threadIdx.x);
+// Up to kMaxGroup views of the same mesh in one launch (smesh_fuse_views): blocks [v * blocks_per_view, (v + 1) * blocks_per_view)
+// project for camera v.
+constexpr int kMaxGroup = 8;
+struct ProjectGroup {
+  const float* verts;
+  uint64_t V;
+  CameraArgs cam[kMaxGroup];
+  ScreenVertex* sv[kMaxGroup];
+  uint32_t* big_count[kMaxGroup];
+  uint32_t blocks_per_view;
+};
+__global__ void k_project_vertices_group(ProjectGroup g) {
+  const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
+  project_vertex(g.verts, g.V, g.cam[v], g.sv[v], g.big_count[v], (uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x);
 }
 
 // ---- triangle setup --------------------------------------------------------------------------------
@@ -593,11 +600,16 @@ __global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
   raster_frag_wave(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 }
 
-// Two views in one launch: blocks [0, blocks_a) rasterise the first view.
-__global__ __launch_bounds__(256) void k_raster_frag2(RasterArgs a, RasterArgs b, uint32_t blocks_a) {
-  const bool first = blockIdx.x < blocks_a;
-  const RasterArgs& v = first ? a : b;   // block-uniform
-  raster_frag_wave(v, ((uint64_t)(blockIdx.x - (first ? 0u : blocks_a)) * blockDim.x + threadIdx.x) >> 6);
+// Several views in one launch: blocks [v * blocks_per_view, (v + 1) * blocks_per_view) rasterise view v.
+struct RasterGroup {
+  RasterArgs view[kMaxGroup];
+  uint32_t* idx[kMaxGroup];       // k_tile_resolve_group: index plane of view v ...
+  uint32_t tile_end[kMaxGroup];   // ... whose tiles are blocks [tile_end[v-1], tile_end[v])
+  uint32_t n, blocks_per_view;
+};
+__global__ __launch_bounds__(256) void k_raster_frag_group(RasterGroup g) {
+  const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
+  raster_frag_wave(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
 }
 
 // One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
@@ -692,12 +704,11 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
   tile_resolve_block(a, idx_out, depth_out, blockIdx.x);
 }
 
-// Two views in one launch: blocks [0, tiles_a) are the tiles of the first view.
-__global__ __launch_bounds__(256) void k_tile_resolve2(RasterArgs a, RasterArgs b, uint32_t* __restrict__ idx_a, uint32_t* __restrict__ idx_b,
-                                                        uint32_t tiles_a) {
-  const bool first = blockIdx.x < tiles_a;
-  const RasterArgs& v = first ? a : b;   // block-uniform
-  tile_resolve_block(v, first ? idx_a : idx_b, nullptr, blockIdx.x - (first ? 0u : tiles_a));
+// Several views in one launch (index planes only).
+__global__ __launch_bounds__(256) void k_tile_resolve_group(RasterGroup g) {
+  uint32_t v = 0;
+  while (v + 1 < g.n && blockIdx.x >= g.tile_end[v]) v++;   // block-uniform, n <= kMaxGroup
+  tile_resolve_block(g.view[v], g.idx[v], nullptr, blockIdx.x - (v ? g.tile_end[v - 1] : 0u));
 }
 
 // Split the key image into the two output planes and re-arm the keys for the next render.
@@ -773,8 +784,8 @@ struct smesh_renderer {
   float* verts = nullptr;          // float32[V*3]
   int32_t* faces = nullptr;        // int32[F*3]
   uint32_t* prim_id = nullptr;     // [F] primitive id per triangle position, when the triangles were re-ordered (else null)
-  // What a render in flight needs besides the per-triangle records.  Two sets: smesh_fuse_views rasterises two views in the
-  // same launches (the second set is allocated on first use); every other entry point uses set 0.
+  // What a render in flight needs besides the per-triangle records, per view slot: smesh_fuse_views rasterises up to
+  // kMaxGroup views in the same launches (slots beyond 0 are allocated on first use); every other entry point uses slot 0.
   struct ViewScratch {
     ScreenVertex* sv = nullptr;      // projected vertices [V]
     uint32_t* huge_queue = nullptr;  // [big_capacity] triangles larger than kMedium x kMedium
@@ -782,7 +793,7 @@ struct smesh_renderer {
     uint64_t keys_pixels = 0;
     FragQueues fq;                   // fragment-queue path: per-tile queues, sized for the largest image seen
     uint64_t fq_tiles = 0;
-  } vs[2];
+  } vs[kMaxGroup];
   bool texels = false;
   uint32_t* tex_res = nullptr;     // [F]
   uint32_t* tex_first = nullptr;   // [F]
@@ -794,12 +805,12 @@ struct smesh_renderer {
     uint32_t* big_queue = nullptr;   // [big_capacity] triangles with a bounding box > 8 x 8
     uint32_t* big_count = nullptr;   // [0] length of the queue; emptied by the next render's vertex kernel
     TriFrag* frags = nullptr;        // [F] per-triangle fragment records
-  } side[2];
+  } side[kMaxGroup];
   uint32_t big_capacity = 0;
   std::vector<ImagePair> images;   // pooled output planes
   Scratch own_idx;                 // for the host-output entry point
   // smesh_fuse_view pipeline: two index/depth slots, rasterised on ctx->raster_stream
-  Scratch fused[2];
+  Scratch fused[kMaxGroup];   // index planes of fuse_view (slots 0, 1) / fuse_views (one per view of a group)
   hipEvent_t ev_rendered[2] = {nullptr, nullptr};   // raster stream: slot is complete
   hipEvent_t ev_consumed[2] = {nullptr, nullptr};   // main stream: the fusion kernels have read the slot
   uint64_t fused_seq = 0;
@@ -948,48 +959,70 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   return SMESH_OK;
 }
 
-// The second scratch set (smesh_fuse_views rasterises two views per launch).
-hipError_t alloc_second_scratch(smesh_renderer* r) {
-  smesh_renderer::ViewScratch& vs = r->vs[1];
+hipError_t alloc_side(smesh_renderer* r, int i);
+
+// Scratch of view slot `i` (smesh_fuse_views rasterises several views per launch).
+hipError_t alloc_scratch(smesh_renderer* r, int i) {
+  smesh_renderer::ViewScratch& vs = r->vs[i];
   hipError_t e = hipSuccess;
   if (!vs.sv) e = hipMalloc(reinterpret_cast<void**>(&vs.sv), std::max<uint64_t>(r->V * sizeof(ScreenVertex), 16));
   if (e == hipSuccess && !vs.huge_queue) e = hipMalloc(reinterpret_cast<void**>(&vs.huge_queue), (size_t)r->big_capacity * 4);
   return e;
 }
 
-// Two views (cams[0] -> side 0, cams[1] -> side 1) through the fragment-queue rasteriser with ONE launch per stage: the
-// vertex stage and the tile resolve are short, latency-bound kernels that fill a fraction of the chip, so two views'
-// worth of blocks take barely longer than one.  Index planes only.  *done = false (nothing launched): the fragment queues
-// are not usable for one of the views and the caller renders them one after the other.
-int render_pair_into(smesh_renderer* r, const smesh_camera_t* cams, uint32_t* const d_idx[2], hipStream_t st, bool* done) {
+// Can a W x H view go through fragment queues of a size that kMaxGroup view slots can afford?  (ensure_queues' sizing rule.)
+bool queues_fit_group(uint64_t W, uint64_t H) {
+  if (raster_path() != RasterPath::Frag) return false;
+  if (getenv("SMESH_FRAG_CAP")) return true;
+  const uint64_t ntiles = div_up(W, kQW) * div_up(H, kQH);
+  const uint64_t cap = 16ull * kQPixels / kQSub;
+  return ntiles * kQSub * cap * 10 <= (2ull << 30);
+}
+
+// n <= kMaxGroup views (cams[v] -> view slot v: its own projected vertices, fragment queues, key image, queues of large
+// triangles, per-triangle records and index plane r->fused[v]) through the fragment-queue rasteriser with ONE launch per
+// stage: the vertex stage and the tile resolve are short kernels that fill a fraction of the chip, and every launch has a
+// ramp and a tail, so n views' worth of blocks take less than n launches.  Index planes only.
+int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st) {
   DeviceCtx* ctx = r->ctx;
-  *done = false;
-  if (raster_path() != RasterPath::Frag || r->F == 0 || r->V == 0) return SMESH_OK;
-  SMESH_HIP(alloc_second_scratch(r));
-  RasterArgs a[2];
-  CameraArgs ca[2];
-  uint32_t tiles[2];
-  for (int v = 0; v < 2; v++) {
-    const uint64_t W = cams[v].width, H = cams[v].height;
+  ProjectGroup pg;
+  RasterGroup rg;
+  memset(&pg, 0, sizeof pg);
+  memset(&rg, 0, sizeof rg);
+  uint32_t tiles = 0;
+  for (int v = 0; v < n; v++) {
+    const uint64_t W = cams[v].width, H = cams[v].height, N = W * H;
+    SMESH_HIP(alloc_side(r, v));
+    SMESH_HIP(alloc_scratch(r, v));
     smesh_renderer::ViewScratch& vs = r->vs[v];
     SMESH_TRY(ensure_keys(vs, W, H, st));
     int qs = SMESH_OK;
-    if (!ensure_queues(r, vs, W, H, st, &qs)) { SMESH_TRY(qs); return SMESH_OK; }
-    ca[v] = camera_args(&cams[v]);
-    a[v] = raster_args(r, vs, v, W, H);
-    a[v].q = vs.fq;
-    tiles[v] = (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
+    if (!ensure_queues(r, vs, W, H, st, &qs)) return qs != SMESH_OK ? qs : fail(SMESH_ERR_RUNTIME, "fragment queues unavailable");
+    if (r->fused[v].bytes < N * 8) {
+      SMESH_HIP(hipStreamSynchronize(st));   // growing a slot frees the old buffer: nothing may still be reading it
+      SMESH_TRY(r->fused[v].reserve(N * 8));
+    }
+    if (v < 2) r->last_idx[v] = nullptr;     // the records of a render_device() on this side are being overwritten
+    pg.cam[v] = camera_args(&cams[v]);
+    pg.sv[v] = vs.sv;
+    pg.big_count[v] = r->side[v].big_count;
+    rg.view[v] = raster_args(r, vs, v, W, H);
+    rg.view[v].q = vs.fq;
+    rg.idx[v] = static_cast<uint32_t*>(r->fused[v].ptr);
+    tiles += (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
+    rg.tile_end[v] = tiles;
   }
+  pg.verts = r->verts; pg.V = r->V;
+  pg.blocks_per_view = (uint32_t)div_up(r->V, 256);
+  rg.n = (uint32_t)n;
+  rg.blocks_per_view = (uint32_t)div_up(div_up(r->F, rg.view[0].tpw), 4);
   ProfScope prof(ctx, SMESH_PROF_RASTER, st);
-  const uint32_t vb = (uint32_t)div_up(r->V, 256), rb = (uint32_t)div_up(div_up(r->F, a[0].tpw), 4);
-  hipLaunchKernelGGL(k_project_vertices2, dim3(2 * vb), dim3(256), 0, st, r->verts, r->V, ca[0], ca[1], r->vs[0].sv, r->vs[1].sv,
-                     r->side[0].big_count, r->side[1].big_count, vb);
+  hipLaunchKernelGGL(k_project_vertices_group, dim3((uint32_t)n * pg.blocks_per_view), dim3(256), 0, st, pg);
   SMESH_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_raster_frag2, dim3(2 * rb), dim3(256), 0, st, a[0], a[1], rb);
+  hipLaunchKernelGGL(k_raster_frag_group, dim3((uint32_t)n * rg.blocks_per_view), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_tile_resolve2, dim3(tiles[0] + tiles[1]), dim3(256), 0, st, a[0], a[1], d_idx[0], d_idx[1], tiles[0]);
+  hipLaunchKernelGGL(k_tile_resolve_group, dim3(tiles), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
-  *done = true;
   return SMESH_OK;
 }
 
@@ -1282,17 +1315,18 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->raster_stream);
   (void)hipStreamSynchronize(r->ctx->stream);
-  for (void* p : {(void*)r->prim_id, (void*)r->verts, (void*)r->faces, (void*)r->tex_res, (void*)r->tex_first,
-                  (void*)r->side[0].big_queue, (void*)r->side[0].big_count, (void*)r->side[0].frags, (void*)r->side[1].big_queue,
-                  (void*)r->side[1].big_count, (void*)r->side[1].frags})
+  for (void* p : {(void*)r->prim_id, (void*)r->verts, (void*)r->faces, (void*)r->tex_res, (void*)r->tex_first})
     if (p) (void)hipFree(p);
+  for (auto& sd : r->side)
+    for (void* p : {(void*)sd.big_queue, (void*)sd.big_count, (void*)sd.frags})
+      if (p) (void)hipFree(p);
   for (auto& vs : r->vs)
     for (void* p : {(void*)vs.sv, (void*)vs.huge_queue, (void*)vs.keys, (void*)vs.fq.key, (void*)vs.fq.pix, (void*)vs.fq.count, (void*)vs.fq.flag})
       if (p) (void)hipFree(p);
   for (auto& im : r->images) { (void)hipFree(im.idx); (void)hipFree(im.depth); }
   r->own_idx.release();
+  for (auto& f : r->fused) f.release();
   for (int i = 0; i < 2; i++) {
-    r->fused[i].release();
     if (r->ev_rendered[i]) (void)hipEventDestroy(r->ev_rendered[i]);
     if (r->ev_consumed[i]) (void)hipEventDestroy(r->ev_consumed[i]);
   }
@@ -1457,32 +1491,42 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
       SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
       r->raster_pending = false;
     }
-    SMESH_HIP(alloc_side(r, 1));
     r->main_pending = true;   // the renderer's scratch is in use on the main stream
-    RenderedView rv[2];
-    uint32_t* d_idx[2];
-    for (int v = 0; v < 2; v++) {
-      const uint64_t N = (uint64_t)cams[i + v].width * cams[i + v].height;
-      if (r->fused[v].bytes < N * 8) {
-        SMESH_HIP(hipStreamSynchronize(ctx->stream));   // growing a slot frees the old buffer: nothing may still be reading it
-        SMESH_TRY(r->fused[v].reserve(N * 8));
-      }
-      d_idx[v] = static_cast<uint32_t*>(r->fused[v].ptr);
-      r->last_idx[v] = nullptr;   // the records of a render_device() on this side are being overwritten
-    }
-    bool both = false;
+    // Rasterise a GROUP of the remaining views with one launch per stage, then fuse them two by two.
     static const bool raster_pairs_off = getenv("SMESH_RASTER_PAIRS") && atoi(getenv("SMESH_RASTER_PAIRS")) == 0;
-    if (!raster_pairs_off) SMESH_TRY(render_pair_into(r, &cams[i], d_idx, ctx->stream, &both));   // one launch per stage for both views
-    for (int v = 0; v < 2; v++) {
-      const smesh_camera_t* cam = &cams[i + v];
-      if (!both) SMESH_TRY(render_into(r, cam, d_idx[v], /*d_depth=*/nullptr, ctx->stream, v));
-      rv[v] = RenderedView{r->side[v].frags, r->side[v].big_queue, r->side[v].big_count, d_idx[v], probs[i + v],
-                           weights ? weights[i + v] : nullptr, cam->width, cam->height};
+    static const int group_max = getenv("SMESH_RASTER_GROUP") ? std::min(kMaxGroup, std::max(2, atoi(getenv("SMESH_RASTER_GROUP")))) : kMaxGroup;
+    int gn = (int)std::min<uint64_t>((uint64_t)group_max, n - i);
+    bool grouped = !raster_pairs_off && r->V != 0;
+    for (int v = 0; v < gn && grouped; v++) grouped = queues_fit_group(cams[i + v].width, cams[i + v].height);
+    if (grouped) {
+      SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->stream));
+    } else {   // images too large for kMaxGroup sets of fragment queues, direct rasteriser, or SMESH_RASTER_PAIRS=0: one view at a time
+      gn = 2;
+      SMESH_HIP(alloc_side(r, 1));
+      for (int v = 0; v < 2; v++) {
+        const uint64_t N = (uint64_t)cams[i + v].width * cams[i + v].height;
+        if (r->fused[v].bytes < N * 8) {
+          SMESH_HIP(hipStreamSynchronize(ctx->stream));   // growing a slot frees the old buffer: nothing may still be reading it
+          SMESH_TRY(r->fused[v].reserve(N * 8));
+        }
+        r->last_idx[v] = nullptr;   // the records of a render_device() on this side are being overwritten
+        SMESH_TRY(render_into(r, &cams[i + v], static_cast<uint32_t*>(r->fused[v].ptr), /*d_depth=*/nullptr, ctx->stream, v));
+      }
     }
-    SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, 2));
+    for (int j = 0; j < gn; j += 2) {
+      const int nv = std::min(2, gn - j);
+      RenderedView rv[2];
+      for (int v = 0; v < nv; v++) {
+        const smesh_renderer::Side& sd = r->side[j + v];
+        const uint64_t k = i + (uint64_t)(j + v);
+        rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[j + v].ptr), probs[k],
+                             weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
+      }
+      SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
+    }
     g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
-    r->fused_seq += 2;
-    i += 2;
+    r->fused_seq += (uint64_t)gn;
+    i += (uint64_t)gn;
   }
   return SMESH_OK;
 }
