@@ -84,6 +84,28 @@ struct TriFrag {
 };
 static_assert(sizeof(TriFrag) == 16, "TriFrag must be 16 bytes");
 
+// Arguments of the triangle-order fusion kernels (fuse_tri.inc.hpp, fusion.hip).
+struct TriFuseArgs {
+  const TriFrag* frags;
+  const uint32_t* idx;
+  const float* probs;
+  const float* weights;       // may be null
+  float* acc;                 // [P][C] dense
+  uint64_t F;
+  uint32_t C, W, H;
+  float iew;
+  const uint32_t* big_queue;
+  const uint32_t* big_len;    // queue length of this render (emptied by the next render's vertex kernel)
+  uint32_t big_capacity;
+  uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the rest the big-triangle queue
+  int dbg;                    // development ablation (SMESH_FDBG): 1 stop after pass 1, 2 no stores, 4 no row loads, 8 no probs loads
+  const uint32_t* prim_id;    // [F] primitive id of triangle f when the renderer re-ordered its triangles (null: id == f)
+  // texel primitives (k_fuse_texel) only
+  const uint32_t* tex_first;  // [F] first texel id of each triangle
+  const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
+  uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
+};
+
 // One rendered view as the triangle-order fusion consumes it (raster.hip -> fusion.hip).
 struct RenderedView {
   const TriFrag* frags;         // per-triangle fragment records of the render

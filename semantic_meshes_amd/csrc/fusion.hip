@@ -36,9 +36,13 @@
 
 using namespace smesh;
 
+// fusion_pair.hip: k_fuse_tri<CT, KIND, EXACT, 2> for the class-count slot `tri_ct` chosen below
+void smesh_launch_fuse_tri_pair(int kind, int tri_ct, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriFuseArgs& tb);
+
 namespace {
 
-constexpr int kWave = 64;
+#include "fuse_tri.inc.hpp"
+
 
 // ------------------------------------------------------------------------------------------------
 // layout normalisation (Fusion.h:26-40): arbitrary dtype/strides -> contiguous uint32[N] / float[N*C]
@@ -68,26 +72,6 @@ __global__ void k_gather_probs(const float* __restrict__ in, int64_t s0, int64_t
   const uint32_t c = (uint32_t)(e - pix * C);
   const uint64_t x = pix / H, y = pix - x * H;
   out[e] = in[x * s0 + y * s1 + (int64_t)c * s2];
-}
-
-// ------------------------------------------------------------------------------------------------
-// aggregator input maps (Fusion.cu:51-56 Summax, :70-73 Sum, :83-87 Mul)
-// ------------------------------------------------------------------------------------------------
-// Mul: LogProb<float>(pow(p, w)) (Fusion.cu:83-87) = log(p^w).  Whenever p^w is a NORMAL float that is w * log(p) to within the
-// rounding the two-step form has itself (pow rounds p^w to 24 bits: 6e-8 absolute in the log; log rounds again), at an eighth of
-// the instructions -- powf made the Mul aggregator three times slower than Sum.  Where p^w leaves the normal range (underflow to
-// zero or denormals, overflow) or the inputs are not positive finite numbers, the two-step form decides: -inf, NaN and the
-// coarse denormal steps are part of the reference's behaviour.
-__device__ __forceinline__ float log_of_power(float p, float w) {
-  const float t = w * logf(p);
-  if (p > 0.0f && isfinite(p) && isfinite(w) && t > -87.0f && t < 88.0f) return t;   // e^-87 .. e^88 is inside float's normal range
-  return logf(powf(p, w));
-}
-
-template <int KIND>
-__device__ __forceinline__ float contribution(float p, float w) {
-  if (KIND == SMESH_AGG_MUL) return log_of_power(p, w);
-  return p * w;
 }
 
 // Opaque to the optimiser: the value must sit in VGPRs here, so the load that produced it cannot be sunk
@@ -178,14 +162,6 @@ struct StripRuns {
   int gidx;        // root lanes: dense index of my group in [0, G)
   int G;           // groups in the strip
 };
-
-// Orders this wave's LDS writes before its later LDS reads (LDS executes a wave's instructions in order;
-// this only stops the compiler from reordering them).  No s_barrier: waves never wait for each other here.
-__device__ __forceinline__ void wave_sync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // Builds runs, links and groups from each lane's primitive id `v` (0xFFFFFFFF outside the image).
 __device__ __forceinline__ StripRuns build_strip(StripLists& L, uint32_t v, uint32_t P, int l) {
@@ -316,7 +292,6 @@ struct PrefetchVecs {  // float4 registers holding the next strip's probs (0 = n
   static constexpr int value = (CT > 0 && CT <= 40) ? (CT * 4 * kSX + kWave - 1) / kWave : 0;
 };
 
-typedef float f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void pin(f4& v) { asm volatile("" : "+v"(v)); }
 template <bool NT>
 __device__ __forceinline__ f4 load_stream(const f4* p) {
@@ -682,375 +657,6 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
       }
     }
     wave_sync();  // the next iteration overwrites the LDS strip
-  }
-}
-
-// Cross-lane moves in registers (DPP) instead of ds_bpermute: a dependent chain of LDS round trips per pixel made
-// the wide-row kernels latency-bound.  Lanes whose source is disabled or outside the row keep `old`.
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ float dpp_f(float old, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
-}
-template <int CTRL, int ROW_MASK = 0xF>
-__device__ __forceinline__ uint32_t dpp_u(uint32_t old, uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
-constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143, kDppWaveShr1 = 0x138;
-
-__device__ __forceinline__ float wave_sum(float v) {   // same value in every lane (read back from lane 63)
-  v += dpp_f<kDppRowShr1>(0.0f, v);
-  v += dpp_f<kDppRowShr2>(0.0f, v);
-  v += dpp_f<kDppRowShr4>(0.0f, v);
-  v += dpp_f<kDppRowShr8>(0.0f, v);
-  v += dpp_f<kDppRowBcast15, 0xA>(0.0f, v);
-  v += dpp_f<kDppRowBcast31, 0xC>(0.0f, v);
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-__device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) {
-  v += dpp_u<kDppRowShr1>(0u, v);
-  v += dpp_u<kDppRowShr2>(0u, v);
-  v += dpp_u<kDppRowShr4>(0u, v);
-  v += dpp_u<kDppRowShr8>(0u, v);
-  v += dpp_u<kDppRowBcast15, 0xA>(0u, v);
-  v += dpp_u<kDppRowBcast31, 0xC>(0u, v);
-  return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Triangle-order fusion (smesh_fuse_view with a triangle renderer): the rasteriser left, per triangle, the set
-// of pixels it emitted (TriFrag).  Every accumulator row is then owned by exactly one lane: NO atomics, no
-// histogram pass (the per-view count is the number of the triangle's fragments that won the depth test), no
-// sort/merge machinery, and the accumulator is read-modify-written once, sequentially, 64 rows per wave.
-// The arithmetic is the reference's, in its order (Mesh.h:94-106): for Sum/Summax the result is bit-identical
-// to the float32 CPU oracle run single-threaded.
-// ------------------------------------------------------------------------------------------------
-struct TriFuseArgs {
-  const TriFrag* frags;
-  const uint32_t* idx;
-  const float* probs;
-  const float* weights;       // may be null
-  float* acc;                 // [P][C] dense
-  uint64_t F;
-  uint32_t C, W, H;
-  float iew;
-  const uint32_t* big_queue;
-  const uint32_t* big_len;    // queue length of this render (emptied by the next render's vertex kernel)
-  uint32_t big_capacity;
-  uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the rest the big-triangle queue
-  int dbg;                    // development ablation (SMESH_FDBG): 1 stop after pass 1, 2 no stores, 4 no row loads, 8 no probs loads
-  const uint32_t* prim_id;    // [F] primitive id of triangle f when the renderer re-ordered its triangles (null: id == f)
-  // texel primitives (k_fuse_texel) only
-  const uint32_t* tex_first;  // [F] first texel id of each triangle
-  const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
-  uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
-};
-
-// float4 at 4-byte alignment: rows are only float-aligned; gfx950 global memory takes dwordx4 at any dword address.
-// (A packed struct gets scalarised: its stores became one write request per lane and dword.)
-typedef float fvec4 __attribute__((ext_vector_type(4)));
-typedef fvec4 fvec4_a4 __attribute__((aligned(4)));
-
-// k_fuse_tri comes in two flavours: EXACT (the class count is the template parameter: cfg 5 / 19 / 40) and run-time C <= CT
-// (CT = 8, 16 .. 40: the register arrays are sized CT, loops are predicated with c < C).
-template <int CT, bool EXACT>
-__device__ __forceinline__ void load_row(const float* __restrict__ pr, int C, float (&p)[CT]) {
-  if (EXACT) {
-#pragma unroll
-    for (int c = 0; c < CT; c++) p[c] = pr[c];
-  } else {
-#pragma unroll
-    for (int c = 0; c < CT; c += 4) {
-      if (c + 4 <= C) {
-        const fvec4 q = *reinterpret_cast<const fvec4_a4*>(pr + c);
-        p[c] = q.x; p[c + 1] = q.y; p[c + 2] = q.z; p[c + 3] = q.w;
-      } else {
-#pragma unroll
-        for (int t = 0; t < 4; t++) if (c + t < CT) p[c + t] = (c + t < C) ? pr[c + t] : 0.0f;
-      }
-    }
-  }
-}
-
-// One triangle of one view, its pixels found by scanning the box [x0, x1] x [y0, y1] of the index image: one WAVE, lanes
-// over the box; per-lane partial sums are combined by a butterfly over the wave and lane c owns class c of the row.
-template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f, const int x0, const int y0, const int x1, const int y1) {
-  const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
-  const int l = threadIdx.x;
-  const int bh = y1 - y0 + 1;
-  const long long npx = (long long)(x1 - x0 + 1) * bh;
-  // U pixels per lane and step: their index loads, then their class vectors, are in flight together
-  constexpr int U = CT <= 24 ? 4 : 2;
-  auto pix_of = [&](long long i) -> uint64_t { return (uint64_t)(x0 + (int)(i / bh)) * a.H + (uint64_t)(y0 + (int)(i % bh)); };
-  uint32_t n = 0;
-  for (long long base = 0; base < npx; base += (long long)kWave * U) {
-    uint32_t v[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const long long i = base + (long long)u * kWave + l;
-      v[u] = a.idx[i < npx ? pix_of(i) : pix_of(0)];
-      if (!(i < npx)) v[u] = ~f;
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) n += v[u] == f ? 1u : 0u;
-  }
-  n = wave_sum_u(n);
-  if (n == 0) return;
-  const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
-  float part[CT];
-#pragma unroll
-  for (int c = 0; c < CT; c++) part[c] = 0.0f;
-  for (long long base = 0; base < npx; base += (long long)kWave * U) {
-    uint64_t pix[U];
-    bool hit[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const long long i = base + (long long)u * kWave + l;
-      pix[u] = i < npx ? pix_of(i) : pix_of(0);
-      hit[u] = a.idx[pix[u]] == f && i < npx;
-    }
-    float p[U][CT];
-    float wt[U];
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      const float* __restrict__ pr = a.probs + (hit[u] ? pix[u] : pix_of(0)) * C;   // unconditional: the loads overlap
-      load_row<CT, EXACT>(pr, C, p[u]);
-      wt[u] = (a.weights && hit[u]) ? a.weights[pix[u]] : 1.0f;
-    }
-#pragma unroll
-    for (int u = 0; u < U; u++) {
-      float sum = 0.0f;
-#pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[u][c];
-      if (!(hit[u] && sum > 0.5f)) continue;
-      const float w = w0 * wt[u];
-      if (KIND == SMESH_AGG_SUMMAX) {
-        float best = p[u][0];
-        int am = 0;
-#pragma unroll
-        for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[u][c] > best) { best = p[u][c]; am = c; }
-#pragma unroll
-        for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] = (c == am) ? part[c] + p[u][c] * w : part[c];
-      } else {
-#pragma unroll
-        for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] += contribution<KIND>(p[u][c], w);
-      }
-    }
-  }
-  float mine = 0.0f;
-#pragma unroll
-  for (int c = 0; c < CT; c++) if (EXACT || c < C) {
-    const float v = wave_sum(part[c]);
-    if (l == c) mine = v;
-  }
-  if (l < C) a.acc[(uint64_t)f * C + l] += mine;   // this wave owns the row: plain read-modify-write
-}
-
-// Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle (so, unlike the small-triangle
-// path, the summation order is a tree).  Runs in the tail blocks of k_fuse_tri.
-template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers) {
-  const uint32_t nbig = min(*a.big_len, a.big_capacity);
-  for (uint32_t q = worker; q < nbig; q += nworkers) {
-    const uint32_t fi = a.big_queue[q];                       // position in the renderer's triangle order
-    const TriFrag rec = a.frags[fi];
-    if (rec.kind != 2) continue;
-    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
-    fuse_box<CT, KIND, EXACT>(a, f, rec.x0, rec.y0, (int)(rec.mask & 0xFFFFu), (int)((rec.mask >> 16) & 0xFFFFu));
-  }
-}
-
-// Two views in one launch: a triangle that is big in EITHER view is left to one tail wave for BOTH views (first view
-// first, as two calls would do it), so that no other wave touches its row; its small view is scanned as an 8 x 8 box.
-// A triangle queued by both views is taken from the first view's queue only.
-template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_big_triangles_pair(const TriFuseArgs& a, const TriFuseArgs& b, uint32_t worker, uint32_t nworkers) {
-  const uint32_t na = min(*a.big_len, a.big_capacity), nb = min(*b.big_len, b.big_capacity);
-  for (uint32_t q = worker; q < na + nb; q += nworkers) {
-    const bool second = q >= na;
-    const uint32_t fi = second ? b.big_queue[q - na] : a.big_queue[q];
-    const TriFrag ra = a.frags[fi], rb = b.frags[fi];
-    if (second ? (rb.kind != 2 || ra.kind == 2) : (ra.kind != 2)) continue;
-    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;
-    for (int j = 0; j < 2; j++) {
-      const TriFrag rec = j ? rb : ra;
-      if (rec.kind == 0) continue;
-      TriFuseArgs v = a;                  // wave-uniform selection of the view
-      if (j) { v.idx = b.idx; v.probs = b.probs; v.weights = b.weights; v.H = b.H; v.W = b.W; }
-      int x1, y1;
-      if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
-      else { x1 = min((int)rec.x0 + 7, (int)v.W - 1); y1 = min((int)rec.y0 + 7, (int)v.H - 1); }
-      fuse_box<CT, KIND, EXACT>(v, f, rec.x0, rec.y0, x1, y1);
-    }
-  }
-}
-
-// NV = 1: one view (a).  NV = 2: views a then b of the same mesh into the same accumulator -- the 64-row block makes ONE
-// round trip for both, and the additions happen in the order two launches would have made them.
-template <int CT, int KIND, bool EXACT, int NV>
-__global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b) {
-  const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
-  constexpr int PB = CT <= 24 ? 2 : 1;        // pixels whose class vectors are in flight together
-  constexpr int KV = (kWave * CT / 4 + kWave - 1) / kWave;   // float4 per lane of the 64-row block
-  __shared__ __attribute__((aligned(16))) float srow[kWave * CT + 4];   // the wave's 64 accumulator rows
-  const int l = threadIdx.x;
-  if (blockIdx.x >= a.tri_blocks) {   // tail blocks: the queued big triangles
-    if (NV == 2) fuse_big_triangles_pair<CT, KIND, EXACT>(a, b, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
-    else fuse_big_triangles<CT, KIND, EXACT>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
-    return;
-  }
-  const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
-  const uint64_t f = f0 + l;
-  TriFrag rec[NV];
-#pragma unroll
-  for (int v = 0; v < NV; v++) { rec[v].x0 = 0; rec[v].y0 = 0; rec[v].kind = 0; rec[v].pad = 0; rec[v].mask = 0ull; }
-  if (f < a.F) {
-    rec[0] = a.frags[f];
-    if (NV == 2) rec[NV - 1] = b.frags[f];
-  }
-  const bool big = rec[0].kind == 2 || rec[NV - 1].kind == 2;   // this row belongs to a tail wave
-  // Re-ordered mesh (renderer's position -> primitive id table): the id is what the index image holds and which row to
-  // update; the 64 rows of a wave are then scattered, so every lane loads / stores its own row instead of the LDS block.
-  const bool scattered = a.prim_id != nullptr;
-  const uint32_t pid = (scattered && f < a.F) ? a.prim_id[f] : (uint32_t)f;
-  auto pixel = [&](int v, int k) -> uint64_t {
-    return (uint64_t)(rec[v].x0 + (k >> 3)) * (v ? b.H : a.H) + rec[v].y0 + (k & 7);
-  };
-
-  // ---- pass 1: which emitted fragments won the depth test?  n = pixels of this primitive in this view.
-  // Four candidates per lane and view are checked per round so that their index loads are in flight together.
-  unsigned long long m[NV], win[NV];
-  uint32_t n[NV];
-#pragma unroll
-  for (int v = 0; v < NV; v++) { m[v] = (rec[v].kind == 1 && !big) ? rec[v].mask : 0ull; win[v] = 0ull; n[v] = 0u; }
-  while (__ballot((m[0] | m[NV - 1]) != 0ull) != 0ull) {
-    int k[NV][4];
-    uint32_t got[NV][4];
-#pragma unroll
-    for (int v = 0; v < NV; v++) {
-      const uint32_t* __restrict__ idx = v ? b.idx : a.idx;
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        k[v][j] = -1;
-        if (m[v]) { k[v][j] = __ffsll((long long)m[v]) - 1; m[v] &= m[v] - 1ull; }
-        got[v][j] = idx[k[v][j] >= 0 ? pixel(v, k[v][j]) : 0];   // unconditional (clamped) so that the loads overlap
-      }
-    }
-#pragma unroll
-    for (int v = 0; v < NV; v++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (k[v][j] >= 0 && got[v][j] == pid) { n[v]++; win[v] |= 1ull << k[v][j]; }
-  }
-  const unsigned long long any_win = win[0] | win[NV - 1];
-  if (__ballot(any_win != 0ull) == 0ull) return;   // nothing of these 64 triangles is visible: rows untouched
-
-  // ---- issue together: the wave's 64 accumulator rows (one contiguous block) and the first PB pixels'
-  // class vectors of every lane
-  const int nrows = (int)min((uint64_t)kWave, a.F - f0);
-  float* __restrict__ blk = a.acc + f0 * C;
-  f4 br[KV];
-  if (nrows == kWave && !scattered) {
-    const f4* b4 = reinterpret_cast<const f4*>(blk);
-#pragma unroll
-    for (int q = 0; q < KV; q++) br[q] = b4[min(l + q * kWave, kWave * C / 4 - 1)];
-  }
-  float accr[CT];
-  bool rows_loaded = false;
-#pragma unroll
-  for (int v = 0; v < NV; v++) {
-    const float* __restrict__ probs = v ? b.probs : a.probs;
-    const float* __restrict__ weights = v ? b.weights : a.weights;
-    float w0 = 0.0f;
-    if (n[v]) {
-      const float image_weight = 1.0f / ((float)n[v]);                       // Mesh.h:100
-      const float pixel_w = 1.0f;                                            // :101
-      w0 = a.iew * image_weight + (1 - a.iew) * pixel_w;                     // :102
-    }
-    unsigned long long mm = win[v];
-    while (__ballot(mm != 0ull) != 0ull) {
-      float p[PB][CT];
-      float wt[PB];
-      bool have[PB];
-#pragma unroll
-      for (int j = 0; j < PB; j++) {
-        have[j] = mm != 0ull;
-        int k = 0;
-        if (mm) { k = __ffsll((long long)mm) - 1; mm &= mm - 1ull; }
-        const uint64_t pix = have[j] ? pixel(v, k) : 0;
-        const float* __restrict__ pr = probs + pix * C;
-        load_row<CT, EXACT>(pr, C, p[j]);
-        wt[j] = weights ? weights[pix] : 1.0f;
-      }
-      if (!rows_loaded && scattered) {
-        if (any_win) load_row<CT, EXACT>(a.acc + (uint64_t)pid * C, C, accr);
-        rows_loaded = true;
-      }
-      if (!rows_loaded) {
-        // park the block in LDS (flat, coalesced) and pick up this lane's row
-        if (nrows == kWave) {
-          f4* s4 = reinterpret_cast<f4*>(srow);
-#pragma unroll
-          for (int q = 0; q < KV; q++)
-            if (l + q * kWave < kWave * C / 4) s4[l + q * kWave] = br[q];
-        } else {
-          for (int q = l; q < nrows * C; q += kWave) srow[q] = blk[q];
-        }
-        wave_sync();
-#pragma unroll
-        for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = srow[l * C + c];
-        rows_loaded = true;
-      }
-      // Mesh.h:94-106 for this primitive's pixels, in image order (x, then y)
-#pragma unroll
-      for (int j = 0; j < PB; j++) {
-        float sum = 0.0f;
-#pragma unroll
-        for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[j][c];                      // tt::sum, sequential float32
-        if (have[j] && sum > 0.5f) {                                          // :98
-          const float w = w0 * wt[j];                                         // :103
-          if (KIND == SMESH_AGG_SUMMAX) {
-            int am = 0;
-            float best = p[j][0];   // (not p[j][am]: a run-time register index would go through scratch)
-#pragma unroll
-            for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[j][c] > best) { best = p[j][c]; am = c; }
-#pragma unroll
-            for (int c = 0; c < CT; c++) if (EXACT || c < C) if (c == am) accr[c] = accr[c] + p[j][c] * w;
-          } else {
-#pragma unroll
-            for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = accr[c] + contribution<KIND>(p[j][c], w);
-          }
-        }
-      }
-    }
-  }
-  if (scattered) {
-    if (any_win) {
-#pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) a.acc[(uint64_t)pid * C + c] = accr[c];
-    }
-    return;
-  }
-  if (__ballot(big) != 0ull) {
-    // Some of these 64 rows belong to big triangles, which the tail blocks of this launch update concurrently:
-    // writing the whole block back would overwrite their sums.  Every other lane stores its own row.
-    if (!big && f < a.F) {
-#pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) blk[l * C + c] = accr[c];
-    }
-    return;
-  }
-#pragma unroll
-  for (int c = 0; c < CT; c++) if (EXACT || c < C) srow[l * C + c] = accr[c];
-  wave_sync();
-  if (nrows == kWave) {
-    f4* b4 = reinterpret_cast<f4*>(blk);
-    const f4* s4 = reinterpret_cast<const f4*>(srow);
-    for (int q = l; q < kWave * C / 4; q += kWave) b4[q] = s4[q];
-  } else {
-    for (int q = l; q < nrows * C; q += kWave) blk[q] = srow[q];
   }
 }
 
@@ -2022,23 +1628,26 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     }
 #define SMESH_FT(K)                                                                           \
     switch (tri_ct) {                                                                         \
-      case 5:  if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<5, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<5, K, true, 1>), grid, block, 0, st, t, t); break;     \
-      case 13: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<13, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<13, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 19: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<19, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<19, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 20: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<20, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<20, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 21: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<21, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<21, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 40: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<40, K, true, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<40, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 8:  if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<8, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<8, K, false, 1>), grid, block, 0, st, t, t); break;    \
-      case 16: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<16, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<16, K, false, 1>), grid, block, 0, st, t, t); break;   \
-      case 24: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<24, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<24, K, false, 1>), grid, block, 0, st, t, t); break;   \
-      case 32: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<32, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<32, K, false, 1>), grid, block, 0, st, t, t); break;   \
-      case 41: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<40, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<40, K, false, 1>), grid, block, 0, st, t, t); break;   \
-      case 48: if (nviews == 2) hipLaunchKernelGGL((k_fuse_tri<48, K, false, 2>), grid, block, 0, st, t, tb); else hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K, true, 1>), grid, block, 0, st, t, t); break;     \
+      case 13: hipLaunchKernelGGL((k_fuse_tri<13, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 19: hipLaunchKernelGGL((k_fuse_tri<19, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 20: hipLaunchKernelGGL((k_fuse_tri<20, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 21: hipLaunchKernelGGL((k_fuse_tri<21, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 40: hipLaunchKernelGGL((k_fuse_tri<40, K, true, 1>), grid, block, 0, st, t, t); break;    \
+      case 8:  hipLaunchKernelGGL((k_fuse_tri<8, K, false, 1>), grid, block, 0, st, t, t); break;    \
+      case 16: hipLaunchKernelGGL((k_fuse_tri<16, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 24: hipLaunchKernelGGL((k_fuse_tri<24, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, t); break;   \
       default:                                                                                \
         if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                               \
         hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, pw, amax);             \
         break;                                                                                \
     }
+    if (nviews == 2) {   // the two-view instances of k_fuse_tri live in fusion_pair.hip
+      smesh_launch_fuse_tri_pair(a->kind, tri_ct, grid, st, t, tb);
+    } else
     switch (a->kind) {
       case SMESH_AGG_SUM: SMESH_FT(SMESH_AGG_SUM); break;
       case SMESH_AGG_SUMMAX: SMESH_FT(SMESH_AGG_SUMMAX); break;
