@@ -53,7 +53,7 @@ def allreduce_raw(aggregator, group=None):
     return aggregator
 
 
-def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None, contiguous=True):
+def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None, contiguous=True, batch=8):
     """Fuse this rank's share of `cameras` and all-reduce.  `probs_of_view(k)` returns the (W,H,C)
     class-probability image of view k (host or device)."""
     dist = _dist()
@@ -61,7 +61,14 @@ def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None,
         rank, world = dist.get_rank(group), dist.get_world_size(group)
     else:
         rank, world = 0, 1
-    for k in shard_views(len(cameras), rank, world, contiguous):
-        idx, _ = renderer.render(cameras[k])
-        aggregator.add(idx, probs_of_view(k))
+    mine = list(shard_views(len(cameras), rank, world, contiguous))
+    if hasattr(aggregator, "fuse_views"):
+        # eight views per call: the library shares rasteriser launches between them and fuses them two by two
+        for b in range(0, len(mine), batch):
+            ks = mine[b:b + batch]
+            aggregator.fuse_views(renderer, [cameras[k] for k in ks], [probs_of_view(k) for k in ks])
+    else:
+        for k in mine:
+            idx, _ = renderer.render(cameras[k])
+            aggregator.add(idx, probs_of_view(k))
     return allreduce_raw(aggregator, group)

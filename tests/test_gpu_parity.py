@@ -1031,3 +1031,29 @@ def test_fuse_views_shuffled_faces_and_fallbacks(sm, oracle):
     with pytest.raises(ValueError):
         agg.fuse_views(tr, tcams, probs[:2])
     agg.fuse_views(tr, [], [])
+
+
+def test_fuse_views_sharded_on_the_device(sm, oracle):
+    """distributed.fuse_views_sharded with the HIP aggregator hands this rank's views over eight per call (fuse_views); without a
+    process group it is the whole job: equal to fusing every view, host or device images alike."""
+    from semantic_meshes_amd import distributed as smdist
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(120, 60, 320, 240, views=11)
+    P, C = len(mesh.faces), 19
+    rng = np.random.default_rng(11)
+    probs = [random_probs(rng, *cam.resolution, C) for cam in cams]
+    dprobs = [to_device(p) for p in probs]
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    agg, hagg = sm.fusion.MeshAggregator(P, C), sm.fusion.MeshAggregator(P, C)
+    smdist.fuse_views_sharded(r, agg, cams, lambda k: dprobs[k], batch=4)
+    smdist.fuse_views_sharded(r, hagg, cams, lambda k: probs[k])
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C)
+        for k, cam in enumerate(cams):
+            oagg.add(o.render(cam)[0], probs[k])
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(hagg.get(), oagg.get(), rtol=2e-5)
+    finally:
+        oracle.set_accum_double(False)
