@@ -1457,9 +1457,10 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   return SMESH_OK;
 }
 
-// A batch of views: smesh_fuse_view for each of them, in order -- except that two consecutive views of a triangle renderer
-// with device-resident class vectors are fused by ONE launch (k_fuse_tri<.., 2>: every 64-row accumulator block makes one
-// round trip for both views; same additions in the same order as two calls).  Asynchronous like smesh_fuse_view.
+// A batch of views: smesh_fuse_view for each of them, in order -- except that, with device-resident class vectors, up to
+// kMaxGroup views share each rasteriser launch, and two consecutive views of a triangle renderer are fused by ONE launch
+// (k_fuse_tri<.., 2>: every 64-row accumulator block makes one round trip for both views; same additions in the same order
+// as two calls).  Asynchronous like smesh_fuse_view.
 int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cams, uint64_t n,
                      const float* const* probs, const float* const* weights, int memkind) {
   if (!r || !a || (n && (!cams || !probs))) return fail(SMESH_ERR_INVALID, "NULL argument");
@@ -1476,9 +1477,16 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
     pairable = !pairs_off && memkind == SMESH_MEM_DEVICE && !r->texels && r->F != 0 && smesh_aggregator_can_fuse_triangles(a, r->F) &&
                smesh_aggregator_can_fuse_pair(a);
   }
+  static const bool raster_pairs_off = getenv("SMESH_RASTER_PAIRS") && atoi(getenv("SMESH_RASTER_PAIRS")) == 0;
+  static const int group_max = getenv("SMESH_RASTER_GROUP") ? std::min(kMaxGroup, std::max(2, atoi(getenv("SMESH_RASTER_GROUP")))) : kMaxGroup;
   uint64_t i = 0;
   while (i < n) {
-    if (!pairable || i + 1 >= n) {
+    // Rasterise a GROUP of the remaining views with one launch per stage (any renderer, any aggregator, device images), then
+    // fuse them two by two where the aggregator has the two-view kernel, else one by one.
+    int gn = (int)std::min<uint64_t>((uint64_t)group_max, n - i);
+    bool grouped = !raster_pairs_off && memkind == SMESH_MEM_DEVICE && r->F != 0 && r->V != 0 && gn >= 2;
+    for (int v = 0; v < gn && grouped; v++) grouped = queues_fit_group(cams[i + v].width, cams[i + v].height);
+    if ((!pairable && !grouped) || i + 1 >= n) {
       SMESH_TRY(smesh_fuse_view(r, a, &cams[i], probs[i], weights ? weights[i] : nullptr, memkind));
       i += 1;
       continue;
@@ -1492,12 +1500,6 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
       r->raster_pending = false;
     }
     r->main_pending = true;   // the renderer's scratch is in use on the main stream
-    // Rasterise a GROUP of the remaining views with one launch per stage, then fuse them two by two.
-    static const bool raster_pairs_off = getenv("SMESH_RASTER_PAIRS") && atoi(getenv("SMESH_RASTER_PAIRS")) == 0;
-    static const int group_max = getenv("SMESH_RASTER_GROUP") ? std::min(kMaxGroup, std::max(2, atoi(getenv("SMESH_RASTER_GROUP")))) : kMaxGroup;
-    int gn = (int)std::min<uint64_t>((uint64_t)group_max, n - i);
-    bool grouped = !raster_pairs_off && r->V != 0;
-    for (int v = 0; v < gn && grouped; v++) grouped = queues_fit_group(cams[i + v].width, cams[i + v].height);
     if (grouped) {
       SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->stream));
     } else {   // images too large for kMaxGroup sets of fragment queues, direct rasteriser, or SMESH_RASTER_PAIRS=0: one view at a time
@@ -1513,7 +1515,12 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
         SMESH_TRY(render_into(r, &cams[i + v], static_cast<uint32_t*>(r->fused[v].ptr), /*d_depth=*/nullptr, ctx->stream, v));
       }
     }
-    for (int j = 0; j < gn; j += 2) {
+    for (int j = 0; j < gn && !pairable; j++) {   // texel renderers, class counts beyond k_fuse_tri, foreign primitive counts
+      const uint64_t k = i + (uint64_t)j;
+      SMESH_TRY(fuse_rendered(r, a, j, static_cast<const uint32_t*>(r->fused[j].ptr), probs[k], weights ? weights[k] : nullptr,
+                              SMESH_MEM_DEVICE, cams[k].width, cams[k].height));
+    }
+    for (int j = 0; j < gn && pairable; j += 2) {
       const int nv = std::min(2, gn - j);
       RenderedView rv[2];
       for (int v = 0; v < nv; v++) {
@@ -1524,7 +1531,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
       }
       SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
     }
-    g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
+    if (pairable) g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
     r->fused_seq += (uint64_t)gn;
     i += (uint64_t)gn;
   }

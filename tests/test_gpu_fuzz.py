@@ -99,14 +99,21 @@ def test_random_texel_soup_against_oracle(sm, oracle, seed):
     oracle.set_accum_double(True)
     try:
         oagg = oracle.OracleAggregator(P, C, kind)
+        batch = []
         for cam in cams:
             idx, depth = r.render(cam)
             oidx, odepth = o.render(cam)
             np.testing.assert_array_equal(np.asarray(idx), oidx)
             np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
             probs = random_probs(rng, W, H, C, zero_fraction=0.1)
-            agg.fuse_view(r, cam, probs)
+            if seed % 2:
+                batch.append(probs)                                   # odd seeds: all views in one fuse_views call (grouped rasteriser launches)
+            else:
+                agg.fuse_view(r, cam, probs)
             oagg.add(oidx, probs)
+        if batch:
+            from semantic_meshes_amd.device import to_device
+            agg.fuse_views(r, cams, [to_device(p) for p in batch])
         assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)
