@@ -596,7 +596,7 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
   }
 }
 
-__global__ __launch_bounds__(256) void k_raster_frag(RasterArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_raster_frag(RasterArgs a) {
   raster_frag_wave(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 }
 
@@ -607,7 +607,7 @@ struct RasterGroup {
   uint32_t tile_end[kMaxGroup];   // ... whose tiles are blocks [tile_end[v-1], tile_end[v])
   uint32_t n, blocks_per_view;
 };
-__global__ __launch_bounds__(256) void k_raster_frag_group(RasterGroup g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_raster_frag_group(RasterGroup g) {
   const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
   raster_frag_wave(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
 }
