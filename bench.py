@@ -173,8 +173,9 @@ def main():
     if os.environ.get("SMESH_BENCH_NO_PROFILE"):   # experiment: what do the HIP events around the kernel cost?
         prof_mask = 0
     # HIP events on the library's stream around every 8th launch of the dominant kernel (an event pair costs ~4 us
-    # of stream time = 4 % of a view, so not every launch is bracketed)
-    _lib.check(_lib.lib().smesh_profile_sample_every(device, int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8"))))
+    # of stream time = 4 % of a view, so not every launch is bracketed); with fuse_views around every 2nd group's
+    # back-to-back fusion launches (four launches of two views each for a group of eight)
+    _lib.check(_lib.lib().smesh_profile_sample_every(device, int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "2"))))
     _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
     barrier()
     t0 = time.perf_counter()
@@ -200,14 +201,17 @@ def main():
     scatter_ms, scatter_n = prof_read(device, _lib.PROF_FUSE_SCATTER)
     regions = ctypes.c_uint64()
     _lib.check(_lib.lib().smesh_profile_regions(device, _lib.PROF_FUSE_SCATTER, ctypes.byref(regions)))
-    views_per_launch = args.steps / max(int(regions.value), 1) if prof_mask else 1.0   # 2 when fuse_views pairs the views
+    # fuse_views times the back-to-back fusion launches of a group of views as ONE region (two views per launch)
+    views_per_region = args.steps / max(int(regions.value), 1) if prof_mask else 1.0
+    launches_per_region = max(1, int(round(views_per_region / 2.0))) if views_per_region > 1.5 else 1
+    views_per_launch = views_per_region / launches_per_region
     hist_ms, hist_n = prof_read(device, _lib.PROF_FUSE_HIST)
     raster_ms, raster_n = prof_read(device, _lib.PROF_RASTER)
 
     if rank == 0:
         N = W * H
         bytes_per_view = 4 * N + 4 * N * C + 8 * C * T_mean       # idx + probs + accumulator RMW
-        t_kernel = scatter_ms * 1e-3 / max(scatter_n, 1)
+        t_kernel = scatter_ms * 1e-3 / max(scatter_n, 1) / launches_per_region
         bytes_per_launch = bytes_per_view * views_per_launch
         achieved = bytes_per_launch / t_kernel / 1e9 if t_kernel > 0 else 0.0
         traffic = None
@@ -245,7 +249,8 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch),
                          "views_per_launch": round(views_per_launch, 3),
-                         "avg_launch_us": round(1e6 * t_kernel, 2), "launches_timed": scatter_n,
+                         "avg_launch_us": round(1e6 * t_kernel, 2), "launches_timed": scatter_n * launches_per_region,
+                         "launches_per_timed_region": launches_per_region,
                          "distinct_primitives_per_view": int(T_mean),
                          "other_kernels_us_per_view": ({"histogram+pixel_weights": round(1e3 * hist_ms / max(args.steps, 1), 2),
                                                         "raster": round(1e3 * raster_ms / max(raster_n, 1) / views_per_launch, 2)}

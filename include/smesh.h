@@ -205,7 +205,9 @@ int smesh_profile_enable(int device, int slot_mask);
  * time, 4 % of a cfg2 view.  `launches` of smesh_profile_read counts the bracketed regions. */
 int smesh_profile_sample_every(int device, uint32_t n);
 int smesh_profile_read(int device, int slot, double* total_ms, uint64_t* launches);
-/* Regions of the slot entered while it was enabled, bracketed or not (with one kernel launch per region: launches). */
+/* Regions of the slot entered while it was enabled, bracketed or not.  A region is one kernel launch, except that smesh_fuse_views
+ * makes ONE region of the back-to-back fusion launches of a group of views (an event pair around a single launch adds the dispatch
+ * latency that back-to-back launches hide). */
 int smesh_profile_regions(int device, int slot, uint64_t* entered);
 int smesh_profile_reset(int device);
 

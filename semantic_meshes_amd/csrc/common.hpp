@@ -34,6 +34,7 @@ struct ProfSlot {
   double total_ms = 0.0;
   uint64_t launches = 0;
   uint64_t seen = 0;   // regions entered while the slot was enabled (only every `profile_every`-th is bracketed)
+  int depth = 0;       // > 0 inside a region of this slot: nested regions belong to it (back-to-back launches timed together)
 };
 
 // One per GPU: a compute stream all of this library's kernels and copies are ordered on.
@@ -57,6 +58,7 @@ struct ProfScope {
   int slot;
   hipEvent_t start = nullptr, stop = nullptr;
   hipStream_t st;
+  bool counted = false;   // this scope opened a region (as opposed to: profiling off, or nested in an open region)
   ProfScope(DeviceCtx* c, int s, hipStream_t stream = nullptr);
   ~ProfScope();
 };

@@ -55,6 +55,8 @@ int get_ctx(int device, DeviceCtx** out) {
 ProfScope::ProfScope(DeviceCtx* c, int s, hipStream_t stream) : ctx(c), slot(s), st(stream ? stream : c->stream) {
   if (!(ctx->profiling & (1u << slot))) return;
   ProfSlot& ps = ctx->slots[slot];
+  if (ps.depth++ > 0) { counted = true; return; }   // inside an open region of this slot
+  counted = true;
   if (ps.seen++ % std::max(1u, ctx->profile_every) != 0) return;
   if (!ps.pool.empty()) {
     start = ps.pool.back().first;
@@ -70,6 +72,7 @@ ProfScope::ProfScope(DeviceCtx* c, int s, hipStream_t stream) : ctx(c), slot(s),
 }
 
 ProfScope::~ProfScope() {
+  if (counted) ctx->slots[slot].depth--;
   if (!start) return;
   (void)hipEventRecord(stop, st);
   ctx->slots[slot].pending.emplace_back(start, stop);

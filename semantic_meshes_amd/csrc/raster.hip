@@ -1520,16 +1520,21 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
       SMESH_TRY(fuse_rendered(r, a, j, static_cast<const uint32_t*>(r->fused[j].ptr), probs[k], weights ? weights[k] : nullptr,
                               SMESH_MEM_DEVICE, cams[k].width, cams[k].height));
     }
-    for (int j = 0; j < gn && pairable; j += 2) {
-      const int nv = std::min(2, gn - j);
-      RenderedView rv[2];
-      for (int v = 0; v < nv; v++) {
-        const smesh_renderer::Side& sd = r->side[j + v];
-        const uint64_t k = i + (uint64_t)(j + v);
-        rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[j + v].ptr), probs[k],
-                             weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
+    // the fusion launches of a group are back to back: one timed region for all of them (smesh_profile_*: a HIP event pair around a
+    // single launch adds the dispatch latency that back-to-back launches hide)
+    if (pairable) {
+      ProfScope fuse_region(ctx, SMESH_PROF_FUSE_SCATTER);
+      for (int j = 0; j < gn; j += 2) {
+        const int nv = std::min(2, gn - j);
+        RenderedView rv[2];
+        for (int v = 0; v < nv; v++) {
+          const smesh_renderer::Side& sd = r->side[j + v];
+          const uint64_t k = i + (uint64_t)(j + v);
+          rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[j + v].ptr), probs[k],
+                               weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
+        }
+        SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
       }
-      SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
     }
     if (pairable) g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
     r->fused_seq += (uint64_t)gn;
