@@ -71,11 +71,7 @@ struct CameraArgs {
 
 // ---- vertex stage: float32 rigid transform, double pinhole projection (render/Camera.h:9-13) --------
 // Also opens the render: empties the big-triangle queue (its length stays readable until the next render).
-__device__ __forceinline__ void project_vertex(const float* __restrict__ verts, uint64_t V, const CameraArgs& cam,
-                                               ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count, const uint64_t i) {
-  if (i == 0) { big_count[0] = 0u; big_count[2] = 0u; }
-  if (i >= V) return;
-  const float X = verts[3 * i + 0], Y = verts[3 * i + 1], Z = verts[3 * i + 2];
+__device__ __forceinline__ ScreenVertex project_point(const CameraArgs& cam, const float X, const float Y, const float Z) {
   const float xc = ((cam.R[0] * X + cam.R[1] * Y) + cam.R[2] * Z) + cam.t[0];
   const float yc = ((cam.R[3] * X + cam.R[4] * Y) + cam.R[5] * Z) + cam.t[1];
   const float zc = ((cam.R[6] * X + cam.R[7] * Y) + cam.R[8] * Z) + cam.t[2];
@@ -89,7 +85,14 @@ __device__ __forceinline__ void project_vertex(const float* __restrict__ verts, 
       s.u = u; s.v = v; s.iz = 1.0 / zd;
     }
   }
-  sv[i] = s;
+  return s;
+}
+
+__device__ __forceinline__ void project_vertex(const float* __restrict__ verts, uint64_t V, const CameraArgs& cam,
+                                               ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count, const uint64_t i) {
+  if (i == 0) { big_count[0] = 0u; big_count[2] = 0u; }
+  if (i >= V) return;
+  sv[i] = project_point(cam, verts[3 * i + 0], verts[3 * i + 1], verts[3 * i + 2]);
 }
 
 __global__ void k_project_vertices(const float* __restrict__ verts, uint64_t V, CameraArgs cam,
@@ -97,8 +100,8 @@ __global__ void k_project_vertices(const float* __restrict__ verts, uint64_t V, 
   project_vertex(verts, V, cam, sv, big_count, (uint64_t)blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// Up to kMaxGroup views of the same mesh in one launch (smesh_fuse_views): blocks [v * blocks_per_view, (v + 1) * blocks_per_view)
-// project for camera v.
+// Up to kMaxGroup views of the same mesh in one launch (smesh_fuse_views): a thread reads its vertex once and projects it for
+// every camera of the group.
 constexpr int kMaxGroup = 8;
 struct ProjectGroup {
   const float* verts;
@@ -106,11 +109,15 @@ struct ProjectGroup {
   CameraArgs cam[kMaxGroup];
   ScreenVertex* sv[kMaxGroup];
   uint32_t* big_count[kMaxGroup];
-  uint32_t blocks_per_view;
+  uint32_t n;
 };
 __global__ void k_project_vertices_group(ProjectGroup g) {
-  const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
-  project_vertex(g.verts, g.V, g.cam[v], g.sv[v], g.big_count[v], (uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x);
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0)
+    for (uint32_t v = 0; v < g.n; v++) { g.big_count[v][0] = 0u; g.big_count[v][2] = 0u; }
+  if (i >= g.V) return;
+  const float X = g.verts[3 * i + 0], Y = g.verts[3 * i + 1], Z = g.verts[3 * i + 2];
+  for (uint32_t v = 0; v < g.n; v++) g.sv[v][i] = project_point(g.cam[v], X, Y, Z);
 }
 
 // ---- triangle setup --------------------------------------------------------------------------------
@@ -1013,11 +1020,11 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     rg.tile_end[v] = tiles;
   }
   pg.verts = r->verts; pg.V = r->V;
-  pg.blocks_per_view = (uint32_t)div_up(r->V, 256);
+  pg.n = (uint32_t)n;
   rg.n = (uint32_t)n;
   rg.blocks_per_view = (uint32_t)div_up(div_up(r->F, rg.view[0].tpw), 4);
   ProfScope prof(ctx, SMESH_PROF_RASTER, st);
-  hipLaunchKernelGGL(k_project_vertices_group, dim3((uint32_t)n * pg.blocks_per_view), dim3(256), 0, st, pg);
+  hipLaunchKernelGGL(k_project_vertices_group, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, pg);
   SMESH_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_raster_frag_group, dim3((uint32_t)n * rg.blocks_per_view), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
