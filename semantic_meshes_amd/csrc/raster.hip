@@ -1282,13 +1282,19 @@ int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_
   // max projected area over all cameras: an F x K reduction, done on the GPU
   std::vector<float> best(F, 0.0f);
   if (F && K) {
+    // The area is taken from the faces in the CALLER's vertex order, as the reference does (:100-127 come before the
+    // re-ordering of :129-146): the float32 area expression is not invariant under permutations of the three vertices, and
+    // ceil() turns a last-bit difference into one more texel row.
     smesh_camera_t* d_cams = nullptr;
     float* d_best = nullptr;
+    int32_t* d_faces = nullptr;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cams), K * sizeof(smesh_camera_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_best), F * 4);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_faces), F * 12);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cams, cameras, K * sizeof(smesh_camera_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(k_texel_area, dim3((uint32_t)div_up(F, 128)), dim3(128), 0, ctx->stream, r->verts, r->faces, F, V,
+      hipLaunchKernelGGL(k_texel_area, dim3((uint32_t)div_up(F, 128)), dim3(128), 0, ctx->stream, r->verts, d_faces, F, V,
                          d_cams, (uint32_t)K, d_best);
       e = hipGetLastError();
     }
@@ -1296,6 +1302,7 @@ int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (d_cams) (void)hipFree(d_cams);
     if (d_best) (void)hipFree(d_best);
+    if (d_faces) (void)hipFree(d_faces);
     if (e != hipSuccess) { smesh_renderer_destroy(r); return fail_hip(e, "texel area reduction", __FILE__, __LINE__); }
   }
   uint64_t total = 0;
