@@ -22,9 +22,17 @@ for a, b in [(1000, 500), (700, 350), (500, 250), (300, 150), (100, 50), (30, 15
             agg.fuse_view(r, cam, probs)
     _lib.synchronize(0)
     dt = (time.perf_counter() - t0) / (reps * len(cams))
+    for cam in cams[:2]:
+        agg.fuse_views(r, cams, [probs] * len(cams))
+    _lib.synchronize(0)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        agg.fuse_views(r, cams, [probs] * len(cams))
+    _lib.synchronize(0)
+    dv = (time.perf_counter() - t0) / (reps * len(cams))
     t0 = time.perf_counter()
     for cam in cams:
         r.render(cam)
     _lib.synchronize(0)
     dr = (time.perf_counter() - t0) / len(cams)
-    print("%8d triangles: fuse_view %8.3f ms/view   (render alone %7.3f ms)" % (len(mesh.faces), 1e3 * dt, 1e3 * dr), flush=True)
+    print("%8d triangles: fuse_view %8.3f ms/view   fuse_views (8 per call) %8.3f ms/view   (render alone %7.3f ms)" % (len(mesh.faces), 1e3 * dt, 1e3 * dv, 1e3 * dr), flush=True)
