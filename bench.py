@@ -162,6 +162,14 @@ def main():
                 j = min(i + B, last)
                 agg.fuse_views(renderer, cams[i:j], probs[i:j])
 
+    # One untimed call with a full batch before anything else: the library allocates the per-view state of a group (fragment
+    # queues, projected vertices, index planes: ~240 MB per view slot at this size) the first time a group of that many views
+    # arrives, and that must not fall into the timed region when W is smaller than the batch.
+    if B > 1:
+        prime = [i % total_views for i in range(B)]
+        agg.fuse_views(renderer, [cams[i] for i in prime], [probs[i] for i in prime])
+        agg.fuse_view(renderer, cams[0], probs[0])     # a trailing odd view takes the one-view kernels: load them too
+        _lib.synchronize(device)
     fuse_range(0, args.warmup)
     if dist is not None:   # untimed: RCCL builds its communicator / channels for this message size on first use
         _lib.synchronize(device)
