@@ -58,6 +58,16 @@ __device__ __forceinline__ float wave_sum(float v) {   // same value in every la
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+__device__ __forceinline__ uint32_t wave_scan_incl_u(uint32_t v) {   // lane l: v[0] + .. + v[l]
+  v += dpp_u<kDppRowShr1>(0u, v);
+  v += dpp_u<kDppRowShr2>(0u, v);
+  v += dpp_u<kDppRowShr4>(0u, v);
+  v += dpp_u<kDppRowShr8>(0u, v);
+  v += dpp_u<kDppRowBcast15, 0xA>(0u, v);
+  v += dpp_u<kDppRowBcast31, 0xC>(0u, v);
+  return v;
+}
+
 __device__ __forceinline__ uint32_t wave_sum_u(uint32_t v) {
   v += dpp_u<kDppRowShr1>(0u, v);
   v += dpp_u<kDppRowShr2>(0u, v);
@@ -107,7 +117,8 @@ __device__ __forceinline__ void load_row(const float* __restrict__ pr, int C, fl
 // One triangle of one view, its pixels found by scanning the box [x0, x1] x [y0, y1] of the index image: one WAVE, lanes
 // over the box; per-lane partial sums are combined by a butterfly over the wave and lane c owns class c of the row.
 template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f, const int x0, const int y0, const int x1, const int y1) {
+__device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f, const int x0, const int y0, const int x1, const int y1,
+                                         uint32_t* __restrict__ lds_list) {
   const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
   const int l = threadIdx.x;
   const int bh = y1 - y0 + 1;
@@ -115,7 +126,8 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
   // U pixels per lane and step: their index loads, then their class vectors, are in flight together
   constexpr int U = CT <= 24 ? 4 : 2;
   auto pix_of = [&](long long i) -> uint64_t { return (uint64_t)(x0 + (int)(i / bh)) * a.H + (uint64_t)(y0 + (int)(i % bh)); };
-  uint32_t n = 0;
+  const bool one_step = npx <= (long long)kWave * U;   // the whole box in one round of index loads
+  uint32_t mine_n = 0, hits = 0;                        // this lane's pixels of the triangle (bit u of `hits`: slot u of the one round)
   for (long long base = 0; base < npx; base += (long long)kWave * U) {
     uint32_t v[U];
 #pragma unroll
@@ -125,49 +137,68 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
       if (!(i < npx)) v[u] = ~f;
     }
 #pragma unroll
-    for (int u = 0; u < U; u++) n += v[u] == f ? 1u : 0u;
+    for (int u = 0; u < U; u++) if (v[u] == f) { mine_n++; hits |= 1u << u; }
   }
-  n = wave_sum_u(n);
+  const uint32_t upto = wave_scan_incl_u(mine_n);
+  const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
   if (n == 0) return;
   const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
   float part[CT];
 #pragma unroll
   for (int c = 0; c < CT; c++) part[c] = 0.0f;
-  for (long long base = 0; base < npx; base += (long long)kWave * U) {
-    uint64_t pix[U];
-    bool hit[U];
+  auto accumulate = [&](const float (&p)[CT], const bool hit, const float wt) {
+    float sum = 0.0f;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const long long i = base + (long long)u * kWave + l;
-      pix[u] = i < npx ? pix_of(i) : pix_of(0);
-      hit[u] = a.idx[pix[u]] == f && i < npx;
+    for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[c];
+    if (!(hit && sum > 0.5f)) return;
+    const float w = w0 * wt;
+    if (KIND == SMESH_AGG_SUMMAX) {
+      float best = p[0];
+      int am = 0;
+#pragma unroll
+      for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[c] > best) { best = p[c]; am = c; }
+#pragma unroll
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] = (c == am) ? part[c] + p[c] * w : part[c];
+    } else {
+#pragma unroll
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] += contribution<KIND>(p[c], w);
     }
-    float p[U][CT];
-    float wt[U];
+  };
+  if (one_step && n <= (uint32_t)kWave) {
+    // Boxes of a few hundred pixels with at most 64 of them visible (the usual triangle just over the 8 x 8 limit): the hits are
+    // compacted through LDS -- lane j takes the j-th visible pixel -- so every lane loads ONE class vector instead of U.
+    uint32_t at = upto - mine_n;
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      const float* __restrict__ pr = a.probs + (hit[u] ? pix[u] : pix_of(0)) * C;   // unconditional: the loads overlap
-      load_row<CT, EXACT>(pr, C, p[u]);
-      wt[u] = (a.weights && hit[u]) ? a.weights[pix[u]] : 1.0f;
-    }
+    for (int u = 0; u < U; u++)
+      if (hits & (1u << u)) lds_list[at++] = (uint32_t)pix_of((long long)u * kWave + l);   // pixel indices fit 32 bits (W, H <= 65536)
+    wave_sync();
+    const bool hit = (uint32_t)l < n;
+    const uint64_t pix = lds_list[hit ? l : 0];
+    wave_sync();   // the list is rewritten by this wave's next triangle
+    float p[CT];
+    load_row<CT, EXACT>(a.probs + pix * C, C, p);
+    const float wt = (a.weights && hit) ? a.weights[pix] : 1.0f;
+    accumulate(p, hit, wt);
+  } else {
+    for (long long base = 0; base < npx; base += (long long)kWave * U) {
+      uint64_t pix[U];
+      bool hit[U];
 #pragma unroll
-    for (int u = 0; u < U; u++) {
-      float sum = 0.0f;
-#pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) sum = sum + p[u][c];
-      if (!(hit[u] && sum > 0.5f)) continue;
-      const float w = w0 * wt[u];
-      if (KIND == SMESH_AGG_SUMMAX) {
-        float best = p[u][0];
-        int am = 0;
-#pragma unroll
-        for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[u][c] > best) { best = p[u][c]; am = c; }
-#pragma unroll
-        for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] = (c == am) ? part[c] + p[u][c] * w : part[c];
-      } else {
-#pragma unroll
-        for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] += contribution<KIND>(p[u][c], w);
+      for (int u = 0; u < U; u++) {
+        const long long i = base + (long long)u * kWave + l;
+        pix[u] = i < npx ? pix_of(i) : pix_of(0);
+        hit[u] = a.idx[pix[u]] == f && i < npx;
       }
+      float p[U][CT];
+      float wt[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const float* __restrict__ pr = a.probs + (hit[u] ? pix[u] : pix_of(0)) * C;   // unconditional: the loads overlap
+        load_row<CT, EXACT>(pr, C, p[u]);
+        wt[u] = (a.weights && hit[u]) ? a.weights[pix[u]] : 1.0f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) accumulate(p[u], hit[u], wt[u]);
     }
   }
   float mine = 0.0f;
@@ -182,14 +213,14 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
 // Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle (so, unlike the small-triangle
 // path, the summation order is a tree).  Runs in the tail blocks of k_fuse_tri.
 template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers) {
+__device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers, uint32_t* __restrict__ lds_list) {
   const uint32_t nbig = min(*a.big_len, a.big_capacity);
   for (uint32_t q = worker; q < nbig; q += nworkers) {
     const uint32_t fi = a.big_queue[q];                       // position in the renderer's triangle order
     const TriFrag rec = a.frags[fi];
     if (rec.kind != 2) continue;
     const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
-    fuse_box<CT, KIND, EXACT>(a, f, rec.x0, rec.y0, (int)(rec.mask & 0xFFFFu), (int)((rec.mask >> 16) & 0xFFFFu));
+    fuse_box<CT, KIND, EXACT>(a, f, rec.x0, rec.y0, (int)(rec.mask & 0xFFFFu), (int)((rec.mask >> 16) & 0xFFFFu), lds_list);
   }
 }
 
@@ -197,7 +228,8 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_
 // first, as two calls would do it), so that no other wave touches its row; its small view is scanned as an 8 x 8 box.
 // A triangle queued by both views is taken from the first view's queue only.
 template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_big_triangles_pair(const TriFuseArgs& a, const TriFuseArgs& b, uint32_t worker, uint32_t nworkers) {
+__device__ __forceinline__ void fuse_big_triangles_pair(const TriFuseArgs& a, const TriFuseArgs& b, uint32_t worker, uint32_t nworkers,
+                                                        uint32_t* __restrict__ lds_list) {
   const uint32_t na = min(*a.big_len, a.big_capacity), nb = min(*b.big_len, b.big_capacity);
   for (uint32_t q = worker; q < na + nb; q += nworkers) {
     const bool second = q >= na;
@@ -213,7 +245,7 @@ __device__ __forceinline__ void fuse_big_triangles_pair(const TriFuseArgs& a, co
       int x1, y1;
       if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
       else { x1 = min((int)rec.x0 + 7, (int)v.W - 1); y1 = min((int)rec.y0 + 7, (int)v.H - 1); }
-      fuse_box<CT, KIND, EXACT>(v, f, rec.x0, rec.y0, x1, y1);
+      fuse_box<CT, KIND, EXACT>(v, f, rec.x0, rec.y0, x1, y1, lds_list);
     }
   }
 }
@@ -228,8 +260,9 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b
   __shared__ __attribute__((aligned(16))) float srow[kWave * CT + 4];   // the wave's 64 accumulator rows
   const int l = threadIdx.x;
   if (blockIdx.x >= a.tri_blocks) {   // tail blocks: the queued big triangles
-    if (NV == 2) fuse_big_triangles_pair<CT, KIND, EXACT>(a, b, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
-    else fuse_big_triangles<CT, KIND, EXACT>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks);
+    uint32_t* lds_list = reinterpret_cast<uint32_t*>(srow);   // the tail waves have no use for the row block: >= 64 entries
+    if (NV == 2) fuse_big_triangles_pair<CT, KIND, EXACT>(a, b, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, lds_list);
+    else fuse_big_triangles<CT, KIND, EXACT>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, lds_list);
     return;
   }
   const uint64_t f0 = (uint64_t)blockIdx.x * kWave;

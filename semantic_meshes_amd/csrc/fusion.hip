@@ -1605,7 +1605,8 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     }
     t.tri_blocks = wide_chunks ? (uint32_t)div_up(F, kWave) : (uint32_t)div_up(F, kWave / G);
   }
-  const uint32_t big_waves = 12u * (uint32_t)std::max(1, ctx->num_cus);    // one wave per queued big triangle at a time; they exit at once if the queue is empty
+  static const uint32_t big_per_cu = getenv("SMESH_BIG_WAVES") ? (uint32_t)std::max(1, atoi(getenv("SMESH_BIG_WAVES"))) : 16u;
+  const uint32_t big_waves = big_per_cu * (uint32_t)std::max(1, ctx->num_cus);    // one wave per queued big triangle at a time; they exit at once if the queue is empty
   const dim3 grid(t.tri_blocks + big_waves), block(kWave);
   const dim3 tgrid(t.tri_blocks), bgrid(big_waves);                        // any-C paths: big triangles in a second launch
   {
