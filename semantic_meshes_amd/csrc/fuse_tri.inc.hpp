@@ -126,6 +126,8 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
   // U pixels per lane and step: their index loads, then their class vectors, are in flight together
   constexpr int U = CT <= 24 ? 4 : 2;
   auto pix_of = [&](long long i) -> uint64_t { return (uint64_t)(x0 + (int)(i / bh)) * a.H + (uint64_t)(y0 + (int)(i % bh)); };
+  // this wave owns the row: its current value is requested now and written back at the end (plain read-modify-write)
+  const float row_value = (l < C) ? a.acc[(uint64_t)f * C + l] : 0.0f;
   const bool one_step = npx <= (long long)kWave * U;   // the whole box in one round of index loads
   uint32_t mine_n = 0, hits = 0;                        // this lane's pixels of the triangle (bit u of `hits`: slot u of the one round)
   for (long long base = 0; base < npx; base += (long long)kWave * U) {
@@ -179,6 +181,20 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
     load_row<CT, EXACT>(a.probs + pix * C, C, p);
     const float wt = (a.weights && hit) ? a.weights[pix] : 1.0f;
     accumulate(p, hit, wt);
+    // part[] is now ONE pixel's contribution per lane: instead of a butterfly per class (6 DPP steps each), the n vectors go
+    // through LDS as rows and lane c adds up column c, in the order of the compacted list
+    float* rows = reinterpret_cast<float*>(lds_list);
+    if (hit) {
+#pragma unroll
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) rows[l * C + c] = part[c];
+    }
+    wave_sync();
+    float col = 0.0f;
+    if (l < C)
+      for (uint32_t j = 0; j < n; j++) col += rows[j * (uint32_t)C + (uint32_t)l];
+    wave_sync();   // the rows are rewritten by this wave's next triangle
+    if (l < C) a.acc[(uint64_t)f * C + l] = row_value + col;
+    return;
   } else {
     for (long long base = 0; base < npx; base += (long long)kWave * U) {
       uint64_t pix[U];
@@ -207,7 +223,7 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
     const float v = wave_sum(part[c]);
     if (l == c) mine = v;
   }
-  if (l < C) a.acc[(uint64_t)f * C + l] += mine;   // this wave owns the row: plain read-modify-write
+  if (l < C) a.acc[(uint64_t)f * C + l] = row_value + mine;
 }
 
 // Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle (so, unlike the small-triangle
