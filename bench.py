@@ -6,9 +6,14 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
 `python -m torch.distributed.run`, one rank per GPU.  A "step" is one pass of the hot path over one view:
 render(camera) -> add(indices, probs), with the view's class-probability image already resident in HBM (generated on
 the device before the timed region).  The views are handed to the library `--views-per-call` at a time
-(smesh_fuse_views: same results as one smesh_fuse_view call per view, but the two views of a pair share their kernel
-launches; `--views-per-call 1` makes one smesh_fuse_view call per view).  After the K steps of every rank the
-raw accumulators are summed with ONE all-reduce (RCCL), inside the timed region.  Rank 0 prints ONE JSON line.
+(smesh_fuse_views: same results as one smesh_fuse_view call per view, but the views of a group share their kernel
+launches; `--views-per-call 1` makes one smesh_fuse_view call per view).  After the K steps of every rank the raw
+accumulators are summed with ONE all-reduce (RCCL), inside the timed region: the native `smesh_allreduce`, enqueued on the
+library's own stream right behind the last fusion kernel (`SMESH_ALLREDUCE=torch` selects the torch.distributed plumbing
+instead).  The timed region contains exactly one host synchronisation: the closing barrier.  Rank 0 prints ONE JSON line.
+
+`--workload cfg4` (5 M triangles as texel primitives, 1296x968, 40 classes) and `--workload cfg5` (20 M triangles,
+4096x2160, 150 classes) run the other single-GPU BASELINE configs through the same code and print the same JSON.
 """
 import argparse
 import ctypes
@@ -23,15 +28,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from semantic_meshes_amd import _lib, fusion, render, synth  # noqa: E402
+from semantic_meshes_amd import comm as smcomm  # noqa: E402
 from semantic_meshes_amd import distributed as smdist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
+KERNEL_NOTES = {
+    "k_fuse_tri": "k_fuse_tri (triangle-order fusion: gather + accumulate, one owner per accumulator row)",
+    "k_fuse_tri_any": "k_fuse_tri_any (triangle-order fusion, row split over lane groups)",
+    "k_fuse_tri_wide": "k_fuse_tri_wide (triangle-order fusion, a row per wave: 128 <= C <= 1024)",
+    "k_fuse_texel": "k_fuse_texel (triangle-order fusion of texel primitives)",
+    "k_scatter_strip": "k_scatter_strip (segmented scatter-add)",
+}
+
 
 def prof_read(device, slot):
-    ms, n = ctypes.c_double(), ctypes.c_uint64()
-    _lib.check(_lib.lib().smesh_profile_read(device, slot, ctypes.byref(ms), ctypes.byref(n)))
-    return ms.value, int(n.value)
+    """(total ms, regions timed, dominant-kernel launches inside them, views those launches fused)"""
+    ms, r, n, v = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    _lib.check(_lib.lib().smesh_profile_read_ex(device, slot, ctypes.byref(ms), ctypes.byref(r), ctypes.byref(n), ctypes.byref(v)))
+    return ms.value, int(r.value), int(n.value), int(v.value)
 
 
 def cpu_baseline(workload, budget_s=20.0):
@@ -90,40 +105,91 @@ def cpu_baseline(workload, budget_s=20.0):
                               "sample": "%d views, %.1f s" % (done2, dt2)}}
 
 
+def host_path(renderer, agg, cams, W, H, C, device, views=6):
+    """The reference's usual calling convention (python/scripts/colorize_cityscapes_mesh.py:65-67): render(), then
+    add(DEVICE indices, HOST numpy probs) -- every view's class vectors cross PCIe (python/semantic_meshes/include/Common.h:14-21
+    accepts HOST or DEVICE).  Pageable numpy memory, and page-locked memory from the library.  Never `value`."""
+    from semantic_meshes_amd.device import pinned_empty
+    src = np.asarray(synth.device_probs(W, H, C, synth.probs_seed(7, 0), 0.0, device))
+    out = {}
+    for label in ("pageable", "pinned"):
+        if label == "pinned":
+            host = pinned_empty((W, H, C), np.float32)
+            host[...] = src
+        else:
+            host = src
+        idx, _ = renderer.render(cams[0])
+        agg.add(idx, host)
+        _lib.synchronize(device)
+        t0 = time.perf_counter()
+        for k in range(views):
+            idx, _ = renderer.render(cams[k % len(cams)])
+            agg.add(idx, host)
+        _lib.synchronize(device)
+        dt = time.perf_counter() - t0
+        out[label] = {"views_per_s": round(views / dt, 1), "pcie_GBps": round(views * host.nbytes / dt / 1e9, 1)}
+        del host
+    out["what"] = "render() + add(device indices, host float32 (W,H,C) probs): %.1f MB per view over PCIe, %d views" % (4e-6 * W * H * C, views)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="cfg2")
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(synth.CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline", action="store_true", help="also for workloads other than cfg2 (slow: the oracle at that size)")
+    ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("SMESH_BENCH_VIEWS_PER_CALL", "8")),
                     help="views handed to the library per call (fuse_views; 1 = one fuse_view call per view)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = {"cfg5": 24}.get(args.workload, 200)
+    if args.warmup is None:
+        args.warmup = {"cfg5": 4}.get(args.workload, 10)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    if world > 1 or "RANK" in os.environ:   # launched through torch.distributed.run
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        # device_id: the communicator is bound to this GPU and created now, not inside the timed region
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     device = local_rank
+    launched = world > 1 or "RANK" in os.environ   # through torch.distributed.run (or any launcher that sets RANK)
+    comm, dist, allreduce_impl = None, None, "none"
+    if launched:
+        if os.environ.get("SMESH_ALLREDUCE", "native") != "torch":
+            try:
+                comm = smcomm.Communicator.from_env(device)
+                allreduce_impl = "native smesh_allreduce (RCCL on the library stream)"
+            except Exception as e:   # every rank fails the same way (no librccl / bootstrap port): fall back together
+                print("bench: native communicator unavailable (%s); using torch.distributed" % e, file=sys.stderr, flush=True)
+                comm = None
+        if comm is None:
+            import torch
+            import torch.distributed as dist
+            torch.cuda.set_device(local_rank)
+            # device_id: the communicator is bound to this GPU and created now, not inside the timed region
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            allreduce_impl = "torch.distributed nccl (RCCL), in place on the accumulator"
 
     cfg = synth.CONFIGS[args.workload]
     W, H, C = cfg["width"], cfg["height"], cfg["classes"]
     mesh = synth.grid_mesh(cfg["a"], cfg["b"])
-    P = len(mesh.faces)
     total_views = args.steps + args.warmup
     # rank r fuses views [r*total, (r+1)*total) of an (N * total)-view ring: weak scaling, cameras from a closed form
     view_ids = [rank * total_views + i for i in range(total_views)]
     ring = max(cfg["views"], world * total_views)
     cams = [synth.ring_camera(k, ring, W, H) for k in view_ids]
 
-    renderer = render.triangles(mesh, device=device)
+    texels = bool(cfg.get("texels"))
+    if texels:
+        # render.texels(mesh, cameras): the texel resolution of a triangle comes from its largest projection over the workspace's
+        # cameras (TexturedTriangleRenderer.h:87-127) -- here the config's whole ring, the same on every rank
+        ctor_cams = [synth.ring_camera(k, cfg["views"], W, H) for k in range(cfg["views"])]
+        renderer = render.texels(mesh, ctor_cams, 0.1, device=device)
+    else:
+        renderer = render.triangles(mesh, device=device)
+    P = renderer.getPrimitivesNum()
     agg = fusion.MeshAggregator(primitives=P, classes=C, device=device)
 
     # ---- inputs resident in HBM before the timed region: one distinct probs image per view -------------
@@ -133,27 +199,39 @@ def main():
     probs = [bufs[i % nbuf] for i in range(total_views)]
     _lib.synchronize(device)
 
-    # distinct primitives touched per view (T of the algorithmic-bytes formula), on a sample of views
+    # distinct primitives touched per view (T of the algorithmic-bytes formula) and visible pixels, on a sample of views
     sample = list(range(args.warmup, total_views, max(1, args.steps // 8)))[:8]
-    T = []
+    T, NV = [], []
     for i in sample:
         idx, _ = renderer.render(cams[i])
         u = np.unique(np.asarray(idx))
         T.append(int((u < P).sum()))
-    T_mean = float(np.mean(T))
+        NV.append(int((np.asarray(idx) < P).sum()))
+        del idx
+    T_mean, NV_mean = float(np.mean(T)), float(np.mean(NV))
 
     def barrier():
-        _lib.synchronize(device)
-        if dist is not None:
-            dist.barrier()
-            import torch
-            torch.cuda.synchronize(device)
+        """every rank's queued work has finished and every rank has arrived (one host synchronisation)"""
+        if comm is not None:
+            comm.barrier()            # a 1-element all-reduce behind everything on the library stream + its wait
+        else:
+            _lib.synchronize(device)
+            if dist is not None:
+                import torch
+                dist.barrier()
+                torch.cuda.synchronize(device)
+
+    def allreduce():
+        if comm is not None:
+            comm.allreduce(agg)       # asynchronous: enqueued behind the last fusion kernel
+        elif dist is not None:
+            smdist.allreduce_raw(agg)
 
     B = max(1, args.views_per_call)
 
     def fuse_range(first, last):
         """views [first, last) in order: one fuse_view call per view, or fuse_views on batches of B (the library then
-        shares launches between the two views of a pair)"""
+        shares launches between the views of a group)"""
         if B == 1:
             for i in range(first, last):
                 agg.fuse_view(renderer, cams[i], probs[i])
@@ -163,7 +241,7 @@ def main():
                 agg.fuse_views(renderer, cams[i:j], probs[i:j])
 
     # One untimed call with a full batch before anything else: the library allocates the per-view state of a group (fragment
-    # queues, projected vertices, index planes: ~240 MB per view slot at this size) the first time a group of that many views
+    # queues, projected vertices, index planes: ~240 MB per view slot at cfg2's size) the first time a group of that many views
     # arrives, and that must not fall into the timed region when W is smaller than the batch.
     if B > 1:
         prime = [i % total_views for i in range(B)]
@@ -171,9 +249,7 @@ def main():
         agg.fuse_view(renderer, cams[0], probs[0])     # a trailing odd view takes the one-view kernels: load them too
         _lib.synchronize(device)
     fuse_range(0, args.warmup)
-    if dist is not None:   # untimed: RCCL builds its communicator / channels for this message size on first use
-        _lib.synchronize(device)
-        smdist.allreduce_raw(agg)
+    allreduce()    # untimed: RCCL builds its channels for this message size on first use
     barrier()
     agg.reset()
     _lib.check(_lib.lib().smesh_profile_reset(device))
@@ -181,20 +257,22 @@ def main():
     if os.environ.get("SMESH_BENCH_NO_PROFILE"):   # experiment: what do the HIP events around the kernel cost?
         prof_mask = 0
     # HIP events on the library's stream around every 8th launch of the dominant kernel (an event pair costs ~4 us
-    # of stream time = 4 % of a view, so not every launch is bracketed); with fuse_views around every 2nd group's
-    # back-to-back fusion launches (four launches of two views each for a group of eight)
+    # of stream time = 4 % of a cfg2 view, so not every launch is bracketed); with fuse_views around every 2nd group's
+    # back-to-back fusion launches (four launches of two views each for a group of eight).  The library counts the launches
+    # and views inside the bracketed regions itself (smesh_profile_read_ex).
     _lib.check(_lib.lib().smesh_profile_sample_every(device, int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "2"))))
     _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
     barrier()
+    _lib.synchronize(device)
     t0 = time.perf_counter()
     fuse_range(args.warmup, total_views)
-    if dist is not None:
-        _lib.synchronize(device)
-        smdist.allreduce_raw(agg)
-    barrier()
+    allreduce()
+    barrier()                      # the only host synchronisation of the timed region
     dt = time.perf_counter() - t0
     _lib.check(_lib.lib().smesh_profile_enable(device, 0))
-    if dist is not None:
+    if comm is not None:
+        dt = comm.reduce_scalars([dt], "max")[0]
+    elif dist is not None:
         import torch
         t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -204,35 +282,38 @@ def main():
     fused = agg.get()
     get_ms = 1e3 * (time.perf_counter() - t1)
     annotated = int((fused.sum(axis=1) > 0.9).sum())
+    del fused
 
     fuse_kernel = _lib.lib().smesh_last_fuse_kernel().decode()
-    scatter_ms, scatter_n = prof_read(device, _lib.PROF_FUSE_SCATTER)
-    regions = ctypes.c_uint64()
-    _lib.check(_lib.lib().smesh_profile_regions(device, _lib.PROF_FUSE_SCATTER, ctypes.byref(regions)))
-    # fuse_views times the back-to-back fusion launches of a group of views as ONE region (two views per launch)
-    views_per_region = args.steps / max(int(regions.value), 1) if prof_mask else 1.0
-    launches_per_region = max(1, int(round(views_per_region / 2.0))) if views_per_region > 1.5 else 1
-    views_per_launch = views_per_region / launches_per_region
-    hist_ms, hist_n = prof_read(device, _lib.PROF_FUSE_HIST)
-    raster_ms, raster_n = prof_read(device, _lib.PROF_RASTER)
+    k_ms, k_regions, k_launches, k_views = prof_read(device, _lib.PROF_FUSE_SCATTER)
+    hist_ms, hist_regions, _, _ = prof_read(device, _lib.PROF_FUSE_HIST)
+    raster_ms, raster_regions, _, _ = prof_read(device, _lib.PROF_RASTER)
 
     if rank == 0:
         N = W * H
-        bytes_per_view = 4 * N + 4 * N * C + 8 * C * T_mean       # idx + probs + accumulator RMW
-        t_kernel = scatter_ms * 1e-3 / max(scatter_n, 1) / launches_per_region
-        bytes_per_launch = bytes_per_view * views_per_launch
-        achieved = bytes_per_launch / t_kernel / 1e9 if t_kernel > 0 else 0.0
-        traffic = None
+        F = len(mesh.faces)
+        # idx + probs + accumulator read-modify-write of the T primitives touched
+        bytes_per_view = 4 * N + 4 * N * C + 8 * C * T_mean
+        # what a triangle-order kernel has to move at least: the index plane, the class vectors of the VISIBLE pixels only,
+        # the per-triangle records, the touched accumulator rows both ways
+        needed_per_view = 4 * N + 4 * C * NV_mean + 16 * F + 8 * C * T_mean
+        t_launch = k_ms * 1e-3 / max(k_launches, 1)                  # average duration of one launch of the dominant kernel
+        views_per_launch = k_views / max(k_launches, 1)
+        achieved = bytes_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        achieved_needed = needed_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "fusion_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "cfg2":
             try:
                 tkey = fuse_kernel + ("_pair" if views_per_launch > 1.5 else "")
                 traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
+                traffic_source = "profiles/fusion_traffic.json (PMC passes of an earlier run of this command; not measured in this run)"
             except Exception:
                 traffic = None
         out = {
             "metric": ("views/sec fused (1080p, 19 classes, 1M-tri mesh)" if args.workload == "cfg2" else
-                       "views/sec fused (%s: %dx%d, %d classes, %d triangles)" % (args.workload, W, H, C, P)),
+                       "views/sec fused (%s: %dx%d, %d classes, %d triangles%s)" % (args.workload, W, H, C, F,
+                                                                                   ", %d texel primitives" % P if texels else "")),
             "value": round(world * args.steps / dt, 2),
             "unit": "views/s",
             "n_gpus": world,
@@ -244,27 +325,33 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "%s: %d-triangle grid mesh, %d views/GPU at %dx%d, %d classes, probs resident in HBM"
-                                   % (args.workload, P, args.steps, W, H, C),
+            "config": {"workload": "%s: %d-triangle grid mesh%s, %d views/GPU at %dx%d, %d classes, probs resident in HBM"
+                                   % (args.workload, F, " as %d texel primitives" % P if texels else "", args.steps, W, H, C),
                        "views_per_call": B,
                        "sharding": "views dp%d, one RCCL all-reduce of float32[P,C]" % world,
+                       "allreduce": allreduce_impl,
+                       "host_syncs_in_timed_region": 1 if (comm is not None or world == 1) else 4,
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
-            "roofline": {"kernel": {"k_fuse_tri": "k_fuse_tri (triangle-order fusion: gather + accumulate, one owner per accumulator row)",
-                                    "k_fuse_tri_any": "k_fuse_tri_any (triangle-order fusion, run-time class count)",
-                                    "k_scatter_strip": "k_scatter_strip (segmented scatter-add)"}.get(fuse_kernel, fuse_kernel),
+            "roofline": {"kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),
                          "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": int(bytes_per_launch),
-                         "views_per_launch": round(views_per_launch, 3),
-                         "avg_launch_us": round(1e6 * t_kernel, 2), "launches_timed": scatter_n * launches_per_region,
-                         "launches_per_timed_region": launches_per_region,
-                         "distinct_primitives_per_view": int(T_mean),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_view": int(bytes_per_view),
+                         "algorithmic_bytes_per_launch": int(bytes_per_view * views_per_launch),
+                         "needed_bytes_per_view": int(needed_per_view),
+                         "frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4),
+                         "views_per_launch": (int(views_per_launch) if views_per_launch == int(views_per_launch)
+                                              else round(views_per_launch, 3)),
+                         "avg_launch_us": round(1e6 * t_launch, 2), "launches_timed": k_launches, "views_timed": k_views,
+                         "regions_timed": k_regions,
+                         "distinct_primitives_per_view": int(T_mean), "visible_pixels_per_view": int(NV_mean),
                          "other_kernels_us_per_view": ({"histogram+pixel_weights": round(1e3 * hist_ms / max(args.steps, 1), 2),
-                                                        "raster": round(1e3 * raster_ms / max(raster_n, 1) / views_per_launch, 2)}
-                                                       if hist_n or raster_n else None)},
+                                                        "raster": round(1e3 * raster_ms / max(raster_regions, 1) / max(1, min(B, 8)), 2)}
+                                                       if hist_regions or raster_regions else None)},
         }
-        if not args.no_cpu_baseline and world == 1:
+        if world == 1 and not args.no_host_path:
+            out["host_path"] = host_path(renderer, agg, cams, W, H, C, device, views=6 if args.workload != "cfg5" else 2)
+        if world == 1 and ((args.workload == "cfg2" and not args.no_cpu_baseline) or args.cpu_baseline):
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
     if dist is not None:

@@ -78,6 +78,15 @@ int smesh_device_count(int* count);
 /* Block until all work queued on `device` by this library has finished. */
 int smesh_synchronize(int device);
 
+/* Stream ordering (new: the reference moves every input with a synchronous cudaMemcpy on the null stream,
+ * python/semantic_meshes/include/Fusion.h:35-37, which orders it after the producer implicitly; this library's streams are
+ * non-blocking).  smesh_stream_wait orders the library's work on `device` after everything queued so far on `producer_stream`
+ * (a hipStream_t; NULL = the legacy default stream) without blocking the host: call it before handing over DEVICE buffers that
+ * another framework wrote on its own stream.  smesh_stream_handle returns the library's main hipStream_t so that a consumer can
+ * order its own work after the library's (smesh_synchronize is the blocking alternative). */
+int smesh_stream_wait(int device, void* producer_stream);
+int smesh_stream_handle(int device, void** stream);
+
 /* ---- triangle renderer --------------------------------------------------------------------- */
 /* Replaces TriangleRenderer::TriangleRenderer (include/semantic_meshes/render/TriangleRenderer.h:30-39):
  * uploads float32[V,3] vertices and int32[F,3] faces; primitive id == face ordinal (:57-60). */
@@ -151,6 +160,28 @@ int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind
 int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* num_floats);
 int smesh_aggregator_row_stride(smesh_aggregator_t* a, uint32_t* row_stride);
 
+/* ---- multi-GPU: one sum all-reduce of the raw accumulators over RCCL / xGMI (new) -------------- */
+/* Views are independent and every aggregator is a sum in some domain (python/semantic_meshes/src/Fusion.cu:46-92), so each GPU
+ * fuses its own views into a private accumulator and ONE ncclAllReduce(float32, sum) of the raw buffers precedes get().
+ * A communicator spans `nranks` GPUs.  One process per GPU: rank 0 calls smesh_comm_unique_id, the host code hands the 128 bytes
+ * to the other ranks (any side channel), every rank calls smesh_comm_create (collective, blocking).  One process driving several
+ * GPUs: smesh_comm_create_all fills `out[0 .. ndev-1]`.  RCCL is loaded at run time; without it these return SMESH_ERR_RUNTIME. */
+typedef struct smesh_comm smesh_comm_t;
+#define SMESH_COMM_ID_BYTES 128
+int smesh_comm_unique_id(uint8_t id[SMESH_COMM_ID_BYTES]);
+int smesh_comm_create(int device, int nranks, int rank, const uint8_t id[SMESH_COMM_ID_BYTES], smesh_comm_t** out);
+int smesh_comm_create_all(const int* devices, int ndev, smesh_comm_t** out);
+int smesh_comm_destroy(smesh_comm_t* c);
+int smesh_comm_rank(const smesh_comm_t* c, int* rank, int* nranks);
+/* Sums the raw accumulators of all ranks in place in HBM.  `n` = the (communicator, aggregator) pairs THIS process holds: 1 in
+ * the one-process-per-GPU layout, ndev after smesh_comm_create_all.  Asynchronous: enqueued on each device's library stream
+ * right behind the fusion kernels already queued there; smesh_aggregator_get / smesh_synchronize order after it.  Every rank's
+ * aggregator must have the same num_primitives, num_classes and kind. */
+int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs, int n);
+/* Blocking reduction of `n` <= 64 host doubles over the communicator (op 0 = sum, 2 = max): a harness's barrier and its
+ * max-over-ranks clock without a second communication library. */
+int smesh_comm_allreduce_f64(smesh_comm_t* c, double* values, int n, int op);
+
 /* ---- annotation renderer: fused annotations gathered back to an image ------------------------- */
 /* Replaces ModelAggregator::renderer() + ModelRenderer::render (include/semantic_meshes/fusion/Mesh.h:124-129,
  * 25-42; the harness does the same with tf.gather, eval-scannet/eval_scannet.py:314): the renderer holds
@@ -205,6 +236,11 @@ int smesh_profile_enable(int device, int slot_mask);
  * time, 4 % of a cfg2 view.  `launches` of smesh_profile_read counts the bracketed regions. */
 int smesh_profile_sample_every(int device, uint32_t n);
 int smesh_profile_read(int device, int slot, double* total_ms, uint64_t* launches);
+/* The same, plus what the bracketed regions contained: `regions` = regions timed (== `launches` of smesh_profile_read),
+ * `kernel_launches` = launches of the slot's dominant kernel inside them, `views` = views those launches processed (a two-view
+ * fusion launch counts 1 and 2).  total_ms / kernel_launches is the kernel's average duration and views / kernel_launches the
+ * views per launch, whatever the grouping of views into calls was.  Any out pointer may be NULL. */
+int smesh_profile_read_ex(int device, int slot, double* total_ms, uint64_t* regions, uint64_t* kernel_launches, uint64_t* views);
 /* Regions of the slot entered while it was enabled, bracketed or not.  A region is one kernel launch, except that smesh_fuse_views
  * makes ONE region of the back-to-back fusion launches of a group of views (an event pair around a single launch adds the dispatch
  * latency that back-to-back launches hide). */
@@ -219,6 +255,9 @@ int smesh_synth_probs(float* out, uint64_t num_pixels, uint32_t num_classes, uin
 /* Raw device memory for benchmark inputs that must be resident in HBM before timing starts. */
 int smesh_device_malloc(int device, uint64_t bytes, void** out);
 int smesh_device_free(int device, void* ptr);
+/* Page-locked host memory (hipHostMalloc): HOST images passed to add() / fuse_view() from such a buffer cross PCIe by DMA. */
+int smesh_host_malloc(uint64_t bytes, void** out);
+int smesh_host_free(void* ptr);
 int smesh_memcpy(void* dst, const void* src, uint64_t bytes, int dst_memkind, int src_memkind, int device);
 
 #ifdef __cplusplus

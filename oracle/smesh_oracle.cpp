@@ -23,6 +23,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <map>
@@ -619,9 +620,20 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, cons
   const int64_t is[2] = {(int64_t)H, 1};   // the oracle has one add(): the reference's
   return smesh_aggregator_add(a, idx, SMESH_IDX_U32, is, SMESH_MEM_HOST, probs, ps, pmem, weights, ws, wmem, W, H);
 }
+int smesh_stream_wait(int, void*) { return SMESH_OK; }   // the oracle has no streams: everything is synchronous
+int smesh_stream_handle(int, void** s) { if (s) *s = nullptr; return SMESH_OK; }
+// multi-GPU exchange: not part of the CPU restatement (tests sum the shards' raw accumulators themselves)
+int smesh_comm_unique_id(uint8_t*) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
+int smesh_comm_create(int, int, int, const uint8_t*, smesh_comm_t**) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
+int smesh_comm_create_all(const int*, int, smesh_comm_t**) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
+int smesh_comm_destroy(smesh_comm_t*) { return SMESH_OK; }
+int smesh_comm_rank(const smesh_comm_t*, int*, int*) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
+int smesh_allreduce(smesh_comm_t* const*, smesh_aggregator_t* const*, int) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
+int smesh_comm_allreduce_f64(smesh_comm_t*, double*, int, int) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
 int smesh_profile_enable(int, int) { return SMESH_OK; }
 int smesh_profile_sample_every(int, uint32_t) { return SMESH_OK; }
 int smesh_profile_read(int, int, double* ms, uint64_t* n) { if (ms) *ms = 0; if (n) *n = 0; return SMESH_OK; }
+int smesh_profile_read_ex(int, int, double* ms, uint64_t* r, uint64_t* l, uint64_t* v) { if (ms) *ms = 0; if (r) *r = 0; if (l) *l = 0; if (v) *v = 0; return SMESH_OK; }
 int smesh_profile_regions(int, int, uint64_t* n) { if (n) *n = 0; return SMESH_OK; }
 int smesh_profile_reset(int) { return SMESH_OK; }
 
@@ -656,6 +668,8 @@ int smesh_synth_probs(float* out, uint64_t N, uint32_t C, uint64_t seed, float z
   return SMESH_OK;
 }
 
+int smesh_host_malloc(uint64_t bytes, void** out) { if (!out) return fail(SMESH_ERR_INVALID, "out is NULL"); *out = malloc(bytes ? bytes : 1); return *out ? SMESH_OK : fail(SMESH_ERR_RUNTIME, "out of memory"); }
+int smesh_host_free(void* p) { free(p); return SMESH_OK; }
 int smesh_device_malloc(int, uint64_t, void**) { return fail(SMESH_ERR_NODEVICE, "oracle has no device memory"); }
 int smesh_device_free(int, void*) { return SMESH_OK; }
 int smesh_memcpy(void* dst, const void* src, uint64_t bytes, int dk, int sk, int) {

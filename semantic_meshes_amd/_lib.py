@@ -38,6 +38,8 @@ SIGNATURES = {
     "smesh_last_error": (ctypes.c_char_p, []),
     "smesh_device_count": (c_int, [P(c_int)]),
     "smesh_synchronize": (c_int, [c_int]),
+    "smesh_stream_wait": (c_int, [c_int, c_void_p]),
+    "smesh_stream_handle": (c_int, [c_int, P(c_void_p)]),
     "smesh_renderer_create_triangles": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_int, P(c_void_p)]),
     "smesh_renderer_create_texels": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64, c_float, c_int, P(c_void_p)]),
     "smesh_renderer_destroy": (c_int, [c_void_p]),
@@ -60,6 +62,13 @@ SIGNATURES = {
     "smesh_aggregator_set_raw": (c_int, [c_void_p, c_void_p, c_int]),
     "smesh_aggregator_raw_pointer": (c_int, [c_void_p, P(c_void_p), P(c_u64)]),
     "smesh_aggregator_row_stride": (c_int, [c_void_p, P(c_u32)]),
+    "smesh_comm_unique_id": (c_int, [c_void_p]),
+    "smesh_comm_create": (c_int, [c_int, c_int, c_int, c_void_p, P(c_void_p)]),
+    "smesh_comm_create_all": (c_int, [P(c_int), c_int, P(c_void_p)]),
+    "smesh_comm_destroy": (c_int, [c_void_p]),
+    "smesh_comm_rank": (c_int, [c_void_p, P(c_int), P(c_int)]),
+    "smesh_allreduce": (c_int, [P(c_void_p), P(c_void_p), c_int]),
+    "smesh_comm_allreduce_f64": (c_int, [c_void_p, P(ctypes.c_double), c_int, c_int]),
     "smesh_aggregator_renderer": (c_int, [c_void_p, P(c_void_p)]),
     "smesh_annotation_renderer_render": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int, c_void_p, c_void_p, c_int, c_u64, c_u64]),
     "smesh_annotation_renderer_destroy": (c_int, [c_void_p]),
@@ -69,11 +78,14 @@ SIGNATURES = {
     "smesh_profile_enable": (c_int, [c_int, c_int]),
     "smesh_profile_sample_every": (c_int, [c_int, ctypes.c_uint32]),
     "smesh_profile_read": (c_int, [c_int, c_int, P(ctypes.c_double), P(c_u64)]),
+    "smesh_profile_read_ex": (c_int, [c_int, c_int, P(ctypes.c_double), P(c_u64), P(c_u64), P(c_u64)]),
     "smesh_profile_regions": (c_int, [c_int, c_int, P(c_u64)]),
     "smesh_profile_reset": (c_int, [c_int]),
     "smesh_synth_probs": (c_int, [c_void_p, c_u64, c_u32, c_u64, c_float, c_int, c_int]),
     "smesh_device_malloc": (c_int, [c_int, c_u64, P(c_void_p)]),
     "smesh_device_free": (c_int, [c_int, c_void_p]),
+    "smesh_host_malloc": (c_int, [c_u64, P(c_void_p)]),
+    "smesh_host_free": (c_int, [c_void_p]),
     "smesh_memcpy": (c_int, [c_void_p, c_void_p, c_u64, c_int, c_int, c_int]),
 }
 

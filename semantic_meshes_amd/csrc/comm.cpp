@@ -1,0 +1,216 @@
+// comm.cpp -- the one exchange step of the sharded path: sum of the raw accumulators over RCCL (xGMI).
+//
+// New functionality: the reference is single-GPU.  Views are independent and every aggregator is a sum in some
+// domain (python/semantic_meshes/src/Fusion.cu:46-92), so each rank fuses its own views and ONE ncclAllReduce(float32, sum) of the
+// raw float32[P * row_stride] buffer, in place in HBM, precedes get().  The collective is enqueued on the library's own stream
+// right behind the last fusion kernel: no host synchronisation between the two, no PyTorch.
+//
+// RCCL is loaded at run time (dlopen): single-GPU users of libsmesh_hip.so do not need it, and a process that already holds a
+// librccl (e.g. the one bundled with PyTorch) keeps using that one.
+#include "common.hpp"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+#include <vector>
+
+using namespace smesh;
+
+// from fusion.hip
+struct smesh_aggregator;
+DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a);
+std::mutex& smesh_aggregator_mutex(smesh_aggregator* a);
+float* smesh_aggregator_acc(smesh_aggregator* a, uint64_t* num_floats);
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+Rccl* rccl() {
+  static Rccl* r = [] {
+    auto* x = new Rccl();
+    const char* names[] = {getenv("SMESH_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* n : names) {
+      if (!n || !*n) continue;
+      x->handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (x->handle) break;
+    }
+    if (!x->handle) { x->error = std::string("cannot load librccl: ") + (dlerror() ? dlerror() : "not found"); return x; }
+    auto sym = [&](const char* s) -> void* {
+      void* p = dlsym(x->handle, s);
+      if (!p && x->error.empty()) x->error = std::string("librccl lacks ") + s;
+      return p;
+    };
+    x->GetUniqueId = reinterpret_cast<decltype(x->GetUniqueId)>(sym("ncclGetUniqueId"));
+    x->CommInitRank = reinterpret_cast<decltype(x->CommInitRank)>(sym("ncclCommInitRank"));
+    x->CommInitAll = reinterpret_cast<decltype(x->CommInitAll)>(sym("ncclCommInitAll"));
+    x->CommDestroy = reinterpret_cast<decltype(x->CommDestroy)>(sym("ncclCommDestroy"));
+    x->AllReduce = reinterpret_cast<decltype(x->AllReduce)>(sym("ncclAllReduce"));
+    x->GroupStart = reinterpret_cast<decltype(x->GroupStart)>(sym("ncclGroupStart"));
+    x->GroupEnd = reinterpret_cast<decltype(x->GroupEnd)>(sym("ncclGroupEnd"));
+    x->GetErrorString = reinterpret_cast<decltype(x->GetErrorString)>(sym("ncclGetErrorString"));
+    return x;
+  }();
+  return r;
+}
+
+int need_rccl(Rccl** out) {
+  Rccl* r = rccl();
+  if (!r->error.empty()) return fail(SMESH_ERR_RUNTIME, r->error);
+  *out = r;
+  return SMESH_OK;
+}
+
+int fail_rccl(Rccl* r, ncclResult_t e, const char* what) {
+  return fail(SMESH_ERR_RUNTIME, std::string("RCCL error in ") + what + ": " + (r->GetErrorString ? r->GetErrorString(e) : "?"));
+}
+
+#define SMESH_RCCL(r, expr)                                   \
+  do {                                                        \
+    ncclResult_t _e = (expr);                                 \
+    if (_e != ncclSuccess) return fail_rccl(r, _e, #expr);    \
+  } while (0)
+
+}  // namespace
+
+struct smesh_comm {
+  DeviceCtx* ctx = nullptr;
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  double* d_small = nullptr;   // device scratch of the small host-value reductions
+  static constexpr int kSmall = 64;
+};
+
+extern "C" {
+
+int smesh_comm_unique_id(uint8_t id[SMESH_COMM_ID_BYTES]) {
+  if (!id) return fail(SMESH_ERR_INVALID, "id is NULL");
+  static_assert(SMESH_COMM_ID_BYTES == sizeof(ncclUniqueId), "unique id size");
+  Rccl* r;
+  SMESH_TRY(need_rccl(&r));
+  ncclUniqueId u;
+  SMESH_RCCL(r, r->GetUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return SMESH_OK;
+}
+
+static int finish_comm(DeviceCtx* ctx, ncclComm_t c, int nranks, int rank, smesh_comm_t** out) {
+  auto* m = new (std::nothrow) smesh_comm();
+  if (!m) return fail(SMESH_ERR_RUNTIME, "out of memory");
+  m->ctx = ctx; m->comm = c; m->nranks = nranks; m->rank = rank;
+  SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_small), smesh_comm::kSmall * sizeof(double)));
+  *out = m;
+  return SMESH_OK;
+}
+
+int smesh_comm_create(int device, int nranks, int rank, const uint8_t id[SMESH_COMM_ID_BYTES], smesh_comm_t** out) {
+  if (!out || !id) return fail(SMESH_ERR_INVALID, "NULL argument");
+  *out = nullptr;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(SMESH_ERR_INVALID, "bad rank / nranks");
+  Rccl* r;
+  SMESH_TRY(need_rccl(&r));
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  SMESH_HIP(hipSetDevice(device));
+  ncclUniqueId u;
+  memcpy(&u, id, sizeof u);
+  ncclComm_t c = nullptr;
+  SMESH_RCCL(r, r->CommInitRank(&c, nranks, u, rank));
+  return finish_comm(ctx, c, nranks, rank, out);
+}
+
+int smesh_comm_create_all(const int* devices, int ndev, smesh_comm_t** out) {
+  if (!out || !devices || ndev < 1) return fail(SMESH_ERR_INVALID, "bad argument");
+  for (int i = 0; i < ndev; i++) out[i] = nullptr;
+  Rccl* r;
+  SMESH_TRY(need_rccl(&r));
+  std::vector<DeviceCtx*> ctx((size_t)ndev);
+  for (int i = 0; i < ndev; i++) SMESH_TRY(get_ctx(devices[i], &ctx[(size_t)i]));
+  std::vector<ncclComm_t> c((size_t)ndev, nullptr);
+  SMESH_RCCL(r, r->CommInitAll(c.data(), ndev, devices));
+  for (int i = 0; i < ndev; i++) SMESH_TRY(finish_comm(ctx[(size_t)i], c[(size_t)i], ndev, i, &out[i]));
+  return SMESH_OK;
+}
+
+int smesh_comm_destroy(smesh_comm_t* c) {
+  if (!c) return SMESH_OK;
+  Rccl* r = rccl();
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->comm && r->CommDestroy) (void)r->CommDestroy(c->comm);
+  if (c->d_small) (void)hipFree(c->d_small);
+  delete c;
+  return SMESH_OK;
+}
+
+int smesh_comm_rank(const smesh_comm_t* c, int* rank, int* nranks) {
+  if (!c) return fail(SMESH_ERR_INVALID, "NULL communicator");
+  if (rank) *rank = c->rank;
+  if (nranks) *nranks = c->nranks;
+  return SMESH_OK;
+}
+
+// Sum the raw accumulators of all ranks in place.  One process per GPU: n == 1.  One process driving several GPUs
+// (smesh_comm_create_all): all of its (communicator, aggregator) pairs in one call -- the collectives are grouped.
+// Asynchronous: enqueued on each device's library stream behind the fusion kernels already queued there; get() /
+// smesh_synchronize() order after it.
+int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs, int n) {
+  if (n < 1 || !comms || !aggs) return fail(SMESH_ERR_INVALID, "bad argument");
+  Rccl* r;
+  SMESH_TRY(need_rccl(&r));
+  for (int i = 0; i < n; i++) {
+    if (!comms[i] || !aggs[i]) return fail(SMESH_ERR_INVALID, "NULL communicator / aggregator");
+    if (smesh_aggregator_ctx(aggs[i]) != comms[i]->ctx) return fail(SMESH_ERR_INVALID, "aggregator and communicator live on different devices");
+  }
+  if (n > 1) SMESH_RCCL(r, r->GroupStart());
+  int status = SMESH_OK;
+  for (int i = 0; i < n && status == SMESH_OK; i++) {
+    std::lock_guard<std::mutex> g(smesh_aggregator_mutex(aggs[i]));
+    DeviceCtx* ctx = comms[i]->ctx;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) { status = fail(SMESH_ERR_RUNTIME, "hipSetDevice failed"); break; }
+    uint64_t count = 0;
+    float* acc = smesh_aggregator_acc(aggs[i], &count);
+    if (count == 0) continue;
+    const ncclResult_t e = r->AllReduce(acc, acc, (size_t)count, ncclFloat32, ncclSum, comms[i]->comm, ctx->stream);
+    if (e != ncclSuccess) status = fail_rccl(r, e, "ncclAllReduce");
+  }
+  if (n > 1) {
+    const ncclResult_t e = r->GroupEnd();
+    if (e != ncclSuccess && status == SMESH_OK) status = fail_rccl(r, e, "ncclGroupEnd");
+  }
+  return status;
+}
+
+// Small reduction of host values over the same communicator (op: 0 = sum, 2 = max), blocking: what a benchmark harness needs
+// for its barrier and its max-over-ranks clock without a second communication library.
+int smesh_comm_allreduce_f64(smesh_comm_t* c, double* values, int n, int op) {
+  if (!c || !values || n < 1 || n > smesh_comm::kSmall) return fail(SMESH_ERR_INVALID, "bad argument");
+  if (op != 0 && op != 2) return fail(SMESH_ERR_INVALID, "op must be 0 (sum) or 2 (max)");
+  Rccl* r;
+  SMESH_TRY(need_rccl(&r));
+  DeviceCtx* ctx = c->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_HIP(hipMemcpyAsync(c->d_small, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  SMESH_RCCL(r, r->AllReduce(c->d_small, c->d_small, (size_t)n, ncclFloat64, op == 0 ? ncclSum : ncclMax, c->comm, ctx->stream));
+  SMESH_HIP(hipMemcpyAsync(values, c->d_small, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  return SMESH_OK;
+}
+
+}  // extern "C"

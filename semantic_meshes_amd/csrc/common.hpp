@@ -35,6 +35,9 @@ struct ProfSlot {
   uint64_t launches = 0;
   uint64_t seen = 0;   // regions entered while the slot was enabled (only every `profile_every`-th is bracketed)
   int depth = 0;       // > 0 inside a region of this slot: nested regions belong to it (back-to-back launches timed together)
+  bool open_timed = false;   // the region that is open right now is one of the bracketed ones
+  uint64_t timed_launches = 0;   // launches of the slot's dominant kernel inside bracketed regions (prof_note) ...
+  uint64_t timed_views = 0;      // ... and the views those launches fused
 };
 
 // One per GPU: a compute stream all of this library's kernels and copies are ordered on.
@@ -42,6 +45,7 @@ struct DeviceCtx {
   int device = -1;
   hipStream_t stream = nullptr;         // main stream: fusion kernels, copies, everything by default
   hipStream_t raster_stream = nullptr;  // smesh_fuse_view rasterises view k+1 here while view k is being fused
+  hipEvent_t ev_order = nullptr;        // smesh_stream_wait: marks the producer's stream
   int num_cus = 256;
   unsigned profiling = 0;   // bit s set = bracket slot s with HIP events
   unsigned profile_every = 1;   // ... every n-th region of the slot (an event pair costs ~4 us of stream time)
@@ -62,6 +66,11 @@ struct ProfScope {
   ProfScope(DeviceCtx* c, int s, hipStream_t stream = nullptr);
   ~ProfScope();
 };
+
+// Called where a slot's dominant kernel is launched: counts the launch and the views it processes if (and only if) it falls
+// inside a region that is being timed, so that total_ms / timed_launches is that kernel's average duration whatever the
+// grouping of views into calls was.
+void prof_note(DeviceCtx* ctx, int slot, uint64_t launches, uint64_t views);
 
 // Grow-only device scratch buffer.
 struct Scratch {

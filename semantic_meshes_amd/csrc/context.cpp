@@ -69,11 +69,18 @@ ProfScope::ProfScope(DeviceCtx* c, int s, hipStream_t stream) : ctx(c), slot(s),
     }
   }
   (void)hipEventRecord(start, st);
+  ps.open_timed = true;
+}
+
+void prof_note(DeviceCtx* ctx, int slot, uint64_t launches, uint64_t views) {
+  ProfSlot& ps = ctx->slots[slot];
+  if (ps.depth > 0 && ps.open_timed) { ps.timed_launches += launches; ps.timed_views += views; }
 }
 
 ProfScope::~ProfScope() {
-  if (counted) ctx->slots[slot].depth--;
+  if (counted && --ctx->slots[slot].depth == 0 && !start) ctx->slots[slot].open_timed = false;
   if (!start) return;
+  ctx->slots[slot].open_timed = false;
   (void)hipEventRecord(stop, st);
   ctx->slots[slot].pending.emplace_back(start, stop);
 }
@@ -125,6 +132,34 @@ int smesh_synchronize(int device) {
   return SMESH_OK;
 }
 
+// Orders the library's streams after everything queued so far on `producer_stream` (NULL = the legacy default stream, on
+// which PyTorch-ROCm runs unless told otherwise): the library's streams are non-blocking, so device buffers written by
+// another framework are NOT implicitly ordered before the kernels that read them (the reference is: synchronous cudaMemcpy
+// on the null stream, Fusion.h:35-37).  Costs an event record + two stream waits, no host synchronisation.
+int smesh_stream_wait(int device, void* producer_stream) {
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(device));
+  hipStream_t ps = static_cast<hipStream_t>(producer_stream);
+  if (ps == ctx->stream || ps == ctx->raster_stream) return SMESH_OK;
+  if (!ctx->ev_order) SMESH_HIP(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
+  SMESH_HIP(hipEventRecord(ctx->ev_order, ps));
+  SMESH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
+  SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, ctx->ev_order, 0));
+  return SMESH_OK;
+}
+
+// The library's main stream (a hipStream_t) of `device`: consumers that want to order their own work after the library's
+// without a host synchronisation (`__cuda_array_interface__` v3 "stream", `__dlpack__(stream=...)`).
+int smesh_stream_handle(int device, void** stream) {
+  if (!stream) return fail(SMESH_ERR_INVALID, "stream is NULL");
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  *stream = ctx->stream;
+  return SMESH_OK;
+}
+
 int smesh_profile_enable(int device, int enabled) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));
@@ -170,6 +205,20 @@ int smesh_profile_read(int device, int slot, double* total_ms, uint64_t* launche
   return SMESH_OK;
 }
 
+int smesh_profile_read_ex(int device, int slot, double* total_ms, uint64_t* regions, uint64_t* launches, uint64_t* views) {
+  if (slot < 0 || slot >= SMESH_PROF_SLOTS) return fail(SMESH_ERR_INVALID, "bad profile slot");
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_TRY(drain(ctx));
+  const ProfSlot& ps = ctx->slots[slot];
+  if (total_ms) *total_ms = ps.total_ms;
+  if (regions) *regions = ps.launches;
+  if (launches) *launches = ps.timed_launches;
+  if (views) *views = ps.timed_views;
+  return SMESH_OK;
+}
+
 int smesh_profile_regions(int device, int slot, uint64_t* entered) {
   if (slot < 0 || slot >= SMESH_PROF_SLOTS) return fail(SMESH_ERR_INVALID, "bad profile slot");
   DeviceCtx* ctx;
@@ -188,6 +237,8 @@ int smesh_profile_reset(int device) {
     ps.total_ms = 0.0;
     ps.launches = 0;
     ps.seen = 0;
+    ps.timed_launches = 0;
+    ps.timed_views = 0;
   }
   return SMESH_OK;
 }
@@ -208,6 +259,22 @@ int smesh_device_free(int device, void* ptr) {
   SMESH_HIP(hipSetDevice(device));
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
   SMESH_HIP(hipFree(ptr));
+  return SMESH_OK;
+}
+
+// Page-locked host memory: host images handed to add() / fuse_view() from such a buffer cross PCIe by DMA at link speed
+// (pageable memory is staged through the driver's bounce buffers).
+int smesh_host_malloc(uint64_t bytes, void** out) {
+  if (!out) return fail(SMESH_ERR_INVALID, "out is NULL");
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(0, &ctx));   // needs a HIP runtime with a device
+  SMESH_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+  return SMESH_OK;
+}
+
+int smesh_host_free(void* ptr) {
+  if (!ptr) return SMESH_OK;
+  SMESH_HIP(hipHostFree(ptr));
   return SMESH_OK;
 }
 

@@ -1456,6 +1456,7 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
       args.pw = static_cast<const float*>(a->pw.ptr);
     }
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
+    prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, 1);
     switch (a->kind) {
       case SMESH_AGG_SUM:    SMESH_TRY(launch_strip<SMESH_AGG_SUM>(args, ctx->num_cus, st)); break;
       case SMESH_AGG_SUMMAX: SMESH_TRY(launch_strip<SMESH_AGG_SUMMAX>(args, ctx->num_cus, st)); break;
@@ -1467,6 +1468,7 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
     float* wpix = static_cast<float*>(a->fb_w.ptr);
     uint32_t* amax = static_cast<uint32_t*>(a->fb_amax.ptr);
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
+    prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, 1);
     const dim3 g1((uint32_t)div_up(N, 256)), g2((uint32_t)div_up(N * C, 256)), b(256);
     switch (a->kind) {
       case SMESH_AGG_SUM:
@@ -1611,6 +1613,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   const dim3 tgrid(t.tri_blocks), bgrid(big_waves);                        // any-C paths: big triangles in a second launch
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
+    prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, (uint64_t)nviews);
 #define SMESH_FA(K)                                                                            \
     switch (G) {                                                                               \
       case 1:  hipLaunchKernelGGL((k_fuse_tri_any<K, 1>), tgrid, block, 0, st, t); break;  \
@@ -1682,6 +1685,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   const dim3 tgrid(t.tri_blocks), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave);
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
+    prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, 1);
     switch (a->kind) {
       case SMESH_AGG_SUM:
         hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_SUM>), tgrid, block, 0, st, t);
@@ -1702,6 +1706,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
 }
 
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a) { return a->ctx; }
+float* smesh_aggregator_acc(smesh_aggregator* a, uint64_t* num_floats) { if (num_floats) *num_floats = a->P * a->S; return a->acc; }
 uint32_t smesh_aggregator_classes(smesh_aggregator* a) { return a->C; }
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a) { return a->mu; }
 Scratch& smesh_aggregator_stage_probs(smesh_aggregator* a) { return a->st_probs; }

@@ -1061,6 +1061,8 @@ int check_camera(const smesh_camera_t* cam) {
   if (!cam) return fail(SMESH_ERR_INVALID, "camera is NULL");
   if (cam->width == 0 || cam->height == 0 || cam->width > 65536 || cam->height > 65536)
     return fail(SMESH_ERR_INVALID, "camera resolution must be in [1, 65536]");
+  // the kernels pack pixel offsets into 32 bits and size their grids with 32-bit block counts (same bound as smesh_aggregator_add)
+  if (cam->width * cam->height >= 0x7FFFFFFFull / 4) return fail(SMESH_ERR_INVALID, "image too large");
   return SMESH_OK;
 }
 
@@ -1581,7 +1583,12 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
                          (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)));
     if (fast) {
       SMESH_HIP(hipSetDevice(ctx->device));
-      return fuse_rendered(r, a, side, idx_dev, probs, weights, probs_mem, W, H);
+      SMESH_TRY(fuse_rendered(r, a, side, idx_dev, probs, weights, probs_mem, W, H));
+      // Like smesh_aggregator_add, inputs are never retained after return (Fusion.h:45-47): device inputs must have been read
+      // before the caller may free or overwrite them (host inputs were waited for inside fuse_rendered).  The explicitly
+      // asynchronous entry points are smesh_fuse_view / smesh_fuse_views.
+      if (probs_mem == SMESH_MEM_DEVICE || (weights && w_mem == SMESH_MEM_DEVICE)) SMESH_HIP(hipStreamSynchronize(ctx->stream));
+      return SMESH_OK;
     }
   }
   const int64_t is[2] = {(int64_t)H, 1};

@@ -58,7 +58,13 @@ class DeviceArray:
 
     @property
     def __cuda_array_interface__(self):
+        # the consumer reads on ITS stream: everything this library still has in flight (render() is asynchronous on a
+        # non-blocking stream) must have landed first -- same contract as __dlpack__ below
         self._exported = True
+        _lib.synchronize(self.device)
+        return self._cai_dict()
+
+    def _cai_dict(self):
         return {
             "shape": self.shape,
             "typestr": self.dtype.str,
@@ -141,6 +147,26 @@ class DeviceBuffer:
         return DeviceArray(self.ptr + offset_bytes, shape, dtype, self.device, owner=self)
 
 
+def _free_pinned(ptr):
+    try:
+        _lib.lib().smesh_host_free(ctypes.c_void_p(ptr))
+    except Exception:
+        pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """A numpy array over page-locked host memory (`smesh_host_malloc`): host images handed to add() from such an array
+    cross PCIe by DMA at link speed.  The memory is released when the array and every view of it are gone."""
+    import weakref
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    p = ctypes.c_void_p()
+    _lib.check(_lib.lib().smesh_host_malloc(max(n, 1), ctypes.byref(p)))
+    buf = (ctypes.c_uint8 * max(n, 1)).from_address(p.value)   # numpy keeps `buf` alive as the base of every view
+    weakref.finalize(buf, _free_pinned, p.value)
+    return np.frombuffer(buf, dtype=dtype, count=n // dtype.itemsize).reshape(shape)
+
+
 def to_device(array, device=0):
     """Copy a host numpy array into a fresh device allocation; returns a DeviceArray owning it."""
     a = np.ascontiguousarray(array)
@@ -151,16 +177,46 @@ def to_device(array, device=0):
     return buf.view(a.shape, a.dtype)
 
 
-def describe(obj, want_ndim, what):
+def _order_after_producer(obj, cai, device):
+    """Device memory written by ANOTHER framework: order the library's (non-blocking) streams after the stream that
+    produced it, without blocking the host.  The reference gets this for free from its synchronous cudaMemcpy on the null
+    stream (Fusion.h:35-37).  Producer stream: torch tensors -> torch's current stream on that device; otherwise the
+    `stream` entry of `__cuda_array_interface__` v3 (1 = legacy default, 2 = per-thread default, else a handle); absent
+    -> the legacy default stream."""
+    stream = 0
+    if (type(obj).__module__ or "").split(".")[0] == "torch":
+        try:
+            import torch
+            stream = int(torch.cuda.current_stream(obj.device).cuda_stream)
+        except Exception:
+            stream = 0
+    elif cai is not None:
+        s = cai.get("stream")
+        stream = 0 if s in (None, 1) else int(s)   # 2 is also hipStreamPerThread's handle value
+    _lib.check(_lib.lib().smesh_stream_wait(int(device or 0), ctypes.c_void_p(stream)))
+
+
+def library_stream(device=0):
+    """The library's main hipStream_t on `device` as an int (for `__dlpack__(stream=...)` / external stream wrappers)."""
+    p = ctypes.c_void_p()
+    _lib.check(_lib.lib().smesh_stream_handle(int(device), ctypes.byref(p)))
+    return int(p.value or 0)
+
+
+def describe(obj, want_ndim, what, device=None):
     """Normalise an add()/render() argument to (pointer, memkind, shape, dtype, element strides, keepalive).
 
     Accepts what the reference's FromTensor accepts in practice: numpy arrays / array-likes
     on the host, and device arrays via DeviceArray or `__cuda_array_interface__` (torch-ROCm, cupy).
+    Device memory that does not come from this library is ordered after its producer's stream (`device` = the GPU of
+    the handle the argument is for).
     """
     if isinstance(obj, DeviceArray):
         shape, dtype, strides, ptr, mem, keep = obj.shape, obj.dtype, obj.strides, obj.ptr, _lib.MEM_DEVICE, obj
     elif hasattr(obj, "__cuda_array_interface__"):
         cai = obj.__cuda_array_interface__
+        if device is not None:   # (None: layout bookkeeping only -- every entry point of the package passes its handle's GPU)
+            _order_after_producer(obj, cai, device)
         shape, dtype = tuple(cai["shape"]), np.dtype(cai["typestr"])
         ptr = int(cai["data"][0])
         bstr = cai.get("strides")
@@ -178,7 +234,19 @@ def describe(obj, want_ndim, what):
     elif type(obj).__name__ == "PyCapsule" or (hasattr(obj, "__dlpack__") and not hasattr(obj, "__array_interface__")
                                                 and not isinstance(obj, np.ndarray)):
         from . import dlpack
-        imp = dlpack.Imported(obj if type(obj).__name__ == "PyCapsule" else obj.__dlpack__())
+        if type(obj).__name__ == "PyCapsule":
+            capsule = obj
+            ordered = False
+        else:
+            try:   # DLPack protocol: the producer makes the data safe to read on the consumer's stream
+                if device is None:
+                    raise TypeError("no device to order on")
+                capsule, ordered = obj.__dlpack__(stream=library_stream(device)), True
+            except Exception:
+                capsule, ordered = obj.__dlpack__(), False
+        imp = dlpack.Imported(capsule)
+        if imp.on_device and not ordered and device is not None:
+            _order_after_producer(obj, None, device)
         shape, dtype, strides, ptr = imp.shape, imp.dtype, imp.strides, imp.ptr
         mem, keep = (_lib.MEM_DEVICE if imp.on_device else _lib.MEM_HOST), imp
     else:

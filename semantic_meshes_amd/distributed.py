@@ -26,10 +26,16 @@ def _dist():
     return dist
 
 
-def allreduce_raw(aggregator, group=None):
+def allreduce_raw(aggregator, group=None, comm=None):
     """Sum the un-normalised accumulators of all ranks in place; afterwards every rank's get() returns the
-    fusion of ALL views.  Works for any object with get_raw()/set_raw(); a HIP aggregator under the nccl
-    backend is reduced in place in HBM (no host round trip)."""
+    fusion of ALL views.
+
+    `comm` (a `semantic_meshes_amd.comm.Communicator`): the native path -- `smesh_allreduce`, ONE ncclAllReduce enqueued on
+    the library's own stream right behind the fusion kernels, no host synchronisation, no PyTorch.
+    Otherwise `torch.distributed` is used as plumbing: works for any object with get_raw()/set_raw(); a HIP aggregator under
+    the nccl backend is reduced in place in HBM (torch's stream is ordered after the library's and back by events)."""
+    if comm is not None:
+        return comm.allreduce(aggregator)
     dist = _dist()
     import os
     if not dist.is_available() or not dist.is_initialized():
@@ -44,7 +50,10 @@ def allreduce_raw(aggregator, group=None):
         if t.data_ptr() != flat.ptr:
             raise RuntimeError("torch copied the accumulator instead of aliasing it")
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        torch.cuda.synchronize(flat.device)
+        # later library work (get(), more views) is ordered after the collective on the device, not by a host wait
+        from . import _lib
+        import ctypes
+        _lib.check(_lib.lib().smesh_stream_wait(flat.device, ctypes.c_void_p(int(torch.cuda.current_stream(flat.device).cuda_stream))))
         return aggregator
     raw = np.ascontiguousarray(aggregator.get_raw(), dtype=np.float32)
     t = torch.from_numpy(raw)
@@ -53,14 +62,17 @@ def allreduce_raw(aggregator, group=None):
     return aggregator
 
 
-def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None, contiguous=True, batch=8):
+def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None, contiguous=True, batch=8, comm=None):
     """Fuse this rank's share of `cameras` and all-reduce.  `probs_of_view(k)` returns the (W,H,C)
-    class-probability image of view k (host or device)."""
-    dist = _dist()
-    if dist.is_available() and dist.is_initialized():
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+    class-probability image of view k (host or device).  `comm`: native communicator (see allreduce_raw)."""
+    if comm is not None:
+        rank, world = comm.rank, comm.world
     else:
-        rank, world = 0, 1
+        dist = _dist()
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        else:
+            rank, world = 0, 1
     mine = list(shard_views(len(cameras), rank, world, contiguous))
     if hasattr(aggregator, "fuse_views"):
         # eight views per call: the library shares rasteriser launches between them and fuses them two by two
@@ -71,4 +83,4 @@ def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None,
         for k in mine:
             idx, _ = renderer.render(cameras[k])
             aggregator.add(idx, probs_of_view(k))
-    return allreduce_raw(aggregator, group)
+    return allreduce_raw(aggregator, group, comm)

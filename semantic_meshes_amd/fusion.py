@@ -41,23 +41,23 @@ class _MeshAggregator:
     def add(self, primitive_image, probs_image, weights_image=None):
         """Fuse one view: `primitive_image` (W,H) of uint32/int32/uint64/int64, `probs_image` (W,H,C) float32,
         optional `weights_image` (W,H) float32; host numpy or device arrays, any non-negative strides."""
-        ip, imem, ishape, idt, istr, k0 = describe(primitive_image, 2, "primitive image")
-        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image")
+        ip, imem, ishape, idt, istr, k0 = describe(primitive_image, 2, "primitive image", self.device)
+        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device)
         if idt not in _IDX_CODES:
             raise ValueError("primitive image dtype must be one of uint32/int32/uint64/int64, got %s" % idt)
         if pdt != np.float32:
             if pmem == _lib.MEM_HOST and pdt.kind == "f":
                 probs_image = np.asarray(probs_image, dtype=np.float32)
-                pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image")
+                pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device)
             else:
                 raise ValueError("probs image must be float32, got %s" % pdt)
         wp, wmem, wstr, k2, wshape = None, _lib.MEM_HOST, None, None, None
         if weights_image is not None:
-            wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image")
+            wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device)
             if wdt != np.float32:
                 if wmem == _lib.MEM_HOST and wdt.kind == "f":
                     weights_image = np.asarray(weights_image, dtype=np.float32)
-                    wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image")
+                    wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device)
                 else:
                     raise ValueError("weights image must be float32, got %s" % wdt)
         if tuple(ishape) != tuple(pshape[:2]) or (wshape is not None and tuple(wshape) != tuple(ishape)):
@@ -135,14 +135,14 @@ class _MeshAggregator:
     def fuse_view(self, renderer, camera, probs_image, weights_image=None):
         """render(camera) + add(indices, probs) in one call without the indices leaving the device."""
         W, H = camera.resolution
-        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image")
+        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device)
         if tuple(pshape) != (W, H, self.classes) or pdt != np.float32:
             raise ValueError("probs image must be float32 (W,H,C) = %s" % ((W, H, self.classes),))
         if pstr != (H * self.classes, self.classes, 1):
             raise ValueError("fuse_view needs a contiguous (W,H,C) probs image")
         wp = None
         if weights_image is not None:
-            wp_, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image")
+            wp_, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device)
             if tuple(wshape) != (W, H) or wdt != np.float32 or wstr != (H, 1) or wmem != pmem:
                 raise ValueError("weights image must be contiguous float32 (W,H) in the same memory as probs")
             wp = ctypes.c_void_p(wp_)
@@ -164,7 +164,7 @@ class _MeshAggregator:
         for i, cam in enumerate(cameras):
             W, H = cam.resolution
             pods[i] = cam._pod
-            pp, pmem, pshape, pdt, pstr, k1 = describe(probs_images[i], 3, "probs image")
+            pp, pmem, pshape, pdt, pstr, k1 = describe(probs_images[i], 3, "probs image", self.device)
             if tuple(pshape) != (W, H, self.classes) or pdt != np.float32:
                 raise ValueError("probs image %d must be float32 (W,H,C) = %s" % (i, (W, H, self.classes)))
             if pstr != (H * self.classes, self.classes, 1):
@@ -177,7 +177,7 @@ class _MeshAggregator:
             keep.append(k1)
             w = None if weights_images is None else weights_images[i]
             if w is not None:
-                wp_, wmem, wshape, wdt, wstr, k2 = describe(w, 2, "weights image")
+                wp_, wmem, wshape, wdt, wstr, k2 = describe(w, 2, "weights image", self.device)
                 if tuple(wshape) != (W, H) or wdt != np.float32 or wstr != (H, 1) or wmem != mem:
                     raise ValueError("weights image %d must be contiguous float32 (W,H) in the same memory as probs" % i)
                 wptr[i] = wp_
@@ -207,7 +207,7 @@ class ModelRenderer:
     def render(self, primitive_image, background=None):
         """float32 (W,H,C) image: annotation of the primitive under each pixel, `background` (C floats,
         default zeros) where the index is out of range."""
-        ip, imem, ishape, idt, istr, keep = describe(primitive_image, 2, "primitive image")
+        ip, imem, ishape, idt, istr, keep = describe(primitive_image, 2, "primitive image", self.device)
         if idt not in _IDX_CODES:
             raise ValueError("primitive image dtype must be one of uint32/int32/uint64/int64, got %s" % idt)
         bg = np.zeros(self.classes, np.float32) if background is None else np.ascontiguousarray(background, dtype=np.float32)

@@ -17,7 +17,7 @@ from .device import DeviceArray, DeviceBuffer
 CONFIGS = {
     "cfg1": dict(a=100, b=50, width=640, height=480, classes=5, views=4),
     "cfg2": dict(a=1000, b=500, width=1920, height=1080, classes=19, views=200),
-    "cfg4": dict(a=2500, b=1000, width=1296, height=968, classes=40, views=1000),
+    "cfg4": dict(a=2500, b=1000, width=1296, height=968, classes=40, views=1000, texels=True),   # render.texels path
     "cfg5": dict(a=5000, b=2000, width=4096, height=2160, classes=150, views=500),
 }
 

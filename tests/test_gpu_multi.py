@@ -1,0 +1,210 @@
+"""GPU tests of the exchange step and of the stream contract with other frameworks.
+
+* native `smesh_allreduce` (RCCL on the library's stream, no PyTorch): world size 1 here (the GPU box has one device;
+  two devices when present), `get()` equal to the single-rank job;
+* the torch.distributed `nccl` in-place path with a forced world-size-1 all-reduce: aliasing, no copy;
+* device inputs produced by torch on ITS stream are ordered before the library's kernels (the library's streams
+  are non-blocking);
+* `__cuda_array_interface__` of a render() result waits for the rasteriser.
+"""
+import ctypes
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from helpers import assert_fused_close, random_probs, small_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _fuse_all(sm, mesh, cams, probs, C, kind="sum", device=0):
+    r = sm.render.triangles(mesh, device=device)
+    agg = sm.fusion.MeshAggregator(len(mesh.faces), C, kind, device=device)
+    for cam, p in zip(cams, probs):
+        agg.fuse_view(r, cam, p)
+    return r, agg
+
+
+def test_native_allreduce_world_one_is_identity_and_async(sm):
+    from semantic_meshes_amd import comm, _lib
+    mesh, cams = small_scene(40, 20, 160, 120, views=4)
+    C = 19
+    rng = np.random.default_rng(5)
+    probs = [random_probs(rng, 160, 120, C) for _ in cams]
+    _, whole = _fuse_all(sm, mesh, cams, probs, C)
+    want_raw, want = whole.get_raw(), whole.get()
+    c = comm.Communicator(0, 0, 1, comm.Communicator.unique_id())
+    r, agg = _fuse_all(sm, mesh, cams, probs, C)
+    c.allreduce(agg)                      # enqueued behind the fusion kernels, no host wait in between
+    np.testing.assert_array_equal(agg.get_raw(), want_raw)
+    np.testing.assert_array_equal(agg.get(), want)
+    assert c.reduce_scalars([1.5, -2.0], "max") == [1.5, -2.0]
+    assert c.reduce_scalars([3.0], "sum") == [3.0]
+    c.barrier()
+    # from_env with the launcher's variables, world size 1
+    env = dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29431")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        c2 = comm.Communicator.from_env()
+        c2.allreduce(agg)
+        np.testing.assert_array_equal(agg.get(), want)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    # errors: a communicator of another device / NULL handles are rejected, not crashed on
+    with pytest.raises(ValueError):
+        _lib.check(_lib.lib().smesh_allreduce(None, None, 1))
+
+
+def test_native_allreduce_all_devices_of_this_box(sm):
+    """smesh_comm_create_all over every visible GPU (1 on the round's box, 8 on a node): views dealt round-robin,
+    one grouped all-reduce, every device's get() equals the single-device fusion within the float tolerance."""
+    from semantic_meshes_amd import comm, _lib
+    ndev = _lib.device_count()
+    mesh, cams = small_scene(36, 18, 128, 96, views=max(4, 2 * ndev))
+    C = 7
+    rng = np.random.default_rng(11)
+    probs = [random_probs(rng, 128, 96, C) for _ in cams]
+    _, whole = _fuse_all(sm, mesh, cams, probs, C)
+    want = whole.get()
+    comms = comm.create_all(list(range(ndev)))
+    aggs, keep = [], []
+    for d in range(ndev):
+        r, a = _fuse_all(sm, mesh, cams[d::ndev], probs[d::ndev], C, device=d)
+        aggs.append(a)
+        keep.append(r)
+    comm.allreduce_all(comms, aggs)
+    for a in aggs:
+        got = a.get()
+        if ndev == 1:
+            np.testing.assert_array_equal(got, want)
+        else:
+            assert_fused_close(got, want)
+
+
+def _torch():
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.fail("torch sees no GPU on a gpu-marked run")
+    return torch
+
+
+def test_torch_nccl_in_place_allreduce_world_one(sm):
+    """distributed.allreduce_raw under backend nccl: torch aliases the padded accumulator (no copy), the all-reduce of a
+    world of one leaves it bit-identical, and the library's later work is ordered after torch's stream."""
+    torch = _torch()
+    import torch.distributed as dist
+    from semantic_meshes_amd import distributed as smdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        mesh, cams = small_scene(40, 20, 160, 120, views=3)
+        C = 19
+        rng = np.random.default_rng(6)
+        probs = [random_probs(rng, 160, 120, C) for _ in cams]
+        _, agg = _fuse_all(sm, mesh, cams, probs, C)
+        want_raw = agg.get_raw()
+        flat = agg.raw_device_array(padded=True)
+        t = torch.as_tensor(flat, device="cuda:0")
+        assert t.data_ptr() == flat.ptr and t.numel() == flat.size
+        os.environ["SMESH_FORCE_ALLREDUCE"] = "1"
+        try:
+            smdist.allreduce_raw(agg)
+        finally:
+            os.environ.pop("SMESH_FORCE_ALLREDUCE", None)
+        np.testing.assert_array_equal(agg.get_raw(), want_raw)
+        # and the sharded helper end to end (world 1: every view is this rank's)
+        r = sm.render.triangles(mesh)
+        agg2 = sm.fusion.MeshAggregator(len(mesh.faces), C)
+        smdist.fuse_views_sharded(r, agg2, cams, lambda k: probs[k])
+        np.testing.assert_array_equal(agg2.get_raw(), want_raw)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_torch_produced_probs_are_ordered_before_the_fusion(sm, oracle):
+    """probs = net(x) on torch's stream; add(idx, probs) right away.  The library's kernels must see the finished tensor:
+    a long chain of torch kernels writes the probabilities last."""
+    torch = _torch()
+    mesh, cams = small_scene(60, 30, 640, 480, views=2)
+    W, H, C = 640, 480, 19
+    P = len(mesh.faces)
+    rng = np.random.default_rng(8)
+    base = random_probs(rng, W, H, C, 0.0)
+    r = sm.render.triangles(mesh)
+    o_r = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    for trial in range(3):
+        agg = sm.fusion.MeshAggregator(P, C)
+        o_a = oracle.OracleAggregator(P, C)
+        for cam in cams:
+            idx, _ = r.render(cam)
+            t = torch.zeros((W, H, C), device="cuda:0")
+            big = torch.ones((4096, 4096), device="cuda:0")
+            for _ in range(6):                       # keep torch's stream busy for a few milliseconds ...
+                big = big @ big * 1e-4
+            t += torch.from_numpy(base).to("cuda:0") * (big[0, 0] * 0 + 1)    # ... and only then write the probabilities
+            agg.add(idx, t)                          # no torch.cuda.synchronize() in between
+            o_a.add(o_r.render(cam)[0], base)
+        np.testing.assert_array_equal(agg.get_raw(), o_a.get_raw())
+
+
+def test_cuda_array_interface_waits_for_the_render(sm, oracle):
+    torch = _torch()
+    from semantic_meshes_amd import synth
+    mesh, cams, _ = synth.scene("cfg2")
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    for k in (3, 50):
+        idx, depth = r.render(cams[k])
+        t = torch.as_tensor(idx, device="cuda:0").clone()     # consumed on torch's stream straight away
+        oidx, _ = o.render(cams[k])
+        np.testing.assert_array_equal(t.cpu().numpy().view(np.uint32), oidx)
+
+
+def test_profile_counts_launches_and_views(sm):
+    """smesh_profile_read_ex: launches / views of the dominant kernel inside the timed regions (bench.py's roofline divisor)."""
+    from semantic_meshes_amd import _lib, synth
+    mesh, cams = small_scene(60, 30, 320, 240, views=11)
+    C = 19
+    P = len(mesh.faces)
+    probs = [synth.device_probs(320, 240, C, 40 + k) for k in range(len(cams))]
+    r = sm.render.triangles(mesh)
+    agg = sm.fusion.MeshAggregator(P, C)
+    L = _lib.lib()
+
+    def read():
+        ms, reg, n, v = ctypes.c_double(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(L.smesh_profile_read_ex(0, _lib.PROF_FUSE_SCATTER, ctypes.byref(ms), ctypes.byref(reg), ctypes.byref(n), ctypes.byref(v)))
+        return ms.value, reg.value, n.value, v.value
+
+    agg.fuse_views(r, cams[:8], probs[:8])       # warm
+    _lib.check(L.smesh_profile_reset(0))
+    _lib.check(L.smesh_profile_sample_every(0, 1))
+    _lib.check(L.smesh_profile_enable(0, 1 << _lib.PROF_FUSE_SCATTER))
+    try:
+        agg.fuse_views(r, cams[:8], probs[:8])   # one region: 4 launches of 2 views
+        ms, reg, n, v = read()
+        assert (reg, n, v) == (1, 4, 8) and ms > 0
+        agg.fuse_views(r, cams[8:11], probs[8:11])   # group of 3: a pair launch and a single
+        ms, reg, n, v = read()
+        assert (reg, n, v) == (2, 6, 11)
+        agg.fuse_view(r, cams[0], probs[0])
+        assert read()[1:] == (3, 7, 12)
+        _lib.check(L.smesh_profile_sample_every(0, 2))   # every second region: counters follow the TIMED regions only
+        _lib.check(L.smesh_profile_reset(0))
+        for _ in range(4):
+            agg.fuse_view(r, cams[1], probs[1])
+        assert read()[1:] == (2, 2, 2)
+    finally:
+        _lib.check(L.smesh_profile_enable(0, 0))
+        _lib.check(L.smesh_profile_sample_every(0, 1))
