@@ -209,14 +209,27 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
 int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cameras, uint64_t n,
                      const float* const* probs, const float* const* weights, int memkind);
 
-/* add() for an index image that is the UNMODIFIED device output `indices_dev` of one of r's two most recent
+/* add() for an index image that is the UNMODIFIED device output `indices_dev` of one of r's six most recent
  * smesh_renderer_render_device() calls: the reference's two-call convention `idx, depth = renderer.render(cam);
  * aggregator.add(idx, probs)` (python/scripts/colorize_cityscapes_mesh.py:65-67) then runs the same triangle-order
- * fusion as smesh_fuse_view, using the per-triangle records that render left behind.  Same results as smesh_aggregator_add;
+ * fusion as smesh_fuse_view, using the per-triangle records that render left behind.  Same results as smesh_aggregator_add,
+ * and like it synchronous for DEVICE inputs (they may be freed or overwritten as soon as it returns);
  * if `idx_dev` is anything else, or the layout is not the dense (W,H[,C]) one, the call IS smesh_aggregator_add. */
 int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, const uint32_t* idx_dev,
                                   const float* probs, const int64_t probs_strides[3], int probs_mem,
                                   const float* weights, const int64_t w_strides[2], int w_mem, uint64_t W, uint64_t H);
+
+/* add() for an index image that has lost its identity but not its CONTENT: an image that went through another framework or the
+ * host (DLPack -> TF -> numpy -> add, eval-scannet/eval_scannet.py:211-238).  If `indices` is a dense (W,H) uint32 / int32 image, HOST
+ * or DEVICE, whose 64-bit content checksum (sum over the pixels of a bijective mix of position and value: a single changed pixel
+ * always changes it) equals that of a plane produced by one of r's six most recent smesh_renderer_render_device() calls whose
+ * per-triangle records are still held, the view is fused in triangle order exactly like smesh_aggregator_add_rendered -- reading
+ * the given image -- and *matched = 1.  Otherwise NOTHING is added and *matched = 0: call smesh_aggregator_add.  Synchronous. */
+int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
+                                 const void* indices, int idx_dtype, const int64_t idx_strides[2], int idx_memkind,
+                                 const float* probs, const int64_t probs_strides[3], int probs_mem,
+                                 const float* weights, const int64_t w_strides[2], int w_mem,
+                                 uint64_t width, uint64_t height, int* matched);
 
 /* Name of the fusion kernel the last smesh_fuse_view() / smesh_aggregator_add_rendered() on this thread dispatched ("k_fuse_tri": triangle-order
  * gather-accumulate, no atomics; "k_fuse_tri_any": the same for any class count; "k_scatter_strip": generic segmented scatter-add).  For reporting. */

@@ -490,9 +490,11 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
       if (g_accum_double) a->accd[primitive_index * C + m] += (double)(next[m] * w);
       else a->acc[primitive_index * C + m] = a->acc[primitive_index * C + m] + next[m] * w;
     } else {
-      // Fusion.cu:83-87: map_input(pow) -> prod of LogProb<float>: L += log(p^w)   (B-6)
+      // Fusion.cu:83-87: map_input(pow) -> prod of LogProb<float>: L += log(p^w).  Whether p^w is rounded to float before
+      // the log is decided inside the absent template-tensors; the spec (the same formula in the HIP
+      // kernels) is w * log(p) in float32 with p^0 = 1 for every p.
       for (uint32_t c = 0; c < C; c++) {
-        const float l = std::log(std::pow(next[c], w));
+        const float l = w == 0.0f ? 0.0f : w * std::log(next[c]);
         if (g_accum_double) a->accd[primitive_index * C + c] += (double)l;
         else a->acc[primitive_index * C + c] = a->acc[primitive_index * C + c] + l;
       }
@@ -613,6 +615,11 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
 }
 
 // --------------------------------------------------------------------------------------------
+int smesh_aggregator_add_matched(smesh_aggregator_t*, smesh_renderer_t*, const void*, int, const int64_t*, int, const float*, const int64_t*, int,
+                                 const float*, const int64_t*, int, uint64_t, uint64_t, int* matched) {
+  if (matched) *matched = 0;   // the oracle keeps no per-render records: every add() is the reference's scatter
+  return SMESH_OK;
+}
 const char* smesh_last_fuse_kernel(void) { return "oracle"; }
 int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, const uint32_t* idx, const float* probs,
                                   const int64_t ps[3], int pmem, const float* weights, const int64_t ws[2], int wmem,

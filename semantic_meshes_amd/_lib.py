@@ -74,6 +74,9 @@ SIGNATURES = {
     "smesh_annotation_renderer_destroy": (c_int, [c_void_p]),
     "smesh_fuse_view": (c_int, [c_void_p, c_void_p, P(CameraPOD), c_void_p, c_void_p, c_int]),
     "smesh_fuse_views": (c_int, [c_void_p, c_void_p, P(CameraPOD), c_u64, P(c_void_p), P(c_void_p), c_int]),
+    "smesh_aggregator_add_matched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int,
+                                             c_void_p, P(ctypes.c_int64), c_int,
+                                             c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64, P(c_int)]),
     "smesh_last_fuse_kernel": (ctypes.c_char_p, []),
     "smesh_profile_enable": (c_int, [c_int, c_int]),
     "smesh_profile_sample_every": (c_int, [c_int, ctypes.c_uint32]),

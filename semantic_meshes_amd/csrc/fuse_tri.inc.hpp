@@ -8,15 +8,25 @@ constexpr int kWave = 64;
 // ------------------------------------------------------------------------------------------------
 // aggregator input maps (Fusion.cu:51-56 Summax, :70-73 Sum, :83-87 Mul)
 // ------------------------------------------------------------------------------------------------
-// Mul: LogProb<float>(pow(p, w)) (Fusion.cu:83-87) = log(p^w).  Whenever p^w is a NORMAL float that is w * log(p) to within the
-// rounding the two-step form has itself (pow rounds p^w to 24 bits: 6e-8 absolute in the log; log rounds again), at an eighth of
-// the instructions -- powf made the Mul aggregator three times slower than Sum.  Where p^w leaves the normal range (underflow to
-// zero or denormals, overflow) or the inputs are not positive finite numbers, the two-step form decides: -inf, NaN and the
-// coarse denormal steps are part of the reference's behaviour.
+// Mul: LogProb<float>(pow(p, w)) (Fusion.cu:83-87) = log(p^w).  Whether the reference rounds p^w to float before the log is
+// decided inside the absent template-tensors; the spec here -- the same one formula in the oracle -- is
+// w * log(p) in float32, with p^0 = 1 for every p (so w == 0 contributes nothing, also for p = 0), p = 0 -> -inf,
+// p < 0 -> NaN.  No pow: nothing underflows, no platform-dependent denormals, an eighth of the instructions.
 __device__ __forceinline__ float log_of_power(float p, float w) {
-  const float t = w * logf(p);
-  if (p > 0.0f && isfinite(p) && isfinite(w) && t > -87.0f && t < 88.0f) return t;   // e^-87 .. e^88 is inside float's normal range
-  return logf(powf(p, w));
+  return w == 0.0f ? 0.0f : w * logf(p);
+}
+
+// Mul rows are log-domain sums whose common offset cancels in get() (logprob_normalize divides by the largest element,
+// Fusion.h:97-104), and so does it in the cross-GPU sum.  The state is float32 like the reference's LogProb<float>: to keep
+// the roundings of a long fusion small, a row is re-centred on its largest finite element whenever a view adds to it, and
+// the view's own contributions are summed separately (from zero) before they meet the row.  The elements that matter in the
+// output -- those within a few units of the maximum -- then stay small numbers with small ulps however many views were fused.
+template <int CT, bool EXACT>
+__device__ __forceinline__ float row_centre(const float (&r)[CT], int C) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < CT; c++) if (EXACT || c < C) if (r[c] > m && r[c] < INFINITY) m = r[c];
+  return m > -INFINITY ? m : 0.0f;
 }
 
 template <int KIND>
@@ -55,6 +65,16 @@ __device__ __forceinline__ float wave_sum(float v) {   // same value in every la
   v += dpp_f<kDppRowShr8>(0.0f, v);
   v += dpp_f<kDppRowBcast15, 0xA>(0.0f, v);
   v += dpp_f<kDppRowBcast31, 0xC>(0.0f, v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ float wave_max(float v) {   // same value in every lane; lanes that must not take part pass -inf
+  v = fmaxf(v, dpp_f<kDppRowShr1>(-INFINITY, v));
+  v = fmaxf(v, dpp_f<kDppRowShr2>(-INFINITY, v));
+  v = fmaxf(v, dpp_f<kDppRowShr4>(-INFINITY, v));
+  v = fmaxf(v, dpp_f<kDppRowShr8>(-INFINITY, v));
+  v = fmaxf(v, dpp_f<kDppRowBcast15, 0xA>(-INFINITY, v));
+  v = fmaxf(v, dpp_f<kDppRowBcast31, 0xC>(-INFINITY, v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
@@ -127,7 +147,7 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
   constexpr int U = CT <= 24 ? 4 : 2;
   auto pix_of = [&](long long i) -> uint64_t { return (uint64_t)(x0 + (int)(i / bh)) * a.H + (uint64_t)(y0 + (int)(i % bh)); };
   // this wave owns the row: its current value is requested now and written back at the end (plain read-modify-write)
-  const float row_value = (l < C) ? a.acc[(uint64_t)f * C + l] : 0.0f;
+  float row_value = (l < C) ? a.acc[(uint64_t)f * C + l] : 0.0f;
   const bool one_step = npx <= (long long)kWave * U;   // the whole box in one round of index loads
   uint32_t mine_n = 0, hits = 0;                        // this lane's pixels of the triangle (bit u of `hits`: slot u of the one round)
   for (long long base = 0; base < npx; base += (long long)kWave * U) {
@@ -145,6 +165,10 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
   const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
   if (n == 0) return;
   const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
+  if (KIND == SMESH_AGG_MUL) {   // re-centre the row on its largest finite element (see row_centre); lane c holds class c
+    const float m = wave_max((l < C && row_value < INFINITY) ? row_value : -INFINITY);
+    if (m > -INFINITY) row_value = row_value - m;
+  }
   float part[CT];
 #pragma unroll
   for (int c = 0; c < CT; c++) part[c] = 0.0f;
@@ -339,8 +363,14 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b
   }
   float accr[CT];
   bool rows_loaded = false;
+  // Mul: the view's contributions are summed from zero (in double where the registers allow it) and meet the re-centred row once
+  typedef typename std::conditional<(CT <= 24), double, float>::type part_t;
+  constexpr int PT = KIND == SMESH_AGG_MUL ? CT : 1;
 #pragma unroll
   for (int v = 0; v < NV; v++) {
+    part_t part[PT];
+#pragma unroll
+    for (int c = 0; c < PT; c++) part[c] = (part_t)0;
     const float* __restrict__ probs = v ? b.probs : a.probs;
     const float* __restrict__ weights = v ? b.weights : a.weights;
     float w0 = 0.0f;
@@ -398,12 +428,20 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b
             for (int c = 1; c < CT; c++) if (EXACT || c < C) if (p[j][c] > best) { best = p[j][c]; am = c; }
 #pragma unroll
             for (int c = 0; c < CT; c++) if (EXACT || c < C) if (c == am) accr[c] = accr[c] + p[j][c] * w;
+          } else if (KIND == SMESH_AGG_MUL) {
+#pragma unroll
+            for (int c = 0; c < PT; c++) if (EXACT || c < C) part[c] = part[c] + (part_t)contribution<KIND>(p[j][c], w);
           } else {
 #pragma unroll
             for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = accr[c] + contribution<KIND>(p[j][c], w);
           }
         }
       }
+    }
+    if (KIND == SMESH_AGG_MUL && n[v]) {   // (n[v] != 0: the loop above ran, so this lane's row is in accr)
+      const float m = row_centre<CT, EXACT>(accr, C);
+#pragma unroll
+      for (int c = 0; c < PT; c++) if (EXACT || c < C) accr[c] = (float)((part_t)(accr[c] - m) + part[c]);
     }
   }
   if (scattered) {

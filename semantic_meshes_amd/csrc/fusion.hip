@@ -33,6 +33,7 @@
 #include <cstdlib>
 #include <new>
 #include <string>
+#include <type_traits>
 
 using namespace smesh;
 
@@ -1355,6 +1356,20 @@ int launch_hist(const ScatterArgs& a, hipStream_t st) {
 
 }  // namespace
 
+// Mul only: re-centre every accumulator row on its largest finite element (fuse_tri.inc.hpp, row_centre) ahead of the
+// fusion kernels that add pixel by pixel into the row (k_fuse_tri does it itself, per view, in registers).
+namespace {
+__global__ void k_mul_recentre(float* __restrict__ acc, uint64_t P, uint32_t C, uint32_t S) {
+  const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  float* __restrict__ row = acc + p * S;
+  float m = -INFINITY;
+  for (uint32_t c = 0; c < C; c++) { const float v = row[c]; if (v > m && v < INFINITY) m = v; }
+  if (!(m > -INFINITY) || m == 0.0f) return;
+  for (uint32_t c = 0; c < C; c++) row[c] = row[c] - m;
+}
+}  // namespace
+
 struct smesh_aggregator {
   DeviceCtx* ctx = nullptr;
   uint64_t P = 0;
@@ -1374,6 +1389,13 @@ struct smesh_aggregator {
 };
 
 namespace {
+
+int mul_recentre(smesh_aggregator* a) {
+  if (a->kind != SMESH_AGG_MUL || a->P == 0) return SMESH_OK;
+  hipLaunchKernelGGL(k_mul_recentre, dim3((uint32_t)div_up(a->P, 256)), dim3(256), 0, a->ctx->stream, a->acc, a->P, a->C, a->S);
+  SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
+}
 
 int stage_in(DeviceCtx* ctx, Scratch& st, const void* host, size_t bytes, const void** dev) {
   SMESH_TRY(st.reserve(bytes));
@@ -1446,6 +1468,7 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
   }
 
   // ---- F2 scatter-add -------------------------------------------------------------------------
+  SMESH_TRY(mul_recentre(a));
   if (strip_path(C)) {
     args.pw = nullptr;
     if (need_hist || weights) {
@@ -1611,6 +1634,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   const uint32_t big_waves = big_per_cu * (uint32_t)std::max(1, ctx->num_cus);    // one wave per queued big triangle at a time; they exit at once if the queue is empty
   const dim3 grid(t.tri_blocks + big_waves), block(kWave);
   const dim3 tgrid(t.tri_blocks), bgrid(big_waves);                        // any-C paths: big triangles in a second launch
+  if (!specialised) SMESH_TRY(mul_recentre(a));
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
     prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, (uint64_t)nviews);
@@ -1683,6 +1707,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   t.dbg = 0; t.prim_id = nullptr;
   t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count;
   const dim3 tgrid(t.tri_blocks), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave);
+  SMESH_TRY(mul_recentre(a));
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
     prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, 1);

@@ -4,6 +4,9 @@
 
 #include "common.hpp"
 
+#include <cmath>
+#include <type_traits>
+
 using namespace smesh;
 
 namespace {

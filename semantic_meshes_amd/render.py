@@ -22,12 +22,19 @@ def _mesh_arrays(mesh):
     return v, f
 
 
+import weakref
+
+_live_renderers = weakref.WeakSet()   # MeshAggregator.add looks here for the render a foreign index image is a copy of
+
+
 class _Renderer:
     """Common part of PlyRendererTriangles / PlyRendererTexels (Renderer.h:12-43)."""
 
     def __init__(self, handle, device):
         self._h = handle
         self.device = device
+        self._primitives = None
+        _live_renderers.add(self)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -38,9 +45,11 @@ class _Renderer:
                 pass
 
     def getPrimitivesNum(self):
-        n = ctypes.c_uint64()
-        _lib.check(_lib.lib().smesh_renderer_num_primitives(self._h, ctypes.byref(n)))
-        return int(n.value)
+        if self._primitives is None:
+            n = ctypes.c_uint64()
+            _lib.check(_lib.lib().smesh_renderer_num_primitives(self._h, ctypes.byref(n)))
+            self._primitives = int(n.value)
+        return self._primitives
 
     def render(self, camera):
         """Rasterise the mesh for `camera`; returns `(primitive_indices, depth)`:

@@ -28,5 +28,7 @@ def assert_fused_close(got, want, rtol=1e-5, atol=2e-7):
     err = np.abs(got - want)
     tol = atol + rtol * np.abs(want)
     bad = err > tol
-    assert not bad.any(), "%d / %d elements out of tolerance, worst abs err %.3e (want %.6g got %.6g)" % (
-        bad.sum(), bad.size, err.max(), want.flat[err.argmax()], got.flat[err.argmax()])
+    if bad.any():
+        need = ((err - atol) / np.maximum(np.abs(want), 1e-300))[bad].max()   # the rtol that would have passed
+        raise AssertionError("%d / %d elements out of tolerance (rtol %.1e would need %.2e), worst abs err %.3e (want %.6g got %.6g)" % (
+            bad.sum(), bad.size, rtol, need, err.max(), want.flat[err.argmax()], got.flat[err.argmax()]))

@@ -8,7 +8,7 @@ r = render.triangles(mesh)
 probs = synth.device_probs(W, H, C, 1, 0.0)
 cams = [synth.ring_camera(k, 100, W, H) for k in range(100)]
 agg = fusion.MeshAggregator(len(mesh.faces), C)
-for mode in ("fuse_view", "render + add", "render + add (index image exported first: generic scatter-add)"):
+for mode in ("fuse_view", "render + add", "render + add (index image exported first: recognised by content)", "render + add (exported, SMESH_MATCH off: generic scatter-add)"):
     for rep in range(2):
         _lib.synchronize(0)
         t0 = time.perf_counter()
@@ -19,6 +19,7 @@ for mode in ("fuse_view", "render + add", "render + add (index image exported fi
                 idx, depth = r.render(cam)
                 if "exported" in mode:
                     _ = idx.__cuda_array_interface__
+                fusion._MeshAggregator.match_renders = "MATCH off" not in mode
                 agg.add(idx, probs)
         _lib.synchronize(0)
         dt = (time.perf_counter() - t0) / len(cams)
