@@ -85,6 +85,10 @@ int smesh_synchronize(int device);
  * another framework wrote on its own stream.  smesh_stream_handle returns the library's main hipStream_t so that a consumer can
  * order its own work after the library's (smesh_synchronize is the blocking alternative). */
 int smesh_stream_wait(int device, void* producer_stream);
+/* The other direction, for the asynchronous entry points (smesh_fuse_view(s), smesh_aggregator_add_rendered / _add_matched with DEVICE
+ * images): `consumer_stream` (NULL = the legacy default stream) waits for everything the library has queued so far, so that the
+ * owner of a DEVICE buffer can overwrite or free it on that stream without a host synchronisation. */
+int smesh_stream_release(int device, void* consumer_stream);
 int smesh_stream_handle(int device, void** stream);
 
 /* ---- triangle renderer --------------------------------------------------------------------- */
@@ -212,8 +216,8 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
 /* add() for an index image that is the UNMODIFIED device output `indices_dev` of one of r's six most recent
  * smesh_renderer_render_device() calls: the reference's two-call convention `idx, depth = renderer.render(cam);
  * aggregator.add(idx, probs)` (python/scripts/colorize_cityscapes_mesh.py:65-67) then runs the same triangle-order
- * fusion as smesh_fuse_view, using the per-triangle records that render left behind.  Same results as smesh_aggregator_add,
- * and like it synchronous for DEVICE inputs (they may be freed or overwritten as soon as it returns);
+ * fusion as smesh_fuse_view, using the per-triangle records that render left behind.  Same results as smesh_aggregator_add, but
+ * ASYNCHRONOUS for DEVICE probs / weights like smesh_fuse_view: keep them valid until smesh_stream_release / smesh_synchronize;
  * if `idx_dev` is anything else, or the layout is not the dense (W,H[,C]) one, the call IS smesh_aggregator_add. */
 int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, const uint32_t* idx_dev,
                                   const float* probs, const int64_t probs_strides[3], int probs_mem,
@@ -224,12 +228,20 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
  * or DEVICE, whose 64-bit content checksum (sum over the pixels of a bijective mix of position and value: a single changed pixel
  * always changes it) equals that of a plane produced by one of r's six most recent smesh_renderer_render_device() calls whose
  * per-triangle records are still held, the view is fused in triangle order exactly like smesh_aggregator_add_rendered -- reading
- * the given image -- and *matched = 1.  Otherwise NOTHING is added and *matched = 0: call smesh_aggregator_add.  Synchronous. */
+ * the given image -- and *matched = 1.  Otherwise NOTHING is added and *matched = 0: call smesh_aggregator_add.  Only planes that
+ * were sealed (smesh_renderer_seal_render) take part.  Waits once for the checksum; the fusion itself is asynchronous for DEVICE
+ * images like smesh_aggregator_add_rendered. */
 int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
                                  const void* indices, int idx_dtype, const int64_t idx_strides[2], int idx_memkind,
                                  const float* probs, const int64_t probs_strides[3], int probs_mem,
                                  const float* weights, const int64_t w_strides[2], int w_mem,
                                  uint64_t width, uint64_t height, int* matched);
+
+/* Computes (once) the content checksum of the plane `indices_dev` returned by one of r's last smesh_renderer_render_device() calls,
+ * which is what makes copies of it recognisable by smesh_aggregator_add_matched.  Call it while the plane still holds what the
+ * rasteriser wrote: before handing the pointer to another framework or copying the image to the host (the Python layer does, in
+ * `__cuda_array_interface__` / `__dlpack__` / numpy conversion).  The plain render -> add loop neither needs nor pays it. */
+int smesh_renderer_seal_render(smesh_renderer_t* r, const uint32_t* indices_dev);
 
 /* Name of the fusion kernel the last smesh_fuse_view() / smesh_aggregator_add_rendered() on this thread dispatched ("k_fuse_tri": triangle-order
  * gather-accumulate, no atomics; "k_fuse_tri_any": the same for any class count; "k_scatter_strip": generic segmented scatter-add).  For reporting. */

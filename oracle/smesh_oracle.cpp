@@ -620,6 +620,7 @@ int smesh_aggregator_add_matched(smesh_aggregator_t*, smesh_renderer_t*, const v
   if (matched) *matched = 0;   // the oracle keeps no per-render records: every add() is the reference's scatter
   return SMESH_OK;
 }
+int smesh_renderer_seal_render(smesh_renderer_t*, const uint32_t*) { return SMESH_OK; }
 const char* smesh_last_fuse_kernel(void) { return "oracle"; }
 int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, const uint32_t* idx, const float* probs,
                                   const int64_t ps[3], int pmem, const float* weights, const int64_t ws[2], int wmem,
@@ -628,6 +629,7 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, cons
   return smesh_aggregator_add(a, idx, SMESH_IDX_U32, is, SMESH_MEM_HOST, probs, ps, pmem, weights, ws, wmem, W, H);
 }
 int smesh_stream_wait(int, void*) { return SMESH_OK; }   // the oracle has no streams: everything is synchronous
+int smesh_stream_release(int, void*) { return SMESH_OK; }
 int smesh_stream_handle(int, void** s) { if (s) *s = nullptr; return SMESH_OK; }
 // multi-GPU exchange: not part of the CPU restatement (tests sum the shards' raw accumulators themselves)
 int smesh_comm_unique_id(uint8_t*) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }

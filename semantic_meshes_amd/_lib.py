@@ -39,6 +39,7 @@ SIGNATURES = {
     "smesh_device_count": (c_int, [P(c_int)]),
     "smesh_synchronize": (c_int, [c_int]),
     "smesh_stream_wait": (c_int, [c_int, c_void_p]),
+    "smesh_stream_release": (c_int, [c_int, c_void_p]),
     "smesh_stream_handle": (c_int, [c_int, P(c_void_p)]),
     "smesh_renderer_create_triangles": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_int, P(c_void_p)]),
     "smesh_renderer_create_texels": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64, c_float, c_int, P(c_void_p)]),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "smesh_aggregator_add_matched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int,
                                              c_void_p, P(ctypes.c_int64), c_int,
                                              c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64, P(c_int)]),
+    "smesh_renderer_seal_render": (c_int, [c_void_p, c_void_p]),
     "smesh_last_fuse_kernel": (ctypes.c_char_p, []),
     "smesh_profile_enable": (c_int, [c_int, c_int]),
     "smesh_profile_sample_every": (c_int, [c_int, ctypes.c_uint32]),

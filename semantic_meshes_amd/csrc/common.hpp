@@ -46,6 +46,7 @@ struct DeviceCtx {
   hipStream_t stream = nullptr;         // main stream: fusion kernels, copies, everything by default
   hipStream_t raster_stream = nullptr;  // smesh_fuse_view rasterises view k+1 here while view k is being fused
   hipEvent_t ev_order = nullptr;        // smesh_stream_wait: marks the producer's stream
+  hipEvent_t ev_release = nullptr;      // smesh_stream_release: marks the library's stream
   int num_cus = 256;
   unsigned profiling = 0;   // bit s set = bracket slot s with HIP events
   unsigned profile_every = 1;   // ... every n-th region of the slot (an event pair costs ~4 us of stream time)
@@ -102,6 +103,7 @@ struct TriFuseArgs {
   const float* probs;
   const float* weights;       // may be null
   float* acc;                 // [P][C] dense
+  float* acc_lo;              // Mul only: second float32 plane, a row's value is acc + acc_lo (fuse_tri.inc.hpp, "Mul state"); else null
   uint64_t F;
   uint32_t C, W, H;
   float iew;

@@ -150,6 +150,23 @@ int smesh_stream_wait(int device, void* producer_stream) {
   return SMESH_OK;
 }
 
+// The other direction: `consumer_stream` (NULL = the legacy default stream) waits for everything this library has queued so far on
+// `device`.  After an asynchronous entry point (smesh_fuse_view, smesh_aggregator_add_rendered ...) read DEVICE buffers that another
+// framework will overwrite or free on that stream, this keeps the framework's later work behind the library's reads without
+// blocking the host.
+int smesh_stream_release(int device, void* consumer_stream) {
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(device));
+  hipStream_t cs = static_cast<hipStream_t>(consumer_stream);
+  if (cs == ctx->stream) return SMESH_OK;
+  if (!ctx->ev_release) SMESH_HIP(hipEventCreateWithFlags(&ctx->ev_release, hipEventDisableTiming));
+  SMESH_HIP(hipEventRecord(ctx->ev_release, ctx->stream));
+  SMESH_HIP(hipStreamWaitEvent(cs, ctx->ev_release, 0));
+  return SMESH_OK;
+}
+
 // The library's main stream (a hipStream_t) of `device`: consumers that want to order their own work after the library's
 // without a host synchronisation (`__cuda_array_interface__` v3 "stream", `__dlpack__(stream=...)`).
 int smesh_stream_handle(int device, void** stream) {

@@ -16,11 +16,15 @@ __device__ __forceinline__ float log_of_power(float p, float w) {
   return w == 0.0f ? 0.0f : w * logf(p);
 }
 
-// Mul rows are log-domain sums whose common offset cancels in get() (logprob_normalize divides by the largest element,
-// Fusion.h:97-104), and so does it in the cross-GPU sum.  The state is float32 like the reference's LogProb<float>: to keep
-// the roundings of a long fusion small, a row is re-centred on its largest finite element whenever a view adds to it, and
-// the view's own contributions are summed separately (from zero) before they meet the row.  The elements that matter in the
-// output -- those within a few units of the maximum -- then stay small numbers with small ulps however many views were fused.
+// Mul state.  Rows are log-domain sums whose common offset cancels in get() (logprob_normalize divides by the largest element,
+// Fusion.h:97-104), and so does it in the cross-GPU sum.  float32 sums of log-probabilities (the reference's LogProb<float>)
+// lose what matters -- the small DIFFERENCE between the leading classes of a row -- to the ulp of the large sums themselves, so
+// here a Mul row is the unevaluated sum of two float32 planes, acc (hi) + acc_lo, and
+//   * k_fuse_tri / fuse_box sum a view's contributions separately, from zero, in double, and fold them into (hi, lo) once per
+//     view in double: hi + lo carries ~48 bits;
+//   * a row is re-centred on its largest finite element whenever a view adds to it, so that hi stays a small number for the
+//     classes that matter -- which also keeps the kernels that only know the hi plane (any class count, texels, the generic
+//     scatter-add: their float32 additions stay valid, hi + lo is still the value) as accurate as float32 allows.
 template <int CT, bool EXACT>
 __device__ __forceinline__ float row_centre(const float (&r)[CT], int C) {
   float m = -INFINITY;
@@ -66,6 +70,26 @@ __device__ __forceinline__ float wave_sum(float v) {   // same value in every la
   v += dpp_f<kDppRowBcast15, 0xA>(0.0f, v);
   v += dpp_f<kDppRowBcast31, 0xC>(0.0f, v);
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {   // the same reduction tree on doubles (two 32-bit DPP moves per step)
+#define SMESH_DPP_D(CTRL, MASK)                                                                                     \
+  {                                                                                                                 \
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, MASK, 0xF, false);                       \
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, MASK, 0xF, false);                       \
+    v += __hiloint2double(hi, lo);                                                                                  \
+  }
+  SMESH_DPP_D(kDppRowShr1, 0xF) SMESH_DPP_D(kDppRowShr2, 0xF) SMESH_DPP_D(kDppRowShr4, 0xF) SMESH_DPP_D(kDppRowShr8, 0xF)
+  SMESH_DPP_D(kDppRowBcast15, 0xA) SMESH_DPP_D(kDppRowBcast31, 0xC)
+#undef SMESH_DPP_D
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+// Folds a view's contribution `part` into the (hi, lo) pair of one Mul accumulator element, the row shifted by -m.
+__device__ __forceinline__ void mul_fold(float& hi, float& lo, const float m, const double part) {
+  const double t = (((double)hi - (double)m) + (double)lo) + part;
+  hi = (float)t;
+  lo = (hi > -INFINITY && hi < INFINITY) ? (float)(t - (double)hi) : 0.0f;   // (-inf / NaN: no remainder)
 }
 
 __device__ __forceinline__ float wave_max(float v) {   // same value in every lane; lanes that must not take part pass -inf
@@ -165,13 +189,25 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
   const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)upto, 63);
   if (n == 0) return;
   const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
-  if (KIND == SMESH_AGG_MUL) {   // re-centre the row on its largest finite element (see row_centre); lane c holds class c
+  float centre = 0.0f;   // Mul: the row is re-centred on its largest finite element (see "Mul state"); lane c holds class c
+  if (KIND == SMESH_AGG_MUL) {
     const float m = wave_max((l < C && row_value < INFINITY) ? row_value : -INFINITY);
-    if (m > -INFINITY) row_value = row_value - m;
+    if (m > -INFINITY) centre = m;
   }
-  float part[CT];
+  typedef typename std::conditional<KIND == SMESH_AGG_MUL, double, float>::type bpart_t;   // Mul: per-lane partial sums in double
+  bpart_t part[CT];
 #pragma unroll
-  for (int c = 0; c < CT; c++) part[c] = 0.0f;
+  for (int c = 0; c < CT; c++) part[c] = (bpart_t)0;
+  auto write_back = [&](const bpart_t total) {   // lane l < C owns class l of the row
+    if (KIND == SMESH_AGG_MUL) {
+      float hi = row_value, lo = a.acc_lo[(uint64_t)f * C + l];
+      mul_fold(hi, lo, centre, (double)total);
+      a.acc[(uint64_t)f * C + l] = hi;
+      a.acc_lo[(uint64_t)f * C + l] = lo;
+    } else {
+      a.acc[(uint64_t)f * C + l] = row_value + (float)total;
+    }
+  };
   auto accumulate = [&](const float (&p)[CT], const bool hit, const float wt) {
     float sum = 0.0f;
 #pragma unroll
@@ -187,7 +223,7 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
       for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] = (c == am) ? part[c] + p[c] * w : part[c];
     } else {
 #pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] += contribution<KIND>(p[c], w);
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) part[c] += (bpart_t)contribution<KIND>(p[c], w);
     }
   };
   if (one_step && n <= (uint32_t)kWave) {
@@ -210,14 +246,14 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
     float* rows = reinterpret_cast<float*>(lds_list);
     if (hit) {
 #pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) rows[l * C + c] = part[c];
+      for (int c = 0; c < CT; c++) if (EXACT || c < C) rows[l * C + c] = (float)part[c];   // (one pixel's contribution: a float32 term)
     }
     wave_sync();
-    float col = 0.0f;
+    bpart_t col = (bpart_t)0;
     if (l < C)
-      for (uint32_t j = 0; j < n; j++) col += rows[j * (uint32_t)C + (uint32_t)l];
+      for (uint32_t j = 0; j < n; j++) col += (bpart_t)rows[j * (uint32_t)C + (uint32_t)l];
     wave_sync();   // the rows are rewritten by this wave's next triangle
-    if (l < C) a.acc[(uint64_t)f * C + l] = row_value + col;
+    if (l < C) write_back(col);
     return;
   } else {
     for (long long base = 0; base < npx; base += (long long)kWave * U) {
@@ -241,13 +277,14 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
       for (int u = 0; u < U; u++) accumulate(p[u], hit[u], wt[u]);
     }
   }
-  float mine = 0.0f;
+  bpart_t mine = (bpart_t)0;
 #pragma unroll
   for (int c = 0; c < CT; c++) if (EXACT || c < C) {
-    const float v = wave_sum(part[c]);
+    bpart_t v;
+    if constexpr (KIND == SMESH_AGG_MUL) v = wave_sum_d(part[c]); else v = wave_sum(part[c]);
     if (l == c) mine = v;
   }
-  if (l < C) a.acc[(uint64_t)f * C + l] = row_value + mine;
+  if (l < C) write_back(mine);
 }
 
 // Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle (so, unlike the small-triangle
@@ -440,8 +477,14 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b
     }
     if (KIND == SMESH_AGG_MUL && n[v]) {   // (n[v] != 0: the loop above ran, so this lane's row is in accr)
       const float m = row_centre<CT, EXACT>(accr, C);
+      float* __restrict__ lo_row = a.acc_lo + (uint64_t)pid * C;   // the lo plane is read and written by the row's owner lane
+      float lo[PT];
 #pragma unroll
-      for (int c = 0; c < PT; c++) if (EXACT || c < C) accr[c] = (float)((part_t)(accr[c] - m) + part[c]);
+      for (int c = 0; c < PT; c++) lo[c] = (EXACT || c < C) ? lo_row[c] : 0.0f;
+#pragma unroll
+      for (int c = 0; c < PT; c++) if (EXACT || c < C) mul_fold(accr[c], lo[c], m, (double)part[c]);
+#pragma unroll
+      for (int c = 0; c < PT; c++) if (EXACT || c < C) lo_row[c] = lo[c];
     }
   }
   if (scattered) {

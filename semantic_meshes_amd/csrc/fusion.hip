@@ -1356,17 +1356,25 @@ int launch_hist(const ScatterArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// Mul only: re-centre every accumulator row on its largest finite element (fuse_tri.inc.hpp, row_centre) ahead of the
-// fusion kernels that add pixel by pixel into the row (k_fuse_tri does it itself, per view, in registers).
+// Mul only (fuse_tri.inc.hpp, "Mul state"): re-centre every row of the (hi, lo) accumulator pair on its largest finite element and
+// renormalise the pair (hi = the float32 nearest to the value, lo = the remainder; `fold`: lo := 0, the value rounded to the
+// hi plane alone -- what leaves the library as "the raw accumulator").  Runs ahead of the fusion kernels that only know the hi
+// plane, in get(), and before the raw accumulator is read or all-reduced.
 namespace {
-__global__ void k_mul_recentre(float* __restrict__ acc, uint64_t P, uint32_t C, uint32_t S) {
+__global__ void k_mul_normalise(float* __restrict__ acc, float* __restrict__ acc_lo, uint64_t P, uint32_t C, uint32_t S, int fold) {
   const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  float* __restrict__ row = acc + p * S;
-  float m = -INFINITY;
-  for (uint32_t c = 0; c < C; c++) { const float v = row[c]; if (v > m && v < INFINITY) m = v; }
-  if (!(m > -INFINITY) || m == 0.0f) return;
-  for (uint32_t c = 0; c < C; c++) row[c] = row[c] - m;
+  float* __restrict__ hi = acc + p * S;
+  float* __restrict__ lo = acc_lo + p * S;
+  double m = -INFINITY;
+  for (uint32_t c = 0; c < C; c++) { const double t = (double)hi[c] + (double)lo[c]; if (t > m && t < INFINITY) m = t; }
+  if (!(m > -INFINITY)) m = 0.0;
+  for (uint32_t c = 0; c < C; c++) {
+    const double t = ((double)hi[c] + (double)lo[c]) - m;
+    const float h = (float)t;
+    hi[c] = h;
+    lo[c] = (fold || !(h > -INFINITY && h < INFINITY)) ? 0.0f : (float)(t - (double)h);
+  }
 }
 }  // namespace
 
@@ -1378,6 +1386,7 @@ struct smesh_aggregator {
   float iew = 0.5f;
   uint32_t S = 0;             // accumulator row stride in floats (C rounded up to 16)
   float* acc = nullptr;       // float32[P*S]
+  float* acc_lo = nullptr;    // Mul only: float32[P*S], a row's value is acc + acc_lo (fuse_tri.inc.hpp, "Mul state")
   uint32_t* count = nullptr;  // uint32[P], all zero between add() calls
   Scratch st_idx, st_probs, st_w;        // host->device staging
   Scratch nm_idx, nm_probs, nm_w;        // normalised (contiguous) copies
@@ -1390,12 +1399,14 @@ struct smesh_aggregator {
 
 namespace {
 
-int mul_recentre(smesh_aggregator* a) {
+int mul_normalise(smesh_aggregator* a, bool fold) {
   if (a->kind != SMESH_AGG_MUL || a->P == 0) return SMESH_OK;
-  hipLaunchKernelGGL(k_mul_recentre, dim3((uint32_t)div_up(a->P, 256)), dim3(256), 0, a->ctx->stream, a->acc, a->P, a->C, a->S);
+  hipLaunchKernelGGL(k_mul_normalise, dim3((uint32_t)div_up(a->P, 256)), dim3(256), 0, a->ctx->stream, a->acc, a->acc_lo, a->P, a->C, a->S,
+                     fold ? 1 : 0);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
+int mul_recentre(smesh_aggregator* a) { return mul_normalise(a, false); }
 
 int stage_in(DeviceCtx* ctx, Scratch& st, const void* host, size_t bytes, const void** dev) {
   SMESH_TRY(st.reserve(bytes));
@@ -1599,7 +1610,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   for (int v = 0; v < 2; v++) {
     const RenderedView& rv = views[v < nviews ? v : 0];
     TriFuseArgs& x = v ? tb : t;
-    x.frags = rv.frags; x.idx = rv.idx; x.probs = rv.probs; x.weights = rv.weights; x.acc = a->acc; x.F = F; x.C = a->C;
+    x.frags = rv.frags; x.idx = rv.idx; x.probs = rv.probs; x.weights = rv.weights; x.acc = a->acc; x.acc_lo = a->acc_lo; x.F = F; x.C = a->C;
     x.W = (uint32_t)rv.W; x.H = (uint32_t)rv.H; x.iew = a->iew; x.big_queue = rv.big_queue; x.big_len = rv.big_len;
     x.big_capacity = big_capacity;
     x.tri_blocks = (uint32_t)div_up(F, kWave);
@@ -1701,7 +1712,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   hipStream_t st = ctx->stream;
   if (F == 0) return SMESH_OK;
   TriFuseArgs t;
-  t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.F = F; t.C = a->C;
+  t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.acc_lo = a->acc_lo; t.F = F; t.C = a->C;
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
   t.dbg = 0; t.prim_id = nullptr;
@@ -1731,7 +1742,12 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
 }
 
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a) { return a->ctx; }
-float* smesh_aggregator_acc(smesh_aggregator* a, uint64_t* num_floats) { if (num_floats) *num_floats = a->P * a->S; return a->acc; }
+// The accumulator as one float32 buffer on the library stream (Mul: the (hi, lo) pair folded into the hi plane first).
+float* smesh_aggregator_acc(smesh_aggregator* a, uint64_t* num_floats) {
+  if (mul_normalise(a, true) != SMESH_OK) { if (num_floats) *num_floats = 0; return nullptr; }
+  if (num_floats) *num_floats = a->P * a->S;
+  return a->acc;
+}
 uint32_t smesh_aggregator_classes(smesh_aggregator* a) { return a->C; }
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a) { return a->mu; }
 Scratch& smesh_aggregator_stage_probs(smesh_aggregator* a) { return a->st_probs; }
@@ -1757,9 +1773,12 @@ int smesh_aggregator_create(uint64_t P, uint32_t C, int kind, float iew, int dev
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&a->acc), acc_bytes ? acc_bytes : 16);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&a->count), P ? P * 4 : 16);
   if (e == hipSuccess) e = hipMemsetAsync(a->acc, 0, acc_bytes, ctx->stream);   // Sum/Summax: 0; Mul: log 1 = 0
+  if (e == hipSuccess && kind == SMESH_AGG_MUL) e = hipMalloc(reinterpret_cast<void**>(&a->acc_lo), acc_bytes ? acc_bytes : 16);
+  if (e == hipSuccess && kind == SMESH_AGG_MUL) e = hipMemsetAsync(a->acc_lo, 0, acc_bytes, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(a->count, 0, P * 4, ctx->stream);
   if (e != hipSuccess) {
     if (a->acc) (void)hipFree(a->acc);
+    if (a->acc_lo) (void)hipFree(a->acc_lo);
     if (a->count) (void)hipFree(a->count);
     delete a;
     return fail_hip(e, "aggregator allocation", __FILE__, __LINE__);
@@ -1773,6 +1792,7 @@ int smesh_aggregator_destroy(smesh_aggregator_t* a) {
   (void)hipSetDevice(a->ctx->device);
   (void)hipStreamSynchronize(a->ctx->stream);
   (void)hipFree(a->acc);
+  if (a->acc_lo) (void)hipFree(a->acc_lo);
   (void)hipFree(a->count);
   if (a->ev_staged) (void)hipEventDestroy(a->ev_staged);
   for (Scratch* s : {&a->st_idx, &a->st_probs, &a->st_w, &a->nm_idx, &a->nm_probs, &a->nm_w, &a->fb_w, &a->fb_amax, &a->pw, &a->out_tmp})
@@ -1787,6 +1807,7 @@ int smesh_aggregator_reset(smesh_aggregator_t* a) {
   std::lock_guard<std::recursive_mutex> lock(a->ctx->mu);
   SMESH_HIP(hipSetDevice(a->ctx->device));
   SMESH_HIP(hipMemsetAsync(a->acc, 0, (size_t)a->P * a->S * 4, a->ctx->stream));
+  if (a->acc_lo) SMESH_HIP(hipMemsetAsync(a->acc_lo, 0, (size_t)a->P * a->S * 4, a->ctx->stream));
   return SMESH_OK;
 }
 
@@ -1844,6 +1865,7 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
 static int finalize_into(smesh_aggregator* a, float* d_out) {
   DeviceCtx* ctx = a->ctx;
   if (a->P == 0) return SMESH_OK;
+  SMESH_TRY(mul_normalise(a, false));   // Mul: centred rows, the hi plane alone now carries the elements that matter to 2^-24
   ProfScope prof(ctx, SMESH_PROF_FINALIZE);
   const int TP = tile_pixels(a->C);
   const int C = (int)a->C;
@@ -1902,6 +1924,7 @@ int smesh_aggregator_get_raw(smesh_aggregator_t* a, float* out, int memkind) {
   SMESH_HIP(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)a->P * a->C * 4;
   if (!bytes) return SMESH_OK;
+  SMESH_TRY(mul_normalise(a, true));
   // padded rows [P][S] -> dense [P][C]
   SMESH_HIP(hipMemcpy2DAsync(out, (size_t)a->C * 4, a->acc, (size_t)a->S * 4, (size_t)a->C * 4, a->P,
                              memkind == SMESH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
@@ -1917,6 +1940,7 @@ int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind
   SMESH_HIP(hipSetDevice(ctx->device));
   const size_t bytes = (size_t)a->P * a->C * 4;
   if (!bytes) return SMESH_OK;
+  if (a->acc_lo) SMESH_HIP(hipMemsetAsync(a->acc_lo, 0, (size_t)a->P * a->S * 4, ctx->stream));
   // dense [P][C] -> padded rows [P][S]; the padding stays zero
   SMESH_HIP(hipMemcpy2DAsync(a->acc, (size_t)a->S * 4, in, (size_t)a->C * 4, (size_t)a->C * 4, a->P,
                              memkind == SMESH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
@@ -1928,6 +1952,7 @@ int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* n)
   if (!a || !ptr) return fail(SMESH_ERR_INVALID, "NULL argument");
   // callers (the RCCL all-reduce) use this from another stream: make sure our work is done first
   SMESH_HIP(hipSetDevice(a->ctx->device));
+  SMESH_TRY(mul_normalise(a, true));
   SMESH_HIP(hipStreamSynchronize(a->ctx->stream));
   *ptr = a->acc;
   if (n) *n = a->P * a->S;

@@ -833,6 +833,7 @@ struct smesh_renderer {
   // smesh_aggregator_add_matched: rec_hash[s] != null-state while side[s]'s records are intact -- the 64-bit content checksum
   // of the plane they describe lives in d_hash[s] (d_hash[kRecordSides]: the checksum of the image being looked up)
   bool rec_valid[kRecordSides] = {};
+  bool hash_valid[kRecordSides] = {};   // d_hash[s] holds the checksum of the plane (smesh_renderer_seal_render)
   unsigned long long* d_hash = nullptr;
   Scratch match_stage;             // device copy of a host index image that is being looked up
   bool raster_pending = false;     // work queued on the raster stream since the last synchronisation
@@ -1419,13 +1420,8 @@ int smesh_renderer_render_device(smesh_renderer_t* r, const smesh_camera_t* cam,
     if (r->last_idx[sd] == im->idx) r->last_idx[sd] = nullptr;   // that plane went back to the pool and is being reused (the records
                                                                   // of its side stay valid: copies of it are still recognised by content)
   r->last_idx[side] = im->idx; r->last_W[side] = cam->width; r->last_H[side] = cam->height;
-  // content checksum of the plane these records describe (smesh_aggregator_add_matched)
-  if (!r->d_hash) {
-    SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&r->d_hash), (kRecordSides + 1) * sizeof(unsigned long long)));
-    SMESH_HIP(hipMemsetAsync(r->d_hash, 0, (kRecordSides + 1) * sizeof(unsigned long long), r->ctx->stream));
-  }
-  SMESH_TRY(plane_checksum(r->ctx, im->idx, cam->width * cam->height, r->d_hash + side));
   r->rec_valid[side] = true;
+  r->hash_valid[side] = false;   // computed when the plane's content first leaves the library (smesh_renderer_seal_render)
   im->idx_out = im->depth_out = true;
   *indices_dev = im->idx;
   *depth_dev = im->depth;
@@ -1628,12 +1624,11 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
                          (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)));
     if (fast) {
       SMESH_HIP(hipSetDevice(ctx->device));
-      SMESH_TRY(fuse_rendered(r, a, side, idx_dev, probs, weights, probs_mem, W, H));
-      // Like smesh_aggregator_add, inputs are never retained after return (Fusion.h:45-47): device inputs must have been read
-      // before the caller may free or overwrite them (host inputs were waited for inside fuse_rendered).  The explicitly
-      // asynchronous entry points are smesh_fuse_view / smesh_fuse_views.
-      if (probs_mem == SMESH_MEM_DEVICE || (weights && w_mem == SMESH_MEM_DEVICE)) SMESH_HIP(hipStreamSynchronize(ctx->stream));
-      return SMESH_OK;
+      // Asynchronous for DEVICE probs / weights, like smesh_fuse_view (host images were waited for inside fuse_rendered): a
+      // host synchronisation per view would serialise the reference's two-call loop on launch latencies (0.10 -> 0.21 ms per
+      // cfg2 view).  Callers order the buffers' next use after the library with smesh_stream_release (no host wait) or
+      // smesh_synchronize; the Python layer does the former for every array that is not the library's own.
+      return fuse_rendered(r, a, side, idx_dev, probs, weights, probs_mem, W, H);
     }
   }
   const int64_t is[2] = {(int64_t)H, 1};
@@ -1666,7 +1661,7 @@ int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
   if (!((!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) || (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives))))
     return SMESH_OK;
   bool any = false;
-  for (int sd = 0; sd < kRecordSides; sd++) any = any || (r->rec_valid[sd] && r->last_W[sd] == W && r->last_H[sd] == H);
+  for (int sd = 0; sd < kRecordSides; sd++) any = any || (r->rec_valid[sd] && r->hash_valid[sd] && r->last_W[sd] == W && r->last_H[sd] == H);
   if (!any || !r->d_hash) return SMESH_OK;
   SMESH_HIP(hipSetDevice(ctx->device));
   const uint64_t N = W * H;
@@ -1682,13 +1677,32 @@ int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
   int side = -1;
   for (int sd = 0; sd < kRecordSides; sd++)
-    if (r->rec_valid[sd] && r->last_W[sd] == W && r->last_H[sd] == H && h[sd] == h[kRecordSides]) side = sd;
+    if (r->rec_valid[sd] && r->hash_valid[sd] && r->last_W[sd] == W && r->last_H[sd] == H && h[sd] == h[kRecordSides]) side = sd;
   if (side < 0) return SMESH_OK;
-  SMESH_TRY(fuse_rendered(r, a, side, d_img, probs, weights, probs_mem, W, H));
+  SMESH_TRY(fuse_rendered(r, a, side, d_img, probs, weights, probs_mem, W, H));   // asynchronous for DEVICE images, see smesh_aggregator_add_rendered
   *matched = 1;
-  // like smesh_aggregator_add: inputs are not retained after return
-  if (idx_mem == SMESH_MEM_DEVICE || probs_mem == SMESH_MEM_DEVICE || (weights && w_mem == SMESH_MEM_DEVICE))
-    SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  return SMESH_OK;
+}
+
+// Computes (once) the content checksum of the plane `indices_dev` that one of r's last smesh_renderer_render_device() calls returned,
+// which makes copies of it recognisable by smesh_aggregator_add_matched.  Call it when the plane's content first leaves the library's
+// hands -- before exporting the pointer to another framework or copying the image to the host -- i.e. while it is still what the
+// rasteriser wrote.  Not needed for (and not paid by) the plain render -> add loop.
+int smesh_renderer_seal_render(smesh_renderer_t* r, const uint32_t* indices_dev) {
+  if (!r || !indices_dev) return fail(SMESH_ERR_INVALID, "NULL argument");
+  std::lock_guard<std::mutex> g(r->mu);
+  DeviceCtx* ctx = r->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  for (int sd = 0; sd < kRecordSides; sd++) {
+    if (r->last_idx[sd] != indices_dev || !r->rec_valid[sd] || r->hash_valid[sd]) continue;
+    SMESH_HIP(hipSetDevice(ctx->device));
+    if (!r->d_hash) {
+      SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&r->d_hash), (kRecordSides + 1) * sizeof(unsigned long long)));
+      SMESH_HIP(hipMemsetAsync(r->d_hash, 0, (kRecordSides + 1) * sizeof(unsigned long long), ctx->stream));
+    }
+    SMESH_TRY(plane_checksum(ctx, indices_dev, r->last_W[sd] * r->last_H[sd], r->d_hash + sd));
+    r->hash_valid[sd] = true;
+  }
   return SMESH_OK;
 }
 

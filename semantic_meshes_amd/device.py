@@ -60,9 +60,17 @@ class DeviceArray:
     def __cuda_array_interface__(self):
         # the consumer reads on ITS stream: everything this library still has in flight (render() is asynchronous on a
         # non-blocking stream) must have landed first -- same contract as __dlpack__ below
+        self._seal()
         self._exported = True
         _lib.synchronize(self.device)
         return self._cai_dict()
+
+    def _seal(self):
+        """A render() result whose content is about to leave the library (export, host copy): let the renderer take its checksum
+        now, while it is what the rasteriser wrote -- copies of it are then recognised by MeshAggregator.add()."""
+        rb = self._rendered_by
+        if rb is not None and not self._exported and getattr(rb, "_h", None) is not None and rb._h.value:
+            _lib.check(_lib.lib().smesh_renderer_seal_render(rb._h, ctypes.c_void_p(self.ptr)))
 
     def _cai_dict(self):
         return {
@@ -81,6 +89,7 @@ class DeviceArray:
         """DLPack capsule over the HBM buffer (what the reference's render() returns, Renderer.h:37-38).
         The producing stream is synchronised first: the consumer may use any stream."""
         from . import dlpack
+        self._seal()
         self._exported = True
         _lib.synchronize(self.device)
         return dlpack.to_capsule(self.ptr, self.shape, self.strides, self.dtype, dlpack.kDLROCM, self.device, self)
@@ -108,6 +117,7 @@ class DeviceArray:
 
     def numpy(self):
         """Copy to a fresh host array (synchronises with the producing stream)."""
+        self._seal()
         if not self._is_contiguous():
             # copy the dense span, then re-stride on the host
             span = 1 + sum((s - 1) * st for s, st in zip(self.shape, self.strides))
@@ -194,6 +204,14 @@ def _order_after_producer(obj, cai, device):
         s = cai.get("stream")
         stream = 0 if s in (None, 1) else int(s)   # 2 is also hipStreamPerThread's handle value
     _lib.check(_lib.lib().smesh_stream_wait(int(device or 0), ctypes.c_void_p(stream)))
+    return stream
+
+
+def release_to(device, streams):
+    """After an asynchronous library call that read device arrays of other frameworks: their streams (`streams`, collected by
+    describe()) wait for the library's reads, so the owners may overwrite or free the arrays right away -- no host wait."""
+    for st in set(streams or ()):
+        _lib.check(_lib.lib().smesh_stream_release(int(device), ctypes.c_void_p(st)))
 
 
 def library_stream(device=0):
@@ -203,20 +221,22 @@ def library_stream(device=0):
     return int(p.value or 0)
 
 
-def describe(obj, want_ndim, what, device=None):
+def describe(obj, want_ndim, what, device=None, streams=None):
     """Normalise an add()/render() argument to (pointer, memkind, shape, dtype, element strides, keepalive).
 
     Accepts what the reference's FromTensor accepts in practice: numpy arrays / array-likes
     on the host, and device arrays via DeviceArray or `__cuda_array_interface__` (torch-ROCm, cupy).
     Device memory that does not come from this library is ordered after its producer's stream (`device` = the GPU of
-    the handle the argument is for).
+    the handle the argument is for); the producer streams are appended to `streams` for release_to().
     """
     if isinstance(obj, DeviceArray):
         shape, dtype, strides, ptr, mem, keep = obj.shape, obj.dtype, obj.strides, obj.ptr, _lib.MEM_DEVICE, obj
     elif hasattr(obj, "__cuda_array_interface__"):
         cai = obj.__cuda_array_interface__
         if device is not None:   # (None: layout bookkeeping only -- every entry point of the package passes its handle's GPU)
-            _order_after_producer(obj, cai, device)
+            st = _order_after_producer(obj, cai, device)
+            if streams is not None:
+                streams.append(st)
         shape, dtype = tuple(cai["shape"]), np.dtype(cai["typestr"])
         ptr = int(cai["data"][0])
         bstr = cai.get("strides")
@@ -245,8 +265,19 @@ def describe(obj, want_ndim, what, device=None):
             except Exception:
                 capsule, ordered = obj.__dlpack__(), False
         imp = dlpack.Imported(capsule)
-        if imp.on_device and not ordered and device is not None:
-            _order_after_producer(obj, None, device)
+        if imp.on_device and device is not None:
+            if not ordered:
+                st = _order_after_producer(obj, None, device)
+            else:   # the producer ordered the hand-over itself; its later use of the buffer: assume its current / default stream
+                st = 0
+                if (type(obj).__module__ or "").split(".")[0] == "torch":
+                    try:
+                        import torch
+                        st = int(torch.cuda.current_stream(obj.device).cuda_stream)
+                    except Exception:
+                        st = 0
+            if streams is not None:
+                streams.append(st)
         shape, dtype, strides, ptr = imp.shape, imp.dtype, imp.strides, imp.ptr
         mem, keep = (_lib.MEM_DEVICE if imp.on_device else _lib.MEM_HOST), imp
     else:

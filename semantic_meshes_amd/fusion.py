@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray, describe
+from .device import DeviceArray, describe, release_to
 
 import os
 
@@ -43,23 +43,24 @@ class _MeshAggregator:
     def add(self, primitive_image, probs_image, weights_image=None):
         """Fuse one view: `primitive_image` (W,H) of uint32/int32/uint64/int64, `probs_image` (W,H,C) float32,
         optional `weights_image` (W,H) float32; host numpy or device arrays, any non-negative strides."""
-        ip, imem, ishape, idt, istr, k0 = describe(primitive_image, 2, "primitive image", self.device)
-        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device)
+        streams = []   # streams of other frameworks whose device arrays this call reads (ordered before and after, no host wait)
+        ip, imem, ishape, idt, istr, k0 = describe(primitive_image, 2, "primitive image", self.device, streams)
+        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device, streams)
         if idt not in _IDX_CODES:
             raise ValueError("primitive image dtype must be one of uint32/int32/uint64/int64, got %s" % idt)
         if pdt != np.float32:
             if pmem == _lib.MEM_HOST and pdt.kind == "f":
                 probs_image = np.asarray(probs_image, dtype=np.float32)
-                pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device)
+                pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device, streams)
             else:
                 raise ValueError("probs image must be float32, got %s" % pdt)
         wp, wmem, wstr, k2, wshape = None, _lib.MEM_HOST, None, None, None
         if weights_image is not None:
-            wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device)
+            wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device, streams)
             if wdt != np.float32:
                 if wmem == _lib.MEM_HOST and wdt.kind == "f":
                     weights_image = np.asarray(weights_image, dtype=np.float32)
-                    wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device)
+                    wp, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device, streams)
                 else:
                     raise ValueError("weights image must be float32, got %s" % wdt)
         if tuple(ishape) != tuple(pshape[:2]) or (wshape is not None and tuple(wshape) != tuple(ishape)):
@@ -79,11 +80,12 @@ class _MeshAggregator:
             _lib.check(_lib.lib().smesh_aggregator_add_rendered(
                 self._h, rb._h, ctypes.c_void_p(ip), ctypes.c_void_p(pp), _c64(pstr), pmem,
                 None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H))
+            release_to(self.device, streams)
             return
         if idt.itemsize == 4 and tuple(istr) == (H, 1) and self.match_renders:
             # An index image that went through another framework or numpy (DLPack -> TF -> .numpy() -> add in the reference's
-            # harness, eval-scannet/eval_scannet.py:211-238): if it still equals, element for element, one of the last renders of
-            # a renderer with this many primitives on this GPU, the triangle-order fusion applies (the library compares on the device)
+            # harness, eval-scannet/eval_scannet.py:211-238): if its content checksum still equals that of one of the last renders of
+            # a renderer with this many primitives on this GPU, the triangle-order fusion applies (smesh_aggregator_add_matched)
             from .render import _live_renderers
             for rb in list(_live_renderers):
                 if rb.device != self.device or rb._h is None or not rb._h.value or rb.getPrimitivesNum() != self.primitives:
@@ -93,6 +95,7 @@ class _MeshAggregator:
                     self._h, rb._h, ctypes.c_void_p(ip), _IDX_CODES[idt], _c64(istr), imem, ctypes.c_void_p(pp), _c64(pstr), pmem,
                     None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H, ctypes.byref(matched)))
                 if matched.value:
+                    release_to(self.device, streams)
                     return
         _lib.check(_lib.lib().smesh_aggregator_add(
             self._h, ctypes.c_void_p(ip), _IDX_CODES[idt], _c64(istr), imem,
@@ -154,18 +157,20 @@ class _MeshAggregator:
     def fuse_view(self, renderer, camera, probs_image, weights_image=None):
         """render(camera) + add(indices, probs) in one call without the indices leaving the device."""
         W, H = camera.resolution
-        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device)
+        streams = []
+        pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device, streams)
         if tuple(pshape) != (W, H, self.classes) or pdt != np.float32:
             raise ValueError("probs image must be float32 (W,H,C) = %s" % ((W, H, self.classes),))
         if pstr != (H * self.classes, self.classes, 1):
             raise ValueError("fuse_view needs a contiguous (W,H,C) probs image")
         wp = None
         if weights_image is not None:
-            wp_, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device)
+            wp_, wmem, wshape, wdt, wstr, k2 = describe(weights_image, 2, "weights image", self.device, streams)
             if tuple(wshape) != (W, H) or wdt != np.float32 or wstr != (H, 1) or wmem != pmem:
                 raise ValueError("weights image must be contiguous float32 (W,H) in the same memory as probs")
             wp = ctypes.c_void_p(wp_)
         _lib.check(_lib.lib().smesh_fuse_view(renderer._h, self._h, ctypes.byref(camera._pod), ctypes.c_void_p(pp), wp, pmem))
+        release_to(self.device, streams)
 
     def fuse_views(self, renderer, cameras, probs_images, weights_images=None):
         """`fuse_view` for a whole batch, in order (the loop of colorize_cityscapes_mesh.py:54-67 as one call).  With a
@@ -179,11 +184,11 @@ class _MeshAggregator:
             return
         pods = (_lib.CameraPOD * n)()
         pptr, wptr = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
-        keep, mem = [], None
+        keep, mem, streams = [], None, []
         for i, cam in enumerate(cameras):
             W, H = cam.resolution
             pods[i] = cam._pod
-            pp, pmem, pshape, pdt, pstr, k1 = describe(probs_images[i], 3, "probs image", self.device)
+            pp, pmem, pshape, pdt, pstr, k1 = describe(probs_images[i], 3, "probs image", self.device, streams)
             if tuple(pshape) != (W, H, self.classes) or pdt != np.float32:
                 raise ValueError("probs image %d must be float32 (W,H,C) = %s" % (i, (W, H, self.classes)))
             if pstr != (H * self.classes, self.classes, 1):
@@ -196,13 +201,14 @@ class _MeshAggregator:
             keep.append(k1)
             w = None if weights_images is None else weights_images[i]
             if w is not None:
-                wp_, wmem, wshape, wdt, wstr, k2 = describe(w, 2, "weights image", self.device)
+                wp_, wmem, wshape, wdt, wstr, k2 = describe(w, 2, "weights image", self.device, streams)
                 if tuple(wshape) != (W, H) or wdt != np.float32 or wstr != (H, 1) or wmem != mem:
                     raise ValueError("weights image %d must be contiguous float32 (W,H) in the same memory as probs" % i)
                 wptr[i] = wp_
                 keep.append(k2)
         _lib.check(_lib.lib().smesh_fuse_views(renderer._h, self._h, pods, n, pptr,
                                                None if weights_images is None else wptr, mem))
+        release_to(self.device, streams)
 
 
 class ModelRenderer:

@@ -677,12 +677,12 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
     assert last() == fast
     oagg.add(o.render(cams[5])[0], probs)
     # ... and after someone changed a single pixel of it the generic path takes over (and honours the change)
+    _ = kept[4].__cuda_array_interface__          # exported (the library takes the plane's checksum at this point) ...
     changed = np.asarray(kept[4]).copy()
     x, y = np.argwhere(changed != BG)[100]
     changed[x, y] = (changed[x, y] + 17) % P
     sm._lib.check(sm._lib.lib().smesh_memcpy(kept[4].ptr, changed.ctypes.data, changed.nbytes, sm._lib.MEM_DEVICE, sm._lib.MEM_HOST, 0))
-    _ = kept[4].__cuda_array_interface__
-    agg.add(kept[4], probs)
+    agg.add(kept[4], probs)                       # ... then modified in place by its new co-owner
     assert last() == "k_scatter_strip"
     oagg.add(changed, probs)
     # 3. a numpy COPY of a render (DLPack -> framework -> .numpy() in the reference's harness) with host probs
