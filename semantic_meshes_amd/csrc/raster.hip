@@ -1648,6 +1648,7 @@ int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
                                  const float* weights, const int64_t w_strides[2], int w_mem, uint64_t W, uint64_t H, int* matched) {
   if (!a || !r || !indices || !idx_strides || !probs || !probs_strides || !matched) return fail(SMESH_ERR_INVALID, "NULL argument");
   *matched = 0;
+  g_last_fuse_kernel = "k_scatter_strip";   // (reporting: unless a render matches below, the caller goes on to smesh_aggregator_add)
   if (weights && !w_strides) return fail(SMESH_ERR_INVALID, "weights without strides");
   DeviceCtx* ctx = r->ctx;
   const int64_t C = (int64_t)smesh_aggregator_classes(a);

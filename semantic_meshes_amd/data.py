@@ -291,7 +291,9 @@ class Colmap:
         if model == "PINHOLE":
             fx, fy, cx, cy = params[:4]
             return dict(width=int(width), height=int(height), f=(fx, fy), c=(cx, cy))
-        raise ValueError("COLMAP camera model %s is not supported (only SIMPLE_PINHOLE and PINHOLE)" % model)
+        # other models may sit in a workspace unused: the error is raised by getCamera() for an image that needs one
+        # (the reference's Camera holds only the two pinhole variants, include/semantic_meshes/render/Camera.h:9-12)
+        return dict(width=int(width), height=int(height), unsupported=str(model))
 
     def _read_cameras(self, path):
         cams = {}
@@ -364,6 +366,9 @@ class Colmap:
             raise IndexError("image index %d out of range" % index)
         im = self._images[index]
         cam = self._cameras[im["camera_id"]]
+        if "unsupported" in cam:
+            raise ValueError("COLMAP camera model %s of image %r is not supported (only SIMPLE_PINHOLE and PINHOLE)"
+                             % (cam["unsupported"], im["name"]))
         return Camera(_qvec_to_rotation(im["q"]), np.asarray(im["t"], dtype=np.float64),
                       np.asarray([cam["width"], cam["height"]], dtype=np.int64),
                       np.asarray(cam["f"], dtype=np.float64), np.asarray(cam["c"], dtype=np.float64))

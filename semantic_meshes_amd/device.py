@@ -94,6 +94,15 @@ class DeviceArray:
         _lib.synchronize(self.device)
         return dlpack.to_capsule(self.ptr, self.shape, self.strides, self.dtype, dlpack.kDLROCM, self.device, self)
 
+    def capsule(self):
+        """A `"dltensor"` PyCapsule over the buffer -- the object the reference's render() returns
+        (python/semantic_meshes/include/Renderer.h:37-38) and `tf.experimental.dlpack.from_dlpack` / `torch.utils.dlpack.from_dlpack`
+        take.  The capsule keeps this array alive; handed back unconsumed to MeshAggregator.add it is recognised as this array."""
+        from . import dlpack
+        self._seal()                       # whoever consumes the capsule may write to the plane later
+        _lib.synchronize(self.device)      # ... and reads it on its own stream
+        return dlpack.to_capsule(self.ptr, self.shape, self.strides, self.dtype, dlpack.kDLROCM, self.device, self)
+
     def transpose(self, *axes):
         """Stride permutation without a copy (callers transpose (H,W,C) network output to (W,H,C))."""
         if len(axes) == 1 and hasattr(axes[0], "__len__"):

@@ -126,3 +126,18 @@ class Imported:
 
     def __del__(self):
         self.close()
+
+
+def own_capsule_owner(capsule):
+    """If `capsule` is an UNCONSUMED capsule made by to_capsule() in this process, consume it and return the object it was made
+    over (nobody else has seen the memory); else None."""
+    if type(capsule).__name__ != "PyCapsule" or not _api.PyCapsule_IsValid(capsule, b"dltensor"):
+        return None
+    addr = _api.PyCapsule_GetPointer(capsule, b"dltensor")
+    entry = _live.get(addr)
+    if entry is None:
+        return None
+    owner = entry[3]
+    _api.PyCapsule_SetName(capsule, b"used_dltensor")
+    _live.pop(addr, None)
+    return owner

@@ -43,6 +43,12 @@ class _MeshAggregator:
     def add(self, primitive_image, probs_image, weights_image=None):
         """Fuse one view: `primitive_image` (W,H) of uint32/int32/uint64/int64, `probs_image` (W,H,C) float32,
         optional `weights_image` (W,H) float32; host numpy or device arrays, any non-negative strides."""
+        if type(primitive_image).__name__ == "PyCapsule":
+            # render() in capsule mode (the reference's return type) handed straight back, as python/scripts/colorize_cityscapes_mesh.py:65-67 does
+            from . import dlpack
+            own = dlpack.own_capsule_owner(primitive_image)
+            if own is not None:
+                primitive_image = own
         streams = []   # streams of other frameworks whose device arrays this call reads (ordered before and after, no host wait)
         ip, imem, ishape, idt, istr, k0 = describe(primitive_image, 2, "primitive image", self.device, streams)
         pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device, streams)

@@ -22,7 +22,10 @@ def _mesh_arrays(mesh):
     return v, f
 
 
+import os
 import weakref
+
+RETURN_CAPSULES = os.environ.get("SMESH_RENDER_CAPSULES", "0") == "1"   # render() returns "dltensor" PyCapsules like the reference
 
 _live_renderers = weakref.WeakSet()   # MeshAggregator.add looks here for the render a foreign index image is a copy of
 
@@ -51,9 +54,14 @@ class _Renderer:
             self._primitives = int(n.value)
         return self._primitives
 
-    def render(self, camera):
+    def render(self, camera, capsules=None):
         """Rasterise the mesh for `camera`; returns `(primitive_indices, depth)`:
-        uint32 (W,H) with background 0xFFFFFFFF and float32 (W,H) with background +inf."""
+        uint32 (W,H) with background 0xFFFFFFFF and float32 (W,H) with background +inf, device-resident.
+
+        By default the two planes are `DeviceArray`s (`__dlpack__`, `__cuda_array_interface__`, `np.asarray`).  With
+        `capsules=True` (or `semantic_meshes.render.RETURN_CAPSULES = True`, or SMESH_RENDER_CAPSULES=1) they are the
+        `"dltensor"` PyCapsules the reference returns (Renderer.h:37-38), which `tf.experimental.dlpack.from_dlpack`
+        (eval-scannet/eval_scannet.py:211-212) requires; `MeshAggregator.add` takes either."""
         if not isinstance(camera, Camera):
             raise TypeError("render() expects a semantic_meshes data.Camera")
         W, H = camera.resolution
@@ -72,6 +80,8 @@ class _Renderer:
         indices = DeviceArray(pi.value, (W, H), np.uint32, self.device, owner=self, on_release=rel_i)
         indices._rendered_by = self   # add(indices, ...) can then reuse what this render left on the device
         depth = DeviceArray(pd.value, (W, H), np.float32, self.device, owner=self, on_release=rel_d)
+        if RETURN_CAPSULES if capsules is None else capsules:
+            return indices.capsule(), depth.capsule()
         return indices, depth
 
     def render_numpy(self, camera):

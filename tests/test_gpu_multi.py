@@ -213,3 +213,41 @@ def test_profile_counts_launches_and_views(sm):
     finally:
         _lib.check(L.smesh_profile_enable(0, 0))
         _lib.check(L.smesh_profile_sample_every(0, 1))
+
+
+def test_render_can_return_the_reference_s_dltensor_capsules(sm, oracle):
+    """python/semantic_meshes/include/Renderer.h:37-38: render() returns PyCapsules named "dltensor".  Behind a switch here;
+    a raw-capsule consumer (torch.utils.dlpack.from_dlpack stands in for tf.experimental.dlpack.from_dlpack,
+    eval_scannet.py:211-212) takes them, and add() takes an unconsumed one as python/scripts/colorize_cityscapes_mesh.py:65-67 does."""
+    torch = _torch()
+    import torch.utils.dlpack
+    mesh, cams = small_scene(120, 60, 320, 240, views=3)
+    P, C = len(mesh.faces), 19
+    rng = np.random.default_rng(3)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    agg, oagg = sm.fusion.MeshAggregator(P, C), oracle.OracleAggregator(P, C)
+    for cam in cams:
+        idx_c, depth_c = r.render(cam, capsules=True)
+        assert type(idx_c).__name__ == "PyCapsule" and type(depth_c).__name__ == "PyCapsule"
+        depth_t = torch.utils.dlpack.from_dlpack(depth_c)                 # consumed by another framework
+        oidx, odepth = o.render(cam)
+        assert depth_t.shape == cam.resolution and depth_t.is_cuda
+        np.testing.assert_array_equal(depth_t.cpu().numpy().view(np.uint32), odepth.view(np.uint32))
+        probs = random_probs(rng, *cam.resolution, C)
+        agg.add(idx_c, probs)                                             # the unconsumed capsule goes straight into add()
+        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri"
+        oagg.add(oidx, probs)
+        with pytest.raises(ValueError):
+            agg.add(idx_c, probs)                                         # a capsule is consumed once
+    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    # ... and a consumed index capsule comes back as the other framework's tensor: recognised by content
+    idx_c, _ = r.render(cams[0], capsules=True)
+    idx_t = torch.utils.dlpack.from_dlpack(idx_c)
+    agg.add(idx_t, to_dev(sm, random_probs(rng, *cams[0].resolution, C)))
+    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri"
+
+
+def to_dev(sm, a):
+    from semantic_meshes_amd.device import to_device
+    return to_device(a)
