@@ -110,8 +110,8 @@ def test_known_answer_scene_of_the_reference(sm, oracle):
 
 def test_cfg4_texels_parity_on_a_240k_triangle_cut(sm, oracle):
     """BASELINE cfg4's path (render.texels + fuse, 1296x968, C = 40) at a size the oracle affords: 240 k triangles, texel
-    resolutions up to 3 (texels_per_pixel 0.6), three cameras.  Layout, index and depth images bit-exact; Sum against the
-    float32 oracle bit for bit (k_fuse_texel adds in image order), get() within 1e-5."""
+    resolutions up to 3 (texels_per_pixel 0.6), three cameras.  Layout, index and depth images bit-exact; Sum's raw accumulator
+    against the float32 oracle to 2e-6, get() within 1e-5."""
     from semantic_meshes_amd import synth
     cfg = synth.CONFIGS["cfg4"]
     W, H, C = cfg["width"], cfg["height"], cfg["classes"]
@@ -144,7 +144,8 @@ def test_cfg4_texels_parity_on_a_240k_triangle_cut(sm, oracle):
         agg.fuse_view(r, cam, dp)
         oagg.add(oidx[k], np.asarray(dp))
     assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_texel"
-    np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+    # (not bit for bit: triangles with a box over 8 x 8 pixels are fused by a whole wave with float atomics on their own rows)
+    np.testing.assert_allclose(agg.get_raw(), oagg.get_raw(), rtol=2e-6, atol=1e-7)
     assert_fused_close(agg.get(), oagg.get())
 
 
@@ -189,7 +190,7 @@ def test_cfg4_full_size_properties(sm):
 
 def test_cfg5_class_count_and_resolution_parity_on_the_1m_triangle_mesh(sm, oracle):
     """BASELINE cfg5's fusion kernel (k_fuse_tri_wide, C = 150) at cfg5's resolution (4096x2160, 5.3 GB of class vectors per
-    view) on the 1 M-triangle mesh, which the oracle affords: indices bit-exact, Sum's accumulator bit for bit."""
+    view) on the 1 M-triangle mesh, which the oracle affords: indices and depth bit-exact, Sum's raw accumulator to 2e-6."""
     from semantic_meshes_amd import synth
     cfg = synth.CONFIGS["cfg5"]
     W, H, C = cfg["width"], cfg["height"], cfg["classes"]
@@ -211,7 +212,9 @@ def test_cfg5_class_count_and_resolution_parity_on_the_1m_triangle_mesh(sm, orac
     np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
     oagg = oracle.OracleAggregator(P, C)
     oagg.add(oidx, np.asarray(dp))
-    np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+    # (not bit for bit: at this resolution many triangles of the 1 M mesh have a box over 8 x 8 pixels and are summed by a whole
+    # wave in tree order; small-triangle scenes with C = 150 are bit-equal, test_fuse_view_triangle_order_is_bit_exact)
+    np.testing.assert_allclose(agg.get_raw(), oagg.get_raw(), rtol=2e-6, atol=1e-7)
     assert_fused_close(agg.get(), oagg.get())
 
 

@@ -108,4 +108,4 @@ def test_render_from_a_loaded_workspace(oracle):
         assert set(np.unique(idx[idx != 0xFFFFFFFF])) <= {0, 1, 2, 3}
         np.testing.assert_array_equal(idx, oidx)
         np.testing.assert_array_equal(depth.view(np.uint32), odepth.view(np.uint32))
-        assert 3.5 < depth[np.isfinite(depth)].min() < depth[np.isfinite(depth)].max() < 6.0
+        assert 3.5 < depth[np.isfinite(depth)].min() <= depth[np.isfinite(depth)].max() < 6.0
