@@ -98,6 +98,40 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels ship their own libamdhip64 / libhsa-runtime64 next to torch; a
+    process that first loads this library against the system ROCm and later imports torch ends up with TWO runtimes, and
+    the second one sees no usable GPU (`torch.cuda.is_available()` False, a hang at exit).  The other order is fine: the
+    dynamic linker satisfies our `libamdhip64.so.7` with the copy torch already mapped.  So, when a torch installation
+    exists in this environment (located, NOT imported), its runtime is mapped first and both then share it in any import
+    order.  SMESH_HIP_RUNTIME=system keeps the system ROCm; =<directory> takes libamdhip64.so / libhsa-runtime64.so from there."""
+    import importlib.util
+    import sys
+    choice = os.environ.get("SMESH_HIP_RUNTIME", "auto")
+    if choice == "system" or "torch" in sys.modules:
+        return
+    libdir = choice if choice not in ("auto", "torch") else None
+    if libdir is None:
+        try:
+            spec = importlib.util.find_spec("torch")
+        except (ImportError, ValueError):
+            spec = None
+        if spec is None or not spec.origin:
+            return
+        libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libhsa-runtime64.so", "libamdhip64.so"):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                return
+    # ... and the RCCL that goes with that runtime (comm.cpp loads RCCL lazily; torch would otherwise map a second one later)
+    rccl = os.path.join(libdir, "librccl.so")
+    if os.path.exists(rccl):
+        os.environ.setdefault("SMESH_RCCL_LIB", rccl)
+
+
 def lib():
     """Load libsmesh_hip.so (once).  Raises RuntimeError if it has not been built."""
     global _lib
@@ -108,6 +142,7 @@ def lib():
                     raise RuntimeError(
                         "semantic_meshes_amd: %s not found -- build it with `make -C semantic_meshes_amd/csrc` "
                         "(or `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback." % LIB_PATH)
+                _preload_hip_runtime()
                 L = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(L, name)  # AttributeError if the library does not export the ABI

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 
@@ -41,11 +42,11 @@ int get_ctx(int device, DeviceCtx** out) {
     SMESH_HIP(hipSetDevice(device));
     auto ctx = std::make_unique<DeviceCtx>();
     ctx->device = device;
-    SMESH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    SMESH_HIP(hipStreamCreateWithFlags(&ctx->raster_stream, hipStreamNonBlocking));
     hipDeviceProp_t prop;
     SMESH_HIP(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    SMESH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    SMESH_HIP(hipStreamCreateWithFlags(&ctx->raster_stream, hipStreamNonBlocking));
     g_ctx[device] = std::move(ctx);
   }
   *out = g_ctx[device].get();

@@ -366,6 +366,14 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b
   uint32_t n[NV];
 #pragma unroll
   for (int v = 0; v < NV; v++) { m[v] = (rec[v].kind == 1 && !big) ? rec[v].mask : 0ull; win[v] = 0ull; n[v] = 0u; }
+  // The tile resolve of the rasteriser has already cleared the losers out of the masks (raster.hip, tile_resolve_block) unless
+  // the render says otherwise (big_len[1]: fragment-queue overflow, direct rasteriser) or the mesh was re-ordered: then the
+  // candidates are checked against the index plane here.
+  const bool verify = scattered || a.big_len[1] != 0u || (NV == 2 && b.big_len[1] != 0u);
+  if (!verify) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) { win[v] = m[v]; n[v] = (uint32_t)__popcll(m[v]); m[v] = 0ull; }
+  }
   while (__ballot((m[0] | m[NV - 1]) != 0ull) != 0ull) {
     int k[NV][4];
     uint32_t got[NV][4];

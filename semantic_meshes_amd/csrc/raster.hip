@@ -90,7 +90,7 @@ __device__ __forceinline__ ScreenVertex project_point(const CameraArgs& cam, con
 
 __device__ __forceinline__ void project_vertex(const float* __restrict__ verts, uint64_t V, const CameraArgs& cam,
                                                ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count, const uint64_t i) {
-  if (i == 0) { big_count[0] = 0u; big_count[2] = 0u; }
+  if (i == 0) { big_count[0] = 0u; big_count[1] = 0u; big_count[2] = 0u; }   // [1]: "the per-triangle masks are not final" flag
   if (i >= V) return;
   sv[i] = project_point(cam, verts[3 * i + 0], verts[3 * i + 1], verts[3 * i + 2]);
 }
@@ -114,7 +114,7 @@ struct ProjectGroup {
 __global__ void k_project_vertices_group(ProjectGroup g) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0)
-    for (uint32_t v = 0; v < g.n; v++) { g.big_count[v][0] = 0u; g.big_count[v][2] = 0u; }
+    for (uint32_t v = 0; v < g.n; v++) { g.big_count[v][0] = 0u; g.big_count[v][1] = 0u; g.big_count[v][2] = 0u; }
   if (i >= g.V) return;
   const float X = g.verts[3 * i + 0], Y = g.verts[3 * i + 1], Z = g.verts[3 * i + 2];
   for (uint32_t v = 0; v < g.n; v++) g.sv[v][i] = project_point(g.cam[v], X, Y, Z);
@@ -258,7 +258,8 @@ struct RasterArgs {
   uint32_t W, H;
   uint32_t* big_queue;        // triangles with a box larger than 8 x 8 (the fusion's cooperative waves walk it)
   uint32_t* huge_queue;       // ... of those, the ones larger than kMedium x kMedium: rasterised by the tile workgroups
-  uint32_t* big_count;        // [0] length of big_queue, [2] length of huge_queue
+  uint32_t* big_count;        // [0] length of big_queue, [2] length of huge_queue, [1] nonzero: the masks of the per-triangle
+                              //     records still hold fragments that lost the depth test (the fusion must check them)
   uint32_t big_capacity;
   TriFrag* frags;             // per-triangle fragment records for the triangle-order fusion (may be null)
   FragQueues q;               // fragment-queue path only
@@ -694,6 +695,30 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
     __syncthreads();
   }
   __syncthreads();
+  // The depth test is decided: tell the triangle-order fusion which fragments of the small triangles LOST it, by clearing their
+  // bit in the triangle's record (about one fragment in twenty at cfg2; the winners need no memory traffic at all).  The record
+  // masks are then exactly the visible pixels of every triangle, and k_fuse_tri no longer reads the index plane to find them --
+  // a quarter of its scattered loads and one memory round trip of every wave.  Not for texel primitives (the key holds a texel
+  // id) nor re-ordered meshes (it holds the caller's face id, the records are indexed by position); a tile that merged
+  // overflowed fragments from the key image cannot name their losers and raises the "check them" flag for the whole view.
+  if (a.frags && !a.prim_id && !a.tex_res) {
+    if (merge) {
+      if (t == 0) a.big_count[1] = 1u;
+    } else {
+      auto lost = [&](const unsigned long long key, const uint32_t pin) {
+        if (key == kNullKey || skeys[pin] == key) return;
+        const uint32_t f = (uint32_t)(key & 0xFFFFFFFFull);
+        const TriFrag rec = a.frags[f];
+        if (rec.kind != 1) return;   // (fragments of triangles with a box over 8 x 8: their record holds the box, not a mask)
+        const int bit = (int)(x0 + (pin >> 6) - rec.x0) * 8 + (int)(y0 + (pin & 63u) - rec.y0);
+        atomicAnd(&a.frags[f].mask, ~(1ull << bit));
+      };
+#pragma unroll
+      for (uint32_t k = 0; k < kSpec; k++)
+        if (sq_lane + k * kGroup < n) lost(spec_key[k], spec_pix[k]);
+      for (uint32_t i = sq_lane + kSpec * kGroup; i < n; i += kGroup) lost(q.key[qbase + i], q.pix[qbase + i]);
+    }
+  }
   for (int p = t; p < kQPixels; p += 256) {
     const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
     if (gx < W && gy < H) {
@@ -851,15 +876,19 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {   //
   return z ^ (z >> 31);
 }
 __global__ __launch_bounds__(256) void k_plane_checksum(const uint32_t* __restrict__ img, uint64_t N, unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long part[4];
   unsigned long long h = 0ull;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (uint64_t)gridDim.x * blockDim.x)
     h += mix64((i << 32) | (unsigned long long)img[i]);
   for (int off = 32; off > 0; off >>= 1) h += __shfl_down(h, off);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, h);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = h;
+  __syncthreads();
+  // one atomic per workgroup: atomics on ONE address are served one after the other (8192 of them took 99 us)
+  if (threadIdx.x == 0) atomicAdd(out, ((part[0] + part[1]) + part[2]) + part[3]);
 }
 int plane_checksum(DeviceCtx* ctx, const uint32_t* d_img, uint64_t N, unsigned long long* d_out) {
   SMESH_HIP(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), ctx->stream));
-  const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(div_up(N, 256 * 4), (uint64_t)ctx->num_cus * 8));
+  const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(div_up(N, 256 * 16), (uint64_t)ctx->num_cus));
   hipLaunchKernelGGL(k_plane_checksum, dim3(blocks), dim3(256), 0, ctx->stream, d_img, N, d_out);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
@@ -976,7 +1005,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
                        r->side[side].big_count);
     SMESH_HIP(hipGetLastError());
   } else {
-    SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 4, st));
+    SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 16, st));
   }
   if (r->F) {
     RasterArgs a = raster_args(r, vs, side, W, H);
@@ -998,6 +1027,8 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   }
   hipLaunchKernelGGL(k_resolve, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, vs.keys, d_idx, d_depth, (uint32_t)W, (uint32_t)H);
   SMESH_HIP(hipGetLastError());
+  // the direct path leaves the emitted fragments in the records, winners and losers alike: the fusion checks them
+  SMESH_HIP(hipMemsetAsync(r->side[side].big_count + 1, 0xFF, 4, st));
   return SMESH_OK;
 }
 
