@@ -811,6 +811,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a) {
   unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
   unsigned long long win = 0ull;
   uint32_t n = 0;
+  if (!a.prim_id && a.big_len[1] == 0u) { win = m; n = (uint32_t)__popcll(m); m = 0ull; }   // the tile resolve has cleared the losers (k_fuse_tri)
   while (__ballot(m != 0ull) != 0ull) {
     int k[4];
     uint32_t got[4];
@@ -993,6 +994,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
   auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
   unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
   unsigned long long win = 0ull;   // pass 1, lane = triangle: the emitted fragments that won the depth test
+  if (!a.prim_id && a.big_len[1] == 0u) { win = m; m = 0ull; }   // the tile resolve has cleared the losers out of the masks (k_fuse_tri)
   while (__ballot(m != 0ull) != 0ull) {
     int k[4];
     uint32_t got[4];

@@ -803,6 +803,7 @@ __global__ void k_texel_area(const float* __restrict__ verts, const int32_t* __r
 
 }  // namespace
 
+constexpr int kSlots = 2 * kMaxGroup;   // two banks of view slots: smesh_fuse_views rasterises group g+1 into one while group g is fused from the other
 constexpr int kRecordSides = 6;   // render_device() rotates over this many sets of per-triangle records (<= kMaxGroup)
 
 struct ImagePair {
@@ -827,7 +828,7 @@ struct smesh_renderer {
     uint64_t keys_pixels = 0;
     FragQueues fq;                   // fragment-queue path: per-tile queues, sized for the largest image seen
     uint64_t fq_tiles = 0;
-  } vs[kMaxGroup];
+  } vs[kSlots];
   bool texels = false;
   uint32_t* tex_res = nullptr;     // [F]
   uint32_t* tex_first = nullptr;   // [F]
@@ -839,12 +840,16 @@ struct smesh_renderer {
     uint32_t* big_queue = nullptr;   // [big_capacity] triangles with a bounding box > 8 x 8
     uint32_t* big_count = nullptr;   // [0] length of the queue; emptied by the next render's vertex kernel
     TriFrag* frags = nullptr;        // [F] per-triangle fragment records
-  } side[kMaxGroup];
+  } side[kSlots];
   uint32_t big_capacity = 0;
   std::vector<ImagePair> images;   // pooled output planes
   Scratch own_idx;                 // for the host-output entry point
   // smesh_fuse_view pipeline: two index/depth slots, rasterised on ctx->raster_stream
-  Scratch fused[kMaxGroup];   // index planes of fuse_view (slots 0, 1) / fuse_views (one per view of a group)
+  Scratch fused[kSlots];   // index planes of fuse_view (slots 0, 1) / fuse_views (one per view of a group)
+  // smesh_fuse_views, group pipeline: bank b (slots b * kMaxGroup ...) has been rasterised / its fusion has been queued
+  hipEvent_t ev_bank_rendered[2] = {nullptr, nullptr}, ev_bank_consumed[2] = {nullptr, nullptr}, ev_main_fence = nullptr;
+  uint64_t group_seq = 0;
+  bool bank_used[2] = {false, false};
   hipEvent_t ev_rendered[2] = {nullptr, nullptr};   // raster stream: slot is complete
   hipEvent_t ev_consumed[2] = {nullptr, nullptr};   // main stream: the fusion kernels have read the slot
   uint64_t fused_seq = 0;
@@ -1056,7 +1061,7 @@ bool queues_fit_group(uint64_t W, uint64_t H) {
 // triangles, per-triangle records and index plane r->fused[v]) through the fragment-queue rasteriser with ONE launch per
 // stage: the vertex stage and the tile resolve are short kernels that fill a fraction of the chip, and every launch has a
 // ramp and a tail, so n views' worth of blocks take less than n launches.  Index planes only.
-int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st) {
+int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st, int base = 0) {
   DeviceCtx* ctx = r->ctx;
   ProjectGroup pg;
   RasterGroup rg;
@@ -1065,23 +1070,24 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   uint32_t tiles = 0;
   for (int v = 0; v < n; v++) {
     const uint64_t W = cams[v].width, H = cams[v].height, N = W * H;
-    SMESH_HIP(alloc_side(r, v));
-    SMESH_HIP(alloc_scratch(r, v));
-    smesh_renderer::ViewScratch& vs = r->vs[v];
+    SMESH_HIP(alloc_side(r, base + v));
+    SMESH_HIP(alloc_scratch(r, base + v));
+    smesh_renderer::ViewScratch& vs = r->vs[base + v];
     SMESH_TRY(ensure_keys(vs, W, H, st));
     int qs = SMESH_OK;
     if (!ensure_queues(r, vs, W, H, st, &qs)) return qs != SMESH_OK ? qs : fail(SMESH_ERR_RUNTIME, "fragment queues unavailable");
-    if (r->fused[v].bytes < N * 8) {
+    if (r->fused[base + v].bytes < N * 8) {
       SMESH_HIP(hipStreamSynchronize(st));   // growing a slot frees the old buffer: nothing may still be reading it
-      SMESH_TRY(r->fused[v].reserve(N * 8));
+      SMESH_HIP(hipStreamSynchronize(r->ctx->stream));
+      SMESH_TRY(r->fused[base + v].reserve(N * 8));
     }
-    if (v < kRecordSides) { r->last_idx[v] = nullptr; r->rec_valid[v] = false; }   // the records of a render_device() on this side are being overwritten
+    if (base + v < kRecordSides) { r->last_idx[base + v] = nullptr; r->rec_valid[base + v] = false; }   // the records of a render_device() on this side are being overwritten
     pg.cam[v] = camera_args(&cams[v]);
     pg.sv[v] = vs.sv;
-    pg.big_count[v] = r->side[v].big_count;
-    rg.view[v] = raster_args(r, vs, v, W, H);
+    pg.big_count[v] = r->side[base + v].big_count;
+    rg.view[v] = raster_args(r, vs, base + v, W, H);
     rg.view[v].q = vs.fq;
-    rg.idx[v] = static_cast<uint32_t*>(r->fused[v].ptr);
+    rg.idx[v] = static_cast<uint32_t*>(r->fused[base + v].ptr);
     tiles += (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
     rg.tile_end[v] = tiles;
   }
@@ -1411,6 +1417,9 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   if (r->d_hash) (void)hipFree(r->d_hash);
   for (auto& f : r->fused) f.release();
   for (int i = 0; i < 2; i++) {
+    if (i == 0 && r->ev_main_fence) (void)hipEventDestroy(r->ev_main_fence);
+    if (r->ev_bank_rendered[i]) (void)hipEventDestroy(r->ev_bank_rendered[i]);
+    if (r->ev_bank_consumed[i]) (void)hipEventDestroy(r->ev_bank_consumed[i]);
     if (r->ev_rendered[i]) (void)hipEventDestroy(r->ev_rendered[i]);
     if (r->ev_consumed[i]) (void)hipEventDestroy(r->ev_consumed[i]);
   }
@@ -1583,12 +1592,45 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
     std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     SMESH_HIP(hipSetDevice(ctx->device));
-    if (r->raster_pending) {
-      SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
-      r->raster_pending = false;
+    static const bool group_pipeline_on = getenv("SMESH_GROUP_PIPELINE") && atoi(getenv("SMESH_GROUP_PIPELINE")) != 0;
+    const bool use_pipeline = grouped && group_pipeline_on;
+    if (!use_pipeline) {
+      if (r->raster_pending) {
+        SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
+        r->raster_pending = false;
+      }
+      r->main_pending = true;   // the renderer's scratch is in use on the main stream
     }
-    r->main_pending = true;   // the renderer's scratch is in use on the main stream
-    if (grouped) {
+    // Group pipeline (SMESH_GROUP_PIPELINE=1; off by default): the rasteriser launches of this group go to the raster stream and
+    // into the view-slot bank the previous group is NOT using, so they run beside the previous group's fusion launches; two
+    // events per group hand the bank over and back.  Measured on cfg2: 12 950-13 010 views/s against 12 660-12 760 without
+    // (+2 %): k_fuse_tri stretches from 83 to 95 us per pair launch and the rasteriser stage from 35 to ~70 us per view while they
+    // share the CUs -- both are bound by how many of their waves a CU holds (96 / 126 VGPRs), not by two different units.
+    const bool group_pipeline = group_pipeline_on;
+    int base = 0;
+    if (use_pipeline) {
+      const int bank = (int)(r->group_seq++ & 1u);
+      base = bank * kMaxGroup;
+      for (int b = 0; b < 2; b++) {
+        if (!r->ev_bank_rendered[b]) SMESH_HIP(hipEventCreateWithFlags(&r->ev_bank_rendered[b], hipEventDisableTiming));
+        if (!r->ev_bank_consumed[b]) SMESH_HIP(hipEventCreateWithFlags(&r->ev_bank_consumed[b], hipEventDisableTiming));
+      }
+      // the bank's previous tenant must have been fused ...
+      if (r->bank_used[bank]) SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, r->ev_bank_consumed[bank], 0));
+      // ... and whatever the main stream did to the renderer's state OUTSIDE this pipeline (plain renders, fuse_view, slot growth)
+      // comes first -- a full fence, paid once after such a call, not per group
+      if (r->main_pending || !r->bank_used[bank]) {
+        if (!r->ev_main_fence) SMESH_HIP(hipEventCreateWithFlags(&r->ev_main_fence, hipEventDisableTiming));
+        SMESH_HIP(hipEventRecord(r->ev_main_fence, ctx->stream));
+        SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, r->ev_main_fence, 0));
+        r->main_pending = false;
+      }
+      SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->raster_stream, base));
+      SMESH_HIP(hipEventRecord(r->ev_bank_rendered[bank], ctx->raster_stream));
+      SMESH_HIP(hipStreamWaitEvent(ctx->stream, r->ev_bank_rendered[bank], 0));
+      r->bank_used[bank] = true;
+      r->raster_pending = true;
+    } else if (grouped) {
       SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->stream));
     } else {   // images too large for kMaxGroup sets of fragment queues, direct rasteriser, or SMESH_RASTER_PAIRS=0: one view at a time
       gn = 2;
@@ -1605,7 +1647,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
     }
     for (int j = 0; j < gn && !pairable; j++) {   // texel renderers, class counts beyond k_fuse_tri, foreign primitive counts
       const uint64_t k = i + (uint64_t)j;
-      SMESH_TRY(fuse_rendered(r, a, j, static_cast<const uint32_t*>(r->fused[j].ptr), probs[k], weights ? weights[k] : nullptr,
+      SMESH_TRY(fuse_rendered(r, a, base + j, static_cast<const uint32_t*>(r->fused[base + j].ptr), probs[k], weights ? weights[k] : nullptr,
                               SMESH_MEM_DEVICE, cams[k].width, cams[k].height));
     }
     // the fusion launches of a group are back to back: one timed region for all of them (smesh_profile_*: a HIP event pair around a
@@ -1616,15 +1658,16 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
         const int nv = std::min(2, gn - j);
         RenderedView rv[2];
         for (int v = 0; v < nv; v++) {
-          const smesh_renderer::Side& sd = r->side[j + v];
+          const smesh_renderer::Side& sd = r->side[base + j + v];
           const uint64_t k = i + (uint64_t)(j + v);
-          rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[j + v].ptr), probs[k],
+          rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[base + j + v].ptr), probs[k],
                                weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
         }
         SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
       }
     }
     if (pairable) g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
+    if (grouped && group_pipeline) SMESH_HIP(hipEventRecord(r->ev_bank_consumed[base / kMaxGroup], ctx->stream));
     r->fused_seq += (uint64_t)gn;
     i += (uint64_t)gn;
   }
