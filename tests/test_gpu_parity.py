@@ -522,7 +522,7 @@ def test_render_fragment_queue_overflow(sm, oracle, monkeypatch, cap):
 
 
 @pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE_PIPELINE=1", "SMESH_FUSE=strip", "SMESH_FUSE_WIDE=0",
-                                  "SMESH_RASTER_PAIRS=0", "SMESH_FUSE_PAIRS=0"])
+                                  "SMESH_RASTER_PAIRS=0", "SMESH_FUSE_PAIRS=0", "SMESH_GROUP_PIPELINE=1"])
 def test_alternative_paths_in_subprocess(knob):
     """These knobs are read once per process: re-run the render / fuse_view parity tests with the direct rasteriser
     (global 64-bit atomicMin per fragment), with the two-stream raster/fusion pipeline, and with the generic
@@ -538,6 +538,8 @@ def test_alternative_paths_in_subprocess(knob):
         sel += " or triangle_order"
     if k in ("SMESH_RASTER", "SMESH_RASTER_PAIRS", "SMESH_FUSE_PAIRS", "SMESH_FUSE"):
         sel = "fuse_views" if k.endswith("PAIRS") else sel + " or fuse_views"
+    if k == "SMESH_GROUP_PIPELINE":
+        sel = "fuse_views"
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
                           "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
