@@ -1,0 +1,46 @@
+# Round-2 evidence for profiles/: bench lines (driver's arguments and defaults), rocprofv3 kernel stats of the same commands,
+# HBM counters of the dominant kernel (separate --pmc passes), the other single-GPU configs, the generic scatter path.
+# usage (on the GPU box, through gpurun): bash tools/profile_round2.sh <tag>; results land in gpurun_out/<tag>/r02_*.
+tag=$1; out=gpurun_out/$tag; mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+last() { grep '^{"metric' $1 | tail -1; }
+python bench.py > $out/bench.log 2>&1; last $out/bench.log > $out/r02_bench.json
+python bench.py --steps 20 --warmup 5 > $out/bench20.log 2>&1; last $out/bench20.log > $out/r02_bench_steps20_warmup5.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt -o bench -- python bench.py --no-cpu-baseline --no-host-path > $out/bench_kt.log 2>&1
+last $out/bench_kt.log > $out/r02_bench_under_rocprof.json; cp $out/kt/bench_kernel_stats.csv $out/r02_bench_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt20 -o bench -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-host-path > $out/bench_kt20.log 2>&1
+last $out/bench_kt20.log > $out/r02_bench_steps20_under_rocprof.json; cp $out/kt20/bench_kernel_stats.csv $out/r02_bench_steps20_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $out/pmc_$c -o bench -- python bench.py --no-cpu-baseline --no-host-path --steps 40 --warmup 8 > $out/pmc_$c.log 2>&1
+done
+SMESH_FUSE=strip python bench.py --no-cpu-baseline --no-host-path > $out/bench_strip.log 2>&1; last $out/bench_strip.log > $out/r02_bench_generic_scatter_path.json
+SMESH_FUSE=strip timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_strip -o bench -- python bench.py --no-cpu-baseline --no-host-path > /dev/null 2>&1
+cp $out/kt_strip/bench_kernel_stats.csv $out/r02_bench_kernel_stats_generic_scatter_path.csv
+for w in cfg4 cfg5; do
+  timeout 900 python bench.py --workload $w > $out/bench_$w.log 2>&1; last $out/bench_$w.log > $out/r02_bench_$w.json
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$w -o bench -- python bench.py --workload $w --no-host-path > $out/bench_kt_$w.log 2>&1
+  cp $out/kt_$w/bench_kernel_stats.csv $out/r02_bench_${w}_kernel_stats.csv
+done
+OUT=$out python - <<'PY'
+import csv, collections, json, os
+out = os.environ["OUT"]
+pm = {}
+for kind in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(out + "/pmc_%s/bench_counter_collection.csv" % kind)):
+        n = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+        acc[n] += float(r["Counter_Value"]); cnt[n] += 1
+    for n in acc:
+        if "synth" in n or "rocclr" in n: continue
+        pm.setdefault(n, {})[kind + "_KiB_avg_per_launch"] = round(acc[n] / cnt[n], 1)
+for n, d in pm.items():
+    if "FETCH_SIZE_KiB_avg_per_launch" in d and "WRITE_SIZE_KiB_avg_per_launch" in d:
+        # MI355X_MICROARCH.md, HBM: FETCH_SIZE reports half of the bytes of wide reads on gfx950 -> doubled; WRITE_SIZE as reported
+        d["hbm_bytes_per_launch"] = int((2 * d["FETCH_SIZE_KiB_avg_per_launch"] + d["WRITE_SIZE_KiB_avg_per_launch"]) * 1024)
+json.dump({"_note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `python bench.py --steps 40 --warmup 8`, "
+           "averages per launch; hbm_bytes_per_launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950 correction of the guide)", "kernels": pm},
+          open(out + "/r02_pmc_hbm_summary.json", "w"), indent=1)
+b = json.load(open(out + "/r02_bench.json"))
+print(b["value"], b["roofline"]["frac"], b["roofline"]["avg_launch_us"], b.get("cpu_baseline", {}).get("value"))
+for n, d in pm.items():
+    print(n[:60], d)
+PY
