@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libsmesh_oracle.so")
+# SMESH_ORACLE_LIB: another build of the same source (the sanitizer builds of oracle/Makefile, tools/oracle_sanitizers.sh)
+_LIB_PATH = os.environ.get("SMESH_ORACLE_LIB") or os.path.join(_HERE, "libsmesh_oracle.so")
 
 AGG_KINDS = {"sum": 0, "summax": 1, "mul": 2}
 _IDX_DTYPES = {np.dtype(np.uint32): 0, np.dtype(np.int32): 1, np.dtype(np.uint64): 2, np.dtype(np.int64): 3}
@@ -34,6 +35,8 @@ class CameraPOD(ctypes.Structure):
 
 def build(force=False):
     """Compile the oracle with g++ (oracle/Makefile)."""
+    if os.environ.get("SMESH_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or (
         os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "smesh_oracle.cpp"))
     ):

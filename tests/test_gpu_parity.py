@@ -61,6 +61,21 @@ def test_render_cfg2_full_size_bit_exact(sm, oracle):
         np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
 
 
+def test_near_plane_whole_triangle_cull_matches_oracle(sm, oracle):
+    """Raster spec B-3: no near-plane clipping -- a triangle with any vertex at z_c <= 1e-6 is dropped as a whole
+    (tests/test_oracle.py::near_plane_scene pins the rule on the oracle; here the HIP path agrees bit for bit)."""
+    from test_oracle import near_plane_scene
+    cam, v, f = near_plane_scene()
+    for z in (-1.0, 0.5):
+        vv = v.copy()
+        vv[5, 2] = z
+        idx, depth = sm.render.triangles(sm.data.Mesh(vv, f)).render(cam)
+        oidx, odepth = oracle.OracleRenderer(vv, f).render(cam)
+        np.testing.assert_array_equal(np.asarray(idx), oidx)
+        np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+        assert (oidx == 1).any() == (z > 0)
+
+
 def test_render_is_deterministic(sm):
     mesh, cams = small_scene(60, 30, 320, 240)
     r = sm.render.triangles(mesh)

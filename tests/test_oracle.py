@@ -21,6 +21,32 @@ def _unrle(vals, lens, shape):
 
 
 # ---- rasteriser -----------------------------------------------------------------------------------
+def near_plane_scene():
+    """Raster spec B-3: a triangle with ANY vertex at z_c <= 1e-6 is dropped as a whole -- there is no
+    near-plane clipping (the rule template-tensors applies is out of tree; this one is pinned here and on the GPU).
+    Camera at the origin looking down +z; triangle 0 lies in front, triangle 1 (nearer, covering triangle 0) has one vertex
+    behind the camera, triangle 2 has a vertex exactly on the camera plane."""
+    from semantic_meshes_amd import data
+    cam = data.Camera(np.eye(3, dtype=np.float32), np.zeros(3, np.float32), np.array([64, 48]), np.array([40.0, 40.0]), np.array([32.0, 24.0]))
+    v = np.array([[-1, -1, 4], [1, -1, 4], [0, 1, 4],          # 0: in front
+                  [-2, -2, 2], [2, -2, 2], [0, 1, -1],         # 1: crosses the camera plane
+                  [-2, -2, 3], [2, -2, 3], [0, 2, 0]], np.float32)   # 2: touches it (z_c == 0)
+    f = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], np.int32)
+    return cam, v, f
+
+
+def test_near_plane_whole_triangle_cull(oracle):
+    cam, v, f = near_plane_scene()
+    idx, depth = oracle.OracleRenderer(v, f).render(cam)
+    assert set(np.unique(idx)) == {0, BG}                     # triangles 1 and 2 vanish completely, they hide nothing
+    assert (idx == 0).sum() > 150 and np.allclose(depth[idx == 0], 4.0)
+    # moved a hair in front of the plane the crossing triangle is back (and, nearer, wins over triangle 0 where they overlap)
+    v2 = v.copy()
+    v2[5, 2] = 0.5
+    idx2, _ = oracle.OracleRenderer(v2, f).render(cam)
+    assert (idx2 == 1).sum() > 500 and (idx2 == 0).sum() < (idx == 0).sum()
+
+
 def test_ka1_empty_scene_is_background(oracle):
     r = oracle.OracleRenderer(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.int32))
     idx, depth = r.render(_camera())
