@@ -418,6 +418,44 @@ static inline uint32_t load_idx(const void* base, int dtype, int64_t off) {
   }
 }
 
+// Mul's logarithm is part of the spec (the reference's pow / log live in the absent template-tensors): a fixed
+// sequence of IEEE float32 operations -- Cephes' logf polynomial with every multiply-add a correctly rounded fma -- that the HIP
+// kernels execute identically (fuse_tri.inc.hpp, log_spec), so that both sides produce bit-identical terms.  Within 2 ulp of ln.
+static inline float log_spec(float x) {
+  if (!(x > 0.0f)) return x == 0.0f ? -std::numeric_limits<float>::infinity() : std::numeric_limits<float>::quiet_NaN();
+  if (std::isinf(x)) return x;
+  int e_adj = 0;
+  uint32_t ix;
+  std::memcpy(&ix, &x, 4);
+  if (ix < 0x00800000u) { x = x * 8388608.0f; e_adj = -23; std::memcpy(&ix, &x, 4); }
+  int e = (int)(ix >> 23) - 127 + e_adj;
+  uint32_t im = (ix & 0x007FFFFFu) | 0x3F800000u;
+  if ((ix & 0x007FFFFFu) > 0x003504F3u) { im -= 0x00800000u; e += 1; }
+  float m;
+  std::memcpy(&m, &im, 4);
+  const float f = m - 1.0f;
+  const float z = f * f;
+  float y = 7.0376836292e-2f;
+  y = std::fmaf(y, f, -1.1514610310e-1f);
+  y = std::fmaf(y, f, 1.1676998740e-1f);
+  y = std::fmaf(y, f, -1.2420140846e-1f);
+  y = std::fmaf(y, f, 1.4249322787e-1f);
+  y = std::fmaf(y, f, -1.6668057665e-1f);
+  y = std::fmaf(y, f, 2.0000714765e-1f);
+  y = std::fmaf(y, f, -2.4999993993e-1f);
+  y = std::fmaf(y, f, 3.3333331174e-1f);
+  y = (y * f) * z;
+  const float fe = (float)e;
+  y = std::fmaf(-2.12194440e-4f, fe, y);
+  y = std::fmaf(-0.5f, z, y);
+  return std::fmaf(0.693359375f, fe, f + y);
+}
+
+extern "C" int smesh_oracle_log_spec(const float* in, float* out, uint64_t n) {   // test hook (tests/test_oracle.py)
+  for (uint64_t i = 0; i < n; i++) out[i] = log_spec(in[i]);
+  return SMESH_OK;
+}
+
 // ModelAggregator::add1/add2 (Fusion.h:42-64) -> ModelAggregator::add (Mesh.h:65-107)
 int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dtype, const int64_t is[2], int imem,
                          const float* probs, const int64_t ps[3], int pmem,
@@ -494,7 +532,7 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
       // the log is decided inside the absent template-tensors; the spec (the same formula in the HIP
       // kernels) is w * log(p) in float32 with p^0 = 1 for every p.
       for (uint32_t c = 0; c < C; c++) {
-        const float l = w == 0.0f ? 0.0f : w * std::log(next[c]);
+        const float l = w == 0.0f ? 0.0f : w * log_spec(next[c]);
         if (g_accum_double) a->accd[primitive_index * C + c] += (double)l;
         else a->acc[primitive_index * C + c] = a->acc[primitive_index * C + c] + l;
       }
@@ -513,7 +551,13 @@ int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind) {
   std::vector<float> row(C);
   for (uint64_t p = 0; p < a->P; p++) {
     for (uint32_t c = 0; c < C; c++) row[c] = g_accum_double ? (float)a->accd[p * C + c] : a->acc[p * C + c];
-    if (a->kind == SMESH_AGG_MUL) {
+    if (a->kind == SMESH_AGG_MUL && g_accum_double) {
+      // the float64 yardstick keeps its precision through the division by the largest element: casting a log-sum of magnitude
+      // 1e4 to float first (as the float32 state of the reference does) would cost 5e-4 relative after exp()
+      double m = a->accd[p * C];
+      for (uint32_t c = 1; c < C; c++) if (a->accd[p * C + c] > m) m = a->accd[p * C + c];
+      for (uint32_t c = 0; c < C; c++) row[c] = (float)std::exp(a->accd[p * C + c] - m);
+    } else if (a->kind == SMESH_AGG_MUL) {
       // logprob_normalize (Fusion.h:97-104): p / max_el(p) in the log domain, then cast to float
       float m = row[0];
       for (uint32_t c = 1; c < C; c++) if (row[c] > m) m = row[c];

@@ -12,8 +12,39 @@ constexpr int kWave = 64;
 // decided inside the absent template-tensors; the spec here -- the same one formula in the oracle -- is
 // w * log(p) in float32, with p^0 = 1 for every p (so w == 0 contributes nothing, also for p = 0), p = 0 -> -inf,
 // p < 0 -> NaN.  No pow: nothing underflows, no platform-dependent denormals, an eighth of the instructions.
+// The log itself is part of the spec: a fixed sequence of IEEE float32 operations (Cephes' logf polynomial, every multiply-add an
+// explicit fma), written out identically in oracle/smesh_oracle.cpp, so that the HIP path and the oracle compute bit-identical
+// terms -- two different library logf's disagree by an ulp per term, which adds up to 1e-4 .. 1e-3 over the thousands of pixels of
+// a large primitive.  Within 2 ulp of the correctly rounded natural logarithm (tests/test_oracle.py).
+__device__ __forceinline__ float log_spec(float x) {
+  if (!(x > 0.0f)) return x == 0.0f ? -INFINITY : NAN;          // log(0) = -inf; negative or NaN -> NaN
+  if (x == INFINITY) return INFINITY;
+  int e_adj = 0;
+  uint32_t ix = __float_as_uint(x);
+  if (ix < 0x00800000u) { x = x * 8388608.0f; e_adj = -23; ix = __float_as_uint(x); }   // denormal: scaled by 2^23 (exact)
+  int e = (int)(ix >> 23) - 127 + e_adj;
+  uint32_t im = (ix & 0x007FFFFFu) | 0x3F800000u;               // mantissa in [1, 2)
+  if ((ix & 0x007FFFFFu) > 0x003504F3u) { im -= 0x00800000u; e += 1; }   // above sqrt(2): halve it -> m in (sqrt(1/2), sqrt(2)]
+  const float f = __uint_as_float(im) - 1.0f;                   // exact
+  const float z = f * f;
+  float y = 7.0376836292e-2f;
+  y = __builtin_fmaf(y, f, -1.1514610310e-1f);
+  y = __builtin_fmaf(y, f, 1.1676998740e-1f);
+  y = __builtin_fmaf(y, f, -1.2420140846e-1f);
+  y = __builtin_fmaf(y, f, 1.4249322787e-1f);
+  y = __builtin_fmaf(y, f, -1.6668057665e-1f);
+  y = __builtin_fmaf(y, f, 2.0000714765e-1f);
+  y = __builtin_fmaf(y, f, -2.4999993993e-1f);
+  y = __builtin_fmaf(y, f, 3.3333331174e-1f);
+  y = (y * f) * z;
+  const float fe = (float)e;
+  y = __builtin_fmaf(-2.12194440e-4f, fe, y);
+  y = __builtin_fmaf(-0.5f, z, y);
+  return __builtin_fmaf(0.693359375f, fe, f + y);
+}
+
 __device__ __forceinline__ float log_of_power(float p, float w) {
-  return w == 0.0f ? 0.0f : w * logf(p);
+  return w == 0.0f ? 0.0f : w * log_spec(p);
 }
 
 // Mul state.  Rows are log-domain sums whose common offset cancels in get() (logprob_normalize divides by the largest element,

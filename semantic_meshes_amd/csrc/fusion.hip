@@ -1118,11 +1118,46 @@ __device__ __forceinline__ void fuse_big_texel_triangles(const TriFuseArgs& a, u
 template <int KIND>
 __global__ __launch_bounds__(kWave) void k_fuse_texel_big(TriFuseArgs a) { fuse_big_texel_triangles<KIND>(a, blockIdx.x, gridDim.x); }
 
+// kTexelBlock lanes per workgroup.  Texel meshes are dense meshes seen from afar: at BASELINE cfg4 seven triangles out of eight emit
+// no fragment at all, so a wave that walked its own 64 triangles to the end issued every one of the ~30 memory instructions of a
+// pixel (class vector, accumulator row in, row out) for a handful of active lanes -- and a memory instruction costs the texture
+// path the same whether 8 or 64 lanes take part.  So the workgroup first collects its visible pixels in LDS (the ones that are
+// the only pixel of their texel in this view: nobody else touches that row) and then deals them out one per lane: the rows move
+// with full waves.  Pixels that share their texel with another pixel of the triangle stay with the triangle's own lane, in image
+// order, as before (the reference's order of additions; a row with a single contribution has no order to keep).
+constexpr int kTexelBlock = 512;
+
 template <int KIND>
-__global__ __launch_bounds__(kWave) void k_fuse_texel(TriFuseArgs a) {
-  const int l = threadIdx.x;
+__device__ __forceinline__ void fuse_texel_pixel(const TriFuseArgs& a, const uint32_t C, const uint64_t pix, const uint32_t v, const uint32_t n) {
+  float p[kSlice];
+  load_slice(a.probs + pix * C, (int)C, p);
+  // the row is requested together with the class vector (wasted only for the rare don't-care pixel)
+  float* row = a.acc + (uint64_t)v * C;
+  float accr[kSlice];
+  load_slice(row, (int)C, accr);
+  const float wt = a.weights ? a.weights[pix] : 1.0f;
+  float sum = 0.0f, best = p[0];
+  int am = 0;
+#pragma unroll
+  for (int j = 0; j < kSlice; j++)
+    if (j < (int)C) {
+      sum = sum + p[j];
+      if (KIND == SMESH_AGG_SUMMAX && p[j] > best) { best = p[j]; am = j; }
+    }
+  if (!(sum > 0.5f)) return;                          // Mesh.h:98
+  const float w = (a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f) * wt;   // :100-103
+  accumulate_slice<KIND>(accr, p, (int)C, w, am);
+  store_slice(row, (int)C, accr);
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kTexelBlock) void k_fuse_texel(TriFuseArgs a) {
+  __shared__ uint32_t s_pix[kTexelBlock], s_tex[kTexelBlock];
+  __shared__ uint32_t s_items;
   const uint32_t C = a.C;
-  const uint64_t f = (uint64_t)blockIdx.x * kWave + l;
+  const uint64_t f = (uint64_t)blockIdx.x * kTexelBlock + threadIdx.x;
+  if (threadIdx.x == 0) s_items = 0u;
+  __syncthreads();
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   uint32_t first = 0, cnt = 0;
@@ -1149,30 +1184,20 @@ __global__ __launch_bounds__(kWave) void k_fuse_texel(TriFuseArgs a) {
     for (int j = 0; j < 4; j++)
       if (k[j] >= 0 && got[j] - first < cnt) win |= 1ull << k[j];
   }
-  if (win == 0ull) return;
   for (m = win; m; m &= m - 1ull) {
     const uint64_t pix = pixel(__ffsll((long long)m) - 1);
     const uint32_t v = a.idx[pix];
     uint32_t n = 0;                                   // Mesh.h:90-93 restricted to this triangle's pixels
     for (unsigned long long m2 = win; m2; m2 &= m2 - 1ull) n += a.idx[pixel(__ffsll((long long)m2) - 1)] == v ? 1u : 0u;
-    float p[kSlice];
-    load_slice(a.probs + pix * C, (int)C, p);
-    float sum = 0.0f, best = p[0];
-    int am = 0;
-#pragma unroll
-    for (int j = 0; j < kSlice; j++)
-      if (j < (int)C) {
-        sum = sum + p[j];
-        if (KIND == SMESH_AGG_SUMMAX && p[j] > best) { best = p[j]; am = j; }
-      }
-    if (!(sum > 0.5f)) continue;                      // :98
-    const float w = (a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f) * (a.weights ? a.weights[pix] : 1.0f);   // :100-103
-    float* row = a.acc + (uint64_t)v * C;             // owned by this lane; a later pixel of the same texel re-reads it
-    float accr[kSlice];
-    load_slice(row, (int)C, accr);
-    accumulate_slice<KIND>(accr, p, (int)C, w, am);
-    store_slice(row, (int)C, accr);
+    if (n == 1u) {                                    // the texel's only pixel in this view: any lane may fuse it
+      const uint32_t slot = atomicAdd(&s_items, 1u);
+      if (slot < (uint32_t)kTexelBlock) { s_pix[slot] = (uint32_t)pix; s_tex[slot] = v; continue; }   // (pixel offsets fit 32 bits: W, H <= 65536)
+    }
+    fuse_texel_pixel<KIND>(a, C, pix, v, n);          // shares its row with a later pixel of this lane: in image order, here
   }
+  __syncthreads();
+  const uint32_t items = min(s_items, (uint32_t)kTexelBlock);
+  if (threadIdx.x < items) fuse_texel_pixel<KIND>(a, C, (uint64_t)s_pix[threadIdx.x], s_tex[threadIdx.x], 1u);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1719,22 +1744,22 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   t.tri_blocks = (uint32_t)div_up(F, kWave);
   t.dbg = 0; t.prim_id = nullptr;
   t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count;
-  const dim3 tgrid(t.tri_blocks), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave);
+  const dim3 tgrid((uint32_t)div_up(F, kTexelBlock)), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave), tblock(kTexelBlock);
   SMESH_TRY(mul_recentre(a));
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
     prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, 1);
     switch (a->kind) {
       case SMESH_AGG_SUM:
-        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_SUM>), tgrid, block, 0, st, t);
+        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_SUM>), tgrid, tblock, 0, st, t);
         hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_SUM>), bgrid, block, 0, st, t);
         break;
       case SMESH_AGG_SUMMAX:
-        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_SUMMAX>), tgrid, block, 0, st, t);
+        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_SUMMAX>), tgrid, tblock, 0, st, t);
         hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_SUMMAX>), bgrid, block, 0, st, t);
         break;
       default:
-        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_MUL>), tgrid, block, 0, st, t);
+        hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_MUL>), tgrid, tblock, 0, st, t);
         hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_MUL>), bgrid, block, 0, st, t);
         break;
     }

@@ -135,9 +135,9 @@ def test_fusion_small_matches_oracle(sm, oracle, kind, iew):
     finally:
         oracle.set_accum_double(False)
     assert got.dtype == np.float32 and got.shape == (P, C)
-    # Mul: one formula on both sides, (hi, lo) state folded in double.  What is left is the float32 log term
-    # itself: the host's and the device's logf differ by up to an ulp (4.8e-7 at |log p| = 6.9), a random walk over a row's pixels
-    assert_fused_close(got, want, rtol=1e-5 if kind != "mul" else 2e-5)
+    # Mul too: one formula on both sides down to the logarithm (a fixed float32 operation sequence), (hi, lo) state folded in
+    # double
+    assert_fused_close(got, want, rtol=1e-5)
     touched = want.sum(axis=1) > 0.5
     assert touched.sum() > P // 4
     np.testing.assert_allclose(got[touched].sum(axis=1), 1.0, rtol=1e-5)   # KA8
@@ -443,11 +443,10 @@ def test_fuse_view_mixed_triangle_sizes(sm, oracle, kind):
             oidx = o.render(cam)[0]
             oagg.add(oidx, probs)
         assert (oidx == P - 1).sum() > 2000                     # the huge triangle is visible around the grid
-        # Mul: the summation is done in double ((hi, lo) state); what remains is the ulp by which the host's and
-        # the device's float32 logf differ per term, a random walk over the thousands of pixels of these primitives
-        # (the hi-plane-only kernels behind SMESH_FUSE=strip add float32 rounding on top)
+        # Mul: bit-identical float32 terms on both sides, summed in double by k_fuse_tri / fuse_box ((hi, lo) state);
+        # the hi-plane-only kernels behind SMESH_FUSE=strip sum thousands of pixels per primitive in float32
         import os
-        mul_tol = 5e-3 if os.environ.get("SMESH_FUSE") == "strip" else 1e-3
+        mul_tol = 5e-3 if os.environ.get("SMESH_FUSE") == "strip" else 1e-5
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
         oracle.set_accum_double(False)
@@ -480,7 +479,7 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
         if os.environ.get("SMESH_FUSE") != "strip":
             assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
                 "k_fuse_tri_wide" if C >= 128 and os.environ.get("SMESH_FUSE_WIDE") != "0" else "k_fuse_tri_any" if C > 48 else "k_fuse_tri")
-        mul_tol = 5e-3 if os.environ.get("SMESH_FUSE") == "strip" else 2e-3   # hi-plane-only kernels (any class count): float32 sums
+        mul_tol = 5e-3 if os.environ.get("SMESH_FUSE") == "strip" else 1e-3   # any class count: the kernels add in float32 on the hi plane
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
         oracle.set_accum_double(False)
@@ -1003,7 +1002,7 @@ def test_mul_aggregator_edge_values(sm, oracle):
             oagg.add(o.render(cam)[0], probs, weights)
         got, want = agg.get(), oagg.get()
         assert np.isfinite(got).all()                                    # NaN / Inf -> 0 in get() (Fusion.h:79-95)
-        assert_fused_close(got, want, rtol=2e-5, atol=1e-6)
+        assert_fused_close(got, want, rtol=1e-5, atol=1e-6)
         # the same classes are wiped out by -inf (threshold: exp() of -87 .. -103 is a denormal on the host, zero on the device)
         assert ((want < 1e-30) == (got < 1e-30)).mean() > 0.9999
     finally:

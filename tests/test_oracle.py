@@ -229,6 +229,26 @@ def test_strided_and_threaded_add_agree(oracle):
     np.testing.assert_allclose(a1.get(), a2.get(), rtol=1e-5, atol=1e-7)
 
 
+def test_mul_log_spec_is_within_an_ulp_of_ln(oracle):
+    """Mul's logarithm is a fixed float32 operation sequence shared by the oracle and the HIP kernels (DESIGN.md
+    3.3): pinned here against numpy's double-precision log."""
+    import ctypes
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.random(500_000, dtype=np.float32), np.exp(rng.uniform(-100, 88, 500_000)).astype(np.float32),
+                        np.float32([1e-45, 1e-40, 1.17549435e-38, 1.0, 2.0, 0.5, 3.4e38, 1.41421354, 1.41421366, 0.70710677,
+                                    np.nextafter(np.float32(1), np.float32(2)), np.nextafter(np.float32(1), np.float32(0))])])
+    x = x[x > 0]
+    out = np.empty_like(x)
+    oracle.lib().smesh_oracle_log_spec(x.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(x)))
+    ref = np.log(x.astype(np.float64))
+    ulp = np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)
+    assert (np.abs(out.astype(np.float64) - ref) <= 1.0 * np.maximum(ulp, 1e-300)).all()
+    special = np.float32([0.0, -1.0, np.inf, np.nan])
+    got = np.empty_like(special)
+    oracle.lib().smesh_oracle_log_spec(special.ctypes.data_as(ctypes.c_void_p), got.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(4))
+    assert got[0] == -np.inf and np.isnan(got[1]) and got[2] == np.inf and np.isnan(got[3])
+
+
 def test_texel_counts(oracle):
     # KA10: r(r+1)/2 texels per triangle (TexturedTriangleRenderer.h:43-47)
     v = np.array([[0.4, 0, 0], [0.5, 1, 0], [0.6, 0, 0]], np.float32)   # debug_render_texels.py:19-23
