@@ -330,7 +330,7 @@ def main():
                        "views_per_call": B,
                        "sharding": "views dp%d, one RCCL all-reduce of float32[P,C]" % world,
                        "allreduce": allreduce_impl,
-                       "host_syncs_in_timed_region": 1 if (comm is not None or world == 1) else 4,
+                       "host_syncs_in_timed_region": 1 if (comm is not None or dist is None) else 4,
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
             "roofline": {"kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),
                          "bound": "hbm",
