@@ -363,10 +363,7 @@ __device__ __forceinline__ void fuse_big_triangles_pair(const TriFuseArgs& a, co
 template <int CT, int KIND, bool EXACT, int NV>
 __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b) {
   const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
-#ifndef SMESH_PB
-#define SMESH_PB 2
-#endif
-  constexpr int PB = CT <= 24 ? SMESH_PB : 1;        // pixels whose class vectors are in flight together
+  constexpr int PB = CT <= 24 ? 2 : 1;        // pixels whose class vectors are in flight together (3 or 4: no difference, round 2)
   constexpr int KV = (kWave * CT / 4 + kWave - 1) / kWave;   // float4 per lane of the 64-row block
   __shared__ __attribute__((aligned(16))) float srow[kWave * CT + 4];   // the wave's 64 accumulator rows
   const int l = threadIdx.x;

@@ -1,5 +1,6 @@
 /* C99 client of include/smesh.h: what a non-Python binding (cgo, JNI, a C++ host) would do.  Compiled with gcc by
- * tests/test_abi.py (syntax only, no GPU) and built + run against libsmesh_hip.so by tests/test_gpu_parity.py. */
+ * tests/test_abi.py (syntax check, and run against the CPU oracle without the device-only part) and built + run against
+ * libsmesh_hip.so by tests/test_gpu_parity.py. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -57,6 +58,53 @@ int main(void) {
   CHECK(smesh_aggregator_get(a, out, SMESH_MEM_HOST));
   for (int p = 0; p < 2; p++)
     if (fabsf(out[p * C] - 0.7f) > 1e-5f || fabsf(out[p * C + 1] - 0.2f) > 1e-5f || fabsf(out[p * C + 2] - 0.1f) > 1e-5f) return 8;
+#ifndef ABI_SMOKE_SKIP_DEVICE_COUNT
+  /* the two-call convention on the device: render_device() -> add_rendered(); a device buffer of the caller's, ordered against
+   * the caller's stream (NULL = the legacy default stream) without host waits; then the same image as a COPY, found by content */
+  {
+    uint32_t* d_idx = NULL; float* d_depth = NULL; void* d_probs = NULL; int matched = -1;
+    uint32_t* copy = (uint32_t*)malloc(sizeof(uint32_t) * W * H);
+    CHECK(smesh_aggregator_reset(a));
+    CHECK(smesh_device_malloc(0, sizeof(float) * W * H * C, &d_probs));
+    CHECK(smesh_memcpy(d_probs, probs, sizeof(float) * W * H * C, SMESH_MEM_DEVICE, SMESH_MEM_HOST, 0));
+    CHECK(smesh_renderer_render_device(r, &cam, &d_idx, &d_depth));
+    CHECK(smesh_stream_wait(0, NULL));
+    CHECK(smesh_aggregator_add_rendered(a, r, d_idx, (const float*)d_probs, pstr, SMESH_MEM_DEVICE, NULL, NULL, SMESH_MEM_HOST, W, H));
+    CHECK(smesh_stream_release(0, NULL));
+    CHECK(smesh_renderer_seal_render(r, d_idx));                         /* before the content leaves the library */
+    CHECK(smesh_memcpy(copy, d_idx, sizeof(uint32_t) * W * H, SMESH_MEM_HOST, SMESH_MEM_DEVICE, 0));
+    if (memcmp(copy, idx, sizeof(uint32_t) * W * H) != 0) return 11;
+    CHECK(smesh_aggregator_add_matched(a, r, copy, SMESH_IDX_U32, istr, SMESH_MEM_HOST, probs, pstr, SMESH_MEM_HOST, NULL, NULL, SMESH_MEM_HOST, W, H, &matched));
+    if (matched != 1) return 12;
+    copy[0] ^= 1u;                                                       /* no longer a copy of the render */
+    CHECK(smesh_aggregator_add_matched(a, r, copy, SMESH_IDX_U32, istr, SMESH_MEM_HOST, probs, pstr, SMESH_MEM_HOST, NULL, NULL, SMESH_MEM_HOST, W, H, &matched));
+    if (matched != 0) return 13;
+    CHECK(smesh_synchronize(0));
+    CHECK(smesh_renderer_release_image(r, d_idx, d_depth));
+    CHECK(smesh_device_free(0, d_probs));
+    free(copy);
+    CHECK(smesh_aggregator_get(a, out, SMESH_MEM_HOST));
+    for (int p = 0; p < 2; p++)
+      if (fabsf(out[p * C] - 0.7f) > 1e-5f || fabsf(out[p * C + 1] - 0.2f) > 1e-5f) return 14;
+    /* timing hooks: one bracketed region, one launch of the fusion kernel, one view */
+    double ms = 0; uint64_t regions = 0, launches = 0, views = 0;
+    CHECK(smesh_profile_reset(0));
+    CHECK(smesh_profile_enable(0, 1 << SMESH_PROF_FUSE_SCATTER));
+    CHECK(smesh_fuse_view(r, a, &cam, probs, NULL, SMESH_MEM_HOST));
+    CHECK(smesh_profile_enable(0, 0));
+    CHECK(smesh_profile_read_ex(0, SMESH_PROF_FUSE_SCATTER, &ms, &regions, &launches, &views));
+    if (regions != 1 || launches != 1 || views != 1 || !(ms > 0)) return 15;
+    /* a communicator of one rank: the all-reduce leaves the accumulator as it is */
+    uint8_t id[SMESH_COMM_ID_BYTES]; smesh_comm_t* comm = NULL; float before[2 * C], after[2 * C];
+    CHECK(smesh_aggregator_get_raw(a, before, SMESH_MEM_HOST));
+    CHECK(smesh_comm_unique_id(id));
+    CHECK(smesh_comm_create(0, 1, 0, id, &comm));
+    { smesh_comm_t* cs[1]; smesh_aggregator_t* as[1]; cs[0] = comm; as[0] = a; CHECK(smesh_allreduce(cs, as, 1)); }
+    CHECK(smesh_aggregator_get_raw(a, after, SMESH_MEM_HOST));
+    if (memcmp(before, after, sizeof before) != 0) return 16;
+    CHECK(smesh_comm_destroy(comm));
+  }
+#endif
   /* invalid arguments come back as SMESH_ERR_INVALID with a message, never as a crash or an exit() */
   if (smesh_aggregator_add(a, idx, 99, istr, SMESH_MEM_HOST, probs, pstr, SMESH_MEM_HOST, NULL, NULL, SMESH_MEM_HOST, W, H) != SMESH_ERR_INVALID) return 9;
   if (strlen(smesh_last_error()) == 0) return 10;
