@@ -251,3 +251,31 @@ def test_render_can_return_the_reference_s_dltensor_capsules(sm, oracle):
 def to_dev(sm, a):
     from semantic_meshes_amd.device import to_device
     return to_device(a)
+
+
+@pytest.mark.parametrize("variant", ["native", "torch"])
+def test_bench_under_the_drivers_launcher_world_one(variant):
+    """bench.py the way the driver starts it for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), with one rank:
+    RANK / WORLD_SIZE / MASTER_* from the environment, the unique id over the bootstrap socket, communicator creation, the
+    all-reduce inside the timed region, the barrier and the max-over-ranks clock -- native RCCL path and torch.distributed variant."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, SMESH_ALLREDUCE=variant)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "16", "--warmup", "8",
+                          "--workload", "cfg1", "--no-host-path"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith('{"metric"')][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["steps"] == 16 and out["value"] > 100
+    assert out["config"]["allreduce"].startswith("native" if variant == "native" else "torch.distributed")
+    assert out["config"]["host_syncs_in_timed_region"] == (1 if variant == "native" else 4)
+    assert out["roofline"]["views_per_launch"] in (1, 2) and 0 < out["roofline"]["frac"] < 1
