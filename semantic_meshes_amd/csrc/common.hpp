@@ -119,6 +119,21 @@ struct TriFuseArgs {
   uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
 };
 
+// What k_fuse_tri needs to know about ONE of the views it fuses in a launch (the per-view part of TriFuseArgs), and NV of them.
+struct TriView {
+  const TriFrag* frags;
+  const uint32_t* idx;
+  const float* probs;
+  const float* weights;       // may be null
+  const uint32_t* big_queue;
+  const uint32_t* big_len;    // [0] queue length, [1] "check the masks against the index plane" flag of the render
+  uint32_t W, H;
+};
+template <int NV>
+struct TriViews {
+  TriView v[NV];
+};
+
 // One rendered view as the triangle-order fusion consumes it (raster.hip -> fusion.hip).
 struct RenderedView {
   const TriFrag* frags;         // per-triangle fragment records of the render

@@ -319,49 +319,64 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
 }
 
 // Triangles with a bounding box larger than 8 x 8 pixels: one WAVE per queued triangle (so, unlike the small-triangle
-// path, the summation order is a tree).  Runs in the tail blocks of k_fuse_tri.
-template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers, uint32_t* __restrict__ lds_list) {
-  const uint32_t nbig = min(*a.big_len, a.big_capacity);
-  for (uint32_t q = worker; q < nbig; q += nworkers) {
-    const uint32_t fi = a.big_queue[q];                       // position in the renderer's triangle order
-    const TriFrag rec = a.frags[fi];
-    if (rec.kind != 2) continue;
-    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
-    fuse_box<CT, KIND, EXACT>(a, f, rec.x0, rec.y0, (int)(rec.mask & 0xFFFFu), (int)((rec.mask >> 16) & 0xFFFFu), lds_list);
-  }
+// path, the summation order is a tree).  Runs in the tail blocks of k_fuse_tri.  With several views in one launch a triangle
+// that is big in ANY of them is left to one tail wave for ALL of them (first view first, as separate calls would do it), so that
+// no other wave touches its row; the views in which it is small are scanned as 8 x 8 boxes.  A triangle queued by several views
+// is taken from the queue of the first of them only.
+__device__ __forceinline__ TriFuseArgs with_view(const TriFuseArgs& a, const TriView& w) {
+  TriFuseArgs x = a;
+  x.frags = w.frags; x.idx = w.idx; x.probs = w.probs; x.weights = w.weights; x.big_queue = w.big_queue; x.big_len = w.big_len;
+  x.W = w.W; x.H = w.H;
+  return x;
 }
 
-// Two views in one launch: a triangle that is big in EITHER view is left to one tail wave for BOTH views (first view
-// first, as two calls would do it), so that no other wave touches its row; its small view is scanned as an 8 x 8 box.
-// A triangle queued by both views is taken from the first view's queue only.
-template <int CT, int KIND, bool EXACT>
-__device__ __forceinline__ void fuse_big_triangles_pair(const TriFuseArgs& a, const TriFuseArgs& b, uint32_t worker, uint32_t nworkers,
-                                                        uint32_t* __restrict__ lds_list) {
-  const uint32_t na = min(*a.big_len, a.big_capacity), nb = min(*b.big_len, b.big_capacity);
-  for (uint32_t q = worker; q < na + nb; q += nworkers) {
-    const bool second = q >= na;
-    const uint32_t fi = second ? b.big_queue[q - na] : a.big_queue[q];
-    const TriFrag ra = a.frags[fi], rb = b.frags[fi];
-    if (second ? (rb.kind != 2 || ra.kind == 2) : (ra.kind != 2)) continue;
-    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;
-    for (int j = 0; j < 2; j++) {
-      const TriFrag rec = j ? rb : ra;
+template <int CT, int KIND, bool EXACT, int NV>
+__device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const TriViews<NV>& vw, uint32_t worker, uint32_t nworkers,
+                                                   uint32_t* __restrict__ lds_list) {
+  uint32_t len[NV], total = 0u;
+#pragma unroll
+  for (int v = 0; v < NV; v++) { len[v] = min(*vw.v[v].big_len, a.big_capacity); total += len[v]; }
+  for (uint32_t q = worker; q < total; q += nworkers) {
+    uint32_t fi = 0u;
+    bool take = false;
+    {
+      uint32_t qq = q;
+      bool earlier_done = false;   // the queue entry has been located
+#pragma unroll
+      for (int j = 0; j < NV; j++) {   // wave-uniform: q is
+        if (!earlier_done) {
+          if (qq < len[j]) {
+            fi = vw.v[j].big_queue[qq];
+            take = vw.v[j].frags[fi].kind == 2;
+#pragma unroll
+            for (int i = 0; i < NV; i++) if (i < j && vw.v[i].frags[fi].kind == 2) take = false;   // an earlier view's queue has it
+            earlier_done = true;
+          } else {
+            qq -= len[j];
+          }
+        }
+      }
+    }
+    if (!take) continue;
+    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const TriFrag rec = vw.v[j].frags[fi];
       if (rec.kind == 0) continue;
-      TriFuseArgs v = a;                  // wave-uniform selection of the view
-      if (j) { v.idx = b.idx; v.probs = b.probs; v.weights = b.weights; v.H = b.H; v.W = b.W; }
+      const TriFuseArgs x = with_view(a, vw.v[j]);
       int x1, y1;
       if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
-      else { x1 = min((int)rec.x0 + 7, (int)v.W - 1); y1 = min((int)rec.y0 + 7, (int)v.H - 1); }
-      fuse_box<CT, KIND, EXACT>(v, f, rec.x0, rec.y0, x1, y1, lds_list);
+      else { x1 = min((int)rec.x0 + 7, (int)x.W - 1); y1 = min((int)rec.y0 + 7, (int)x.H - 1); }
+      fuse_box<CT, KIND, EXACT>(x, f, rec.x0, rec.y0, x1, y1, lds_list);
     }
   }
 }
 
-// NV = 1: one view (a).  NV = 2: views a then b of the same mesh into the same accumulator -- the 64-row block makes ONE
-// round trip for both, and the additions happen in the order two launches would have made them.
+// NV views (1, 2, 4 or 8) of the same mesh into the same accumulator in ONE launch, in order: the wave's 64-row block makes one
+// round trip for all of them (the accumulator traffic is 15 us of a two-view launch's 83 at cfg2), and the additions happen in the
+// order NV launches would have made them.  `a`: what the views share (accumulator, mesh, class count ...); `vw`: the views.
 template <int CT, int KIND, bool EXACT, int NV>
-__global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b) {
+__global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> vw) {
   const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
   constexpr int PB = CT <= 24 ? 2 : 1;        // pixels whose class vectors are in flight together (3 or 4: no difference, round 2)
   constexpr int KV = (kWave * CT / 4 + kWave - 1) / kWave;   // float4 per lane of the 64-row block
@@ -369,62 +384,69 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b
   const int l = threadIdx.x;
   if (blockIdx.x >= a.tri_blocks) {   // tail blocks: the queued big triangles
     uint32_t* lds_list = reinterpret_cast<uint32_t*>(srow);   // the tail waves have no use for the row block: >= 64 entries
-    if (NV == 2) fuse_big_triangles_pair<CT, KIND, EXACT>(a, b, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, lds_list);
-    else fuse_big_triangles<CT, KIND, EXACT>(a, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, lds_list);
+    fuse_big_triangles<CT, KIND, EXACT, NV>(a, vw, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, lds_list);
     return;
   }
   const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
   const uint64_t f = f0 + l;
-  TriFrag rec[NV];
+  // per view: box origin (x0 | y0 << 16) and the mask of this triangle's VISIBLE pixels inside its <= 8 x 8 box
+  uint32_t org[NV];
+  unsigned long long msk[NV];
+  bool big = false;   // a box over 8 x 8 in any view: this row belongs to a tail wave
 #pragma unroll
-  for (int v = 0; v < NV; v++) { rec[v].x0 = 0; rec[v].y0 = 0; rec[v].kind = 0; rec[v].pad = 0; rec[v].mask = 0ull; }
+  for (int v = 0; v < NV; v++) { org[v] = 0u; msk[v] = 0ull; }
   if (f < a.F) {
-    rec[0] = a.frags[f];
-    if (NV == 2) rec[NV - 1] = b.frags[f];
+#pragma unroll
+    for (int v = 0; v < NV; v++) {
+      const TriFrag rec = vw.v[v].frags[f];
+      org[v] = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
+      msk[v] = rec.kind == 1 ? rec.mask : 0ull;
+      big = big || rec.kind == 2;
+    }
   }
-  const bool big = rec[0].kind == 2 || rec[NV - 1].kind == 2;   // this row belongs to a tail wave
+  if (big) {
+#pragma unroll
+    for (int v = 0; v < NV; v++) msk[v] = 0ull;
+  }
   // Re-ordered mesh (renderer's position -> primitive id table): the id is what the index image holds and which row to
   // update; the 64 rows of a wave are then scattered, so every lane loads / stores its own row instead of the LDS block.
   const bool scattered = a.prim_id != nullptr;
   const uint32_t pid = (scattered && f < a.F) ? a.prim_id[f] : (uint32_t)f;
   auto pixel = [&](int v, int k) -> uint64_t {
-    return (uint64_t)(rec[v].x0 + (k >> 3)) * (v ? b.H : a.H) + rec[v].y0 + (k & 7);
+    return (uint64_t)((org[v] & 0xFFFFu) + (uint32_t)(k >> 3)) * vw.v[v].H + (org[v] >> 16) + (uint32_t)(k & 7);
   };
 
-  // ---- pass 1: which emitted fragments won the depth test?  n = pixels of this primitive in this view.
-  // Four candidates per lane and view are checked per round so that their index loads are in flight together.
-  unsigned long long m[NV], win[NV];
-  uint32_t n[NV];
+  // ---- pass 1, normally skipped: the tile resolve of the rasteriser has already cleared the losers of the depth test out of the
+  // masks (raster.hip, tile_resolve_block) unless the render says otherwise (big_len[1]: fragment-queue overflow, direct
+  // rasteriser) or the mesh was re-ordered: then the candidates are checked against the index plane here, four index loads in
+  // flight per lane.
+  bool verify = scattered;
 #pragma unroll
-  for (int v = 0; v < NV; v++) { m[v] = (rec[v].kind == 1 && !big) ? rec[v].mask : 0ull; win[v] = 0ull; n[v] = 0u; }
-  // The tile resolve of the rasteriser has already cleared the losers out of the masks (raster.hip, tile_resolve_block) unless
-  // the render says otherwise (big_len[1]: fragment-queue overflow, direct rasteriser) or the mesh was re-ordered: then the
-  // candidates are checked against the index plane here.
-  const bool verify = scattered || a.big_len[1] != 0u || (NV == 2 && b.big_len[1] != 0u);
-  if (!verify) {
-#pragma unroll
-    for (int v = 0; v < NV; v++) { win[v] = m[v]; n[v] = (uint32_t)__popcll(m[v]); m[v] = 0ull; }
-  }
-  while (__ballot((m[0] | m[NV - 1]) != 0ull) != 0ull) {
-    int k[NV][4];
-    uint32_t got[NV][4];
+  for (int v = 0; v < NV; v++) verify = verify || vw.v[v].big_len[1] != 0u;
+  if (verify) {
 #pragma unroll
     for (int v = 0; v < NV; v++) {
-      const uint32_t* __restrict__ idx = v ? b.idx : a.idx;
+      const uint32_t* __restrict__ idx = vw.v[v].idx;
+      unsigned long long m = msk[v], win = 0ull;
+      while (__ballot(m != 0ull) != 0ull) {
+        int k[4];
+        uint32_t got[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        k[v][j] = -1;
-        if (m[v]) { k[v][j] = __ffsll((long long)m[v]) - 1; m[v] &= m[v] - 1ull; }
-        got[v][j] = idx[k[v][j] >= 0 ? pixel(v, k[v][j]) : 0];   // unconditional (clamped) so that the loads overlap
+        for (int j = 0; j < 4; j++) {
+          k[j] = -1;
+          if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
+          got[j] = idx[k[j] >= 0 ? pixel(v, k[j]) : 0];   // unconditional (clamped) so that the loads overlap
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (k[j] >= 0 && got[j] == pid) win |= 1ull << k[j];
       }
+      msk[v] = win;
     }
-#pragma unroll
-    for (int v = 0; v < NV; v++)
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-        if (k[v][j] >= 0 && got[v][j] == pid) { n[v]++; win[v] |= 1ull << k[v][j]; }
   }
-  const unsigned long long any_win = win[0] | win[NV - 1];
+  unsigned long long any_win = 0ull;
+#pragma unroll
+  for (int v = 0; v < NV; v++) any_win |= msk[v];
   if (__ballot(any_win != 0ull) == 0ull) return;   // nothing of these 64 triangles is visible: rows untouched
 
   // ---- issue together: the wave's 64 accumulator rows (one contiguous block) and the first PB pixels'
@@ -447,15 +469,16 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b
     part_t part[PT];
 #pragma unroll
     for (int c = 0; c < PT; c++) part[c] = (part_t)0;
-    const float* __restrict__ probs = v ? b.probs : a.probs;
-    const float* __restrict__ weights = v ? b.weights : a.weights;
+    const float* __restrict__ probs = vw.v[v].probs;
+    const float* __restrict__ weights = vw.v[v].weights;
+    const uint32_t nv = (uint32_t)__popcll(msk[v]);   // this primitive's pixels in this view: the histogram entry of Mesh.h:90-93
     float w0 = 0.0f;
-    if (n[v]) {
-      const float image_weight = 1.0f / ((float)n[v]);                       // Mesh.h:100
+    if (nv) {
+      const float image_weight = 1.0f / ((float)nv);                         // Mesh.h:100
       const float pixel_w = 1.0f;                                            // :101
       w0 = a.iew * image_weight + (1 - a.iew) * pixel_w;                     // :102
     }
-    unsigned long long mm = win[v];
+    unsigned long long mm = msk[v];
     while (__ballot(mm != 0ull) != 0ull) {
       float p[PB][CT];
       float wt[PB];
@@ -514,7 +537,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriFuseArgs b
         }
       }
     }
-    if (KIND == SMESH_AGG_MUL && n[v]) {   // (n[v] != 0: the loop above ran, so this lane's row is in accr)
+    if (KIND == SMESH_AGG_MUL && nv) {   // (nv != 0: the loop above ran, so this lane's row is in accr)
       const float m = row_centre<CT, EXACT>(accr, C);
       float* __restrict__ lo_row = a.acc_lo + (uint64_t)pid * C;   // the lo plane is read and written by the row's owner lane
       float lo[PT];

@@ -38,7 +38,7 @@
 using namespace smesh;
 
 // fusion_pair.hip: k_fuse_tri<CT, KIND, EXACT, 2> for the class-count slot `tri_ct` chosen below
-void smesh_launch_fuse_tri_pair(int kind, int tri_ct, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriFuseArgs& tb);
+void smesh_launch_fuse_tri_multi(int kind, int tri_ct, int nviews, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv);
 
 namespace {
 
@@ -1624,19 +1624,32 @@ const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordere
 
 bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a) { return a->C <= (uint32_t)kFuseTriMaxC; }
 
+// How many views one k_fuse_tri launch takes for this aggregator: 8 (class counts up to 24: the per-view state is 3 registers, the
+// kernel stays at four waves per SIMD), 2 up to kFuseTriMaxC, else 1.  Instances exist for 1, 2, 4 and 8.
+int smesh_aggregator_max_fused_views(smesh_aggregator* a) {
+  static const int cap = getenv("SMESH_FUSE_VIEWS") ? std::max(1, atoi(getenv("SMESH_FUSE_VIEWS"))) : 8;
+  const int m = a->C <= 24u ? 8 : (a->C <= (uint32_t)kFuseTriMaxC ? 2 : 1);
+  return std::min(m, cap);
+}
+
 // `nviews` = 1, or 2 (smesh_aggregator_can_fuse_pair): views[0] then views[1] of the same renderer in one launch.
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews) {
   DeviceCtx* ctx = a->ctx;
   hipStream_t st = ctx->stream;
   if (F == 0) return SMESH_OK;
-  if (nviews < 1 || nviews > 2 || (nviews == 2 && !smesh_aggregator_can_fuse_pair(a)))
+  if ((nviews != 1 && nviews != 2 && nviews != 4 && nviews != 8) || nviews > smesh_aggregator_max_fused_views(a))
     return fail(SMESH_ERR_INVALID, "fuse_triangles: unsupported view count");
   const uint64_t N = views[0].W * views[0].H;
-  TriFuseArgs t, tb;
-  for (int v = 0; v < 2; v++) {
+  TriFuseArgs t;
+  TriViews<8> tv;
+  for (int v = 0; v < 8; v++) {
     const RenderedView& rv = views[v < nviews ? v : 0];
-    TriFuseArgs& x = v ? tb : t;
+    tv.v[v] = TriView{rv.frags, rv.idx, rv.probs, rv.weights, rv.big_queue, rv.big_len, (uint32_t)rv.W, (uint32_t)rv.H};
+  }
+  for (int v = 0; v < 1; v++) {
+    const RenderedView& rv = views[0];
+    TriFuseArgs& x = t;
     x.frags = rv.frags; x.idx = rv.idx; x.probs = rv.probs; x.weights = rv.weights; x.acc = a->acc; x.acc_lo = a->acc_lo; x.F = F; x.C = a->C;
     x.W = (uint32_t)rv.W; x.H = (uint32_t)rv.H; x.iew = a->iew; x.big_queue = rv.big_queue; x.big_len = rv.big_len;
     x.big_capacity = big_capacity;
@@ -1694,25 +1707,27 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     }
 #define SMESH_FT(K)                                                                           \
     switch (tri_ct) {                                                                         \
-      case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K, true, 1>), grid, block, 0, st, t, t); break;     \
-      case 13: hipLaunchKernelGGL((k_fuse_tri<13, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 19: hipLaunchKernelGGL((k_fuse_tri<19, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 20: hipLaunchKernelGGL((k_fuse_tri<20, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 21: hipLaunchKernelGGL((k_fuse_tri<21, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 40: hipLaunchKernelGGL((k_fuse_tri<40, K, true, 1>), grid, block, 0, st, t, t); break;    \
-      case 8:  hipLaunchKernelGGL((k_fuse_tri<8, K, false, 1>), grid, block, 0, st, t, t); break;    \
-      case 16: hipLaunchKernelGGL((k_fuse_tri<16, K, false, 1>), grid, block, 0, st, t, t); break;   \
-      case 24: hipLaunchKernelGGL((k_fuse_tri<24, K, false, 1>), grid, block, 0, st, t, t); break;   \
-      case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false, 1>), grid, block, 0, st, t, t); break;   \
-      case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false, 1>), grid, block, 0, st, t, t); break;   \
-      case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, t); break;   \
+      case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K, true, 1>), grid, block, 0, st, t, tv1); break;     \
+      case 13: hipLaunchKernelGGL((k_fuse_tri<13, K, true, 1>), grid, block, 0, st, t, tv1); break;    \
+      case 19: hipLaunchKernelGGL((k_fuse_tri<19, K, true, 1>), grid, block, 0, st, t, tv1); break;    \
+      case 20: hipLaunchKernelGGL((k_fuse_tri<20, K, true, 1>), grid, block, 0, st, t, tv1); break;    \
+      case 21: hipLaunchKernelGGL((k_fuse_tri<21, K, true, 1>), grid, block, 0, st, t, tv1); break;    \
+      case 40: hipLaunchKernelGGL((k_fuse_tri<40, K, true, 1>), grid, block, 0, st, t, tv1); break;    \
+      case 8:  hipLaunchKernelGGL((k_fuse_tri<8, K, false, 1>), grid, block, 0, st, t, tv1); break;    \
+      case 16: hipLaunchKernelGGL((k_fuse_tri<16, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
+      case 24: hipLaunchKernelGGL((k_fuse_tri<24, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
+      case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
+      case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
+      case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
       default:                                                                                \
         if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                               \
         hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, pw, amax);             \
         break;                                                                                \
     }
-    if (nviews == 2) {   // the two-view instances of k_fuse_tri live in fusion_pair.hip
-      smesh_launch_fuse_tri_pair(a->kind, tri_ct, grid, st, t, tb);
+    TriViews<1> tv1;
+    tv1.v[0] = tv.v[0];
+    if (nviews >= 2) {   // the several-view instances of k_fuse_tri live in fusion_pair.hip / fusion_multi*.hip
+      smesh_launch_fuse_tri_multi(a->kind, tri_ct, nviews, grid, st, t, tv);
     } else
     switch (a->kind) {
       case SMESH_AGG_SUM: SMESH_FT(SMESH_AGG_SUM); break;

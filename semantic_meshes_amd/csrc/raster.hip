@@ -39,6 +39,7 @@ int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_id
                                        const float* d_w, uint64_t W, uint64_t H);
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
 bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a);
+int smesh_aggregator_max_fused_views(smesh_aggregator* a);
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews);
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
@@ -1654,9 +1655,12 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
     // single launch adds the dispatch latency that back-to-back launches hide)
     if (pairable) {
       ProfScope fuse_region(ctx, SMESH_PROF_FUSE_SCATTER);
-      for (int j = 0; j < gn; j += 2) {
-        const int nv = std::min(2, gn - j);
-        RenderedView rv[2];
+      const int max_nv = smesh_aggregator_max_fused_views(a);
+      for (int j = 0; j < gn;) {
+        // the largest of 8 / 4 / 2 / 1 views that fits what is left of the group and what the kernel takes for this class count
+        int nv = 1;
+        while (nv * 2 <= std::min(max_nv, gn - j)) nv *= 2;
+        RenderedView rv[kMaxGroup];
         for (int v = 0; v < nv; v++) {
           const smesh_renderer::Side& sd = r->side[base + j + v];
           const uint64_t k = i + (uint64_t)(j + v);
@@ -1664,6 +1668,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
                                weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
         }
         SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
+        j += nv;
       }
     }
     if (pairable) g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);

@@ -197,14 +197,16 @@ def test_profile_counts_launches_and_views(sm):
     _lib.check(L.smesh_profile_sample_every(0, 1))
     _lib.check(L.smesh_profile_enable(0, 1 << _lib.PROF_FUSE_SCATTER))
     try:
-        agg.fuse_views(r, cams[:8], probs[:8])   # one region: 4 launches of 2 views
+        agg.fuse_views(r, cams[:8], probs[:8])   # one region: ONE launch of 8 views (class counts up to 24)
         ms, reg, n, v = read()
-        assert (reg, n, v) == (1, 4, 8) and ms > 0
-        agg.fuse_views(r, cams[8:11], probs[8:11])   # group of 3: a pair launch and a single
+        assert (reg, n, v) == (1, 1, 8) and ms > 0
+        agg.fuse_views(r, cams[8:11], probs[8:11])   # group of 3: a two-view launch and a single
         ms, reg, n, v = read()
-        assert (reg, n, v) == (2, 6, 11)
+        assert (reg, n, v) == (2, 3, 11)
         agg.fuse_view(r, cams[0], probs[0])
-        assert read()[1:] == (3, 7, 12)
+        assert read()[1:] == (3, 4, 12)
+        agg.fuse_views(r, cams[:7], probs[:7])   # 7 = 4 + 2 + 1
+        assert read()[1:] == (4, 7, 19)
         _lib.check(L.smesh_profile_sample_every(0, 2))   # every second region: counters follow the TIMED regions only
         _lib.check(L.smesh_profile_reset(0))
         for _ in range(4):
