@@ -256,11 +256,11 @@ def main():
     prof_mask = 0xFF if os.environ.get("SMESH_BENCH_PROFILE_ALL") else (1 << _lib.PROF_FUSE_SCATTER)
     if os.environ.get("SMESH_BENCH_NO_PROFILE"):   # experiment: what do the HIP events around the kernel cost?
         prof_mask = 0
-    # HIP events on the library's stream around every 8th launch of the dominant kernel (an event pair costs ~4 us
-    # of stream time = 4 % of a cfg2 view, so not every launch is bracketed); with fuse_views around every 2nd group's
-    # back-to-back fusion launches (four launches of two views each for a group of eight).  The library counts the launches
-    # and views inside the bracketed regions itself (smesh_profile_read_ex).
-    _lib.check(_lib.lib().smesh_profile_sample_every(device, int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "2"))))
+    # HIP events on the library's stream around every 8th launch of the dominant kernel when every view is its own call (an event
+    # pair costs ~4 us of stream time = 5 % of a cfg2 view); with fuse_views around the fusion launches of EVERY group (one launch of
+    # eight views for class counts up to 24: 4 us in 600).  The library counts the launches and views inside the bracketed
+    # regions itself (smesh_profile_read_ex).
+    _lib.check(_lib.lib().smesh_profile_sample_every(device, int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "1"))))
     _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
     barrier()
     _lib.synchronize(device)
@@ -299,13 +299,29 @@ def main():
         needed_per_view = 4 * N + 4 * C * NV_mean + 16 * F + 8 * C * T_mean
         t_launch = k_ms * 1e-3 / max(k_launches, 1)                  # average duration of one launch of the dominant kernel
         views_per_launch = k_views / max(k_launches, 1)
+        # which launches those were: a call of n views is cut into launches of 8 / 4 / 2 / 1 views, largest first (the library's
+        # rule, smesh_fuse_views); cross-checked against the library's own counters
+        mix = {}
+        if B > 1 and int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "1")) == 1 and prof_mask:
+            cap = 8 if C <= 24 else (2 if C <= 48 else 1)
+            cap = min(cap, int(os.environ.get("SMESH_FUSE_VIEWS", "8")))
+            for i in range(args.warmup, total_views, B):
+                left = min(i + B, total_views) - i
+                while left:
+                    nv = 1
+                    while nv * 2 <= min(cap, left):
+                        nv *= 2
+                    mix[nv] = mix.get(nv, 0) + 1
+                    left -= nv
+            if sum(mix.values()) != k_launches or sum(k * v for k, v in mix.items()) != k_views:
+                mix = {}
         achieved = bytes_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         achieved_needed = needed_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "fusion_traffic.json")
         if os.path.exists(tpath) and args.workload == "cfg2":
             try:
-                tkey = fuse_kernel + ("_pair" if views_per_launch > 1.5 else "")
+                tkey = fuse_kernel + ("_x8" if views_per_launch > 6 else "_pair" if views_per_launch > 1.5 else "")
                 traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
                 traffic_source = "profiles/fusion_traffic.json (PMC passes of an earlier run of this command; not measured in this run)"
             except Exception:
@@ -342,8 +358,9 @@ def main():
                          "frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4),
                          "views_per_launch": (int(views_per_launch) if views_per_launch == int(views_per_launch)
                                               else round(views_per_launch, 3)),
-                         "avg_launch_us": round(1e6 * t_launch, 2), "launches_timed": k_launches, "views_timed": k_views,
-                         "regions_timed": k_regions,
+                         "launches_by_views": {str(k): v for k, v in sorted(mix.items(), reverse=True)} or None,
+                         "avg_launch_us": round(1e6 * t_launch, 2), "us_per_view": round(1e3 * k_ms / max(k_views, 1), 3),
+                         "launches_timed": k_launches, "views_timed": k_views, "regions_timed": k_regions,
                          "distinct_primitives_per_view": int(T_mean), "visible_pixels_per_view": int(NV_mean),
                          "other_kernels_us_per_view": ({"histogram+pixel_weights": round(1e3 * hist_ms / max(args.steps, 1), 2),
                                                         "raster": round(1e3 * raster_ms / max(raster_regions, 1) / max(1, min(B, 8)), 2)}
