@@ -303,7 +303,7 @@ def main():
         # rule, smesh_fuse_views); cross-checked against the library's own counters
         mix = {}
         if B > 1 and int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "1")) == 1 and prof_mask:
-            cap = 8 if C <= 24 else (2 if C <= 48 else 1)
+            cap = 8 if C <= 40 else (2 if C <= 48 else 1)
             cap = min(cap, int(os.environ.get("SMESH_FUSE_VIEWS", "8")))
             for i in range(args.warmup, total_views, B):
                 left = min(i + B, total_views) - i

@@ -1624,11 +1624,12 @@ const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordere
 
 bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a) { return a->C <= (uint32_t)kFuseTriMaxC; }
 
-// How many views one k_fuse_tri launch takes for this aggregator: 8 (class counts up to 24: the per-view state is 3 registers, the
-// kernel stays at four waves per SIMD), 2 up to kFuseTriMaxC, else 1.  Instances exist for 1, 2, 4 and 8.
+// How many views one k_fuse_tri launch takes for this aggregator: 8 for class counts up to 40 (the per-view state is 3 registers:
+// 149 VGPRs at C = 19, 206 at C = 40 -- the occupancy of the two-view instance or one wave less), 2 up to kFuseTriMaxC (the 48-slot
+// instance has no registers left), else 1.  Instances exist for 1, 2, 4 and 8 views.
 int smesh_aggregator_max_fused_views(smesh_aggregator* a) {
   static const int cap = getenv("SMESH_FUSE_VIEWS") ? std::max(1, atoi(getenv("SMESH_FUSE_VIEWS"))) : 8;
-  const int m = a->C <= 24u ? 8 : (a->C <= (uint32_t)kFuseTriMaxC ? 2 : 1);
+  const int m = a->C <= 40u ? 8 : (a->C <= (uint32_t)kFuseTriMaxC ? 2 : 1);
   return std::min(m, cap);
 }
 

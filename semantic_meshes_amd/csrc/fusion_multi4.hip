@@ -1,5 +1,5 @@
-// fusion_multi4.hip -- the four-views-per-launch instances of the triangle-order fusion kernel k_fuse_tri (class counts up to 24:
-// exact instances 5 / 13 / 19 / 20 / 21, run-time-C instances sized 8 / 16 / 24).  A translation unit of its own so that the
+// fusion_multi4.hip -- the four-views-per-launch instances of the triangle-order fusion kernel k_fuse_tri (class counts up to 40:
+// exact instances 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 / 16 / 24 / 32 / 40).  A translation unit of its own so that the
 // instance sets compile in parallel (see fusion_pair.hip).
 #include <hip/hip_runtime.h>
 
@@ -27,6 +27,9 @@ void smesh_launch_fuse_tri_4(int kind, int tri_ct, dim3 grid, hipStream_t st, co
     case 19: hipLaunchKernelGGL((k_fuse_tri<19, K, true, 4>), grid, block, 0, st, t, vn); break;         \
     case 20: hipLaunchKernelGGL((k_fuse_tri<20, K, true, 4>), grid, block, 0, st, t, vn); break;         \
     case 21: hipLaunchKernelGGL((k_fuse_tri<21, K, true, 4>), grid, block, 0, st, t, vn); break;         \
+    case 40: hipLaunchKernelGGL((k_fuse_tri<40, K, true, 4>), grid, block, 0, st, t, vn); break;         \
+    case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false, 4>), grid, block, 0, st, t, vn); break;        \
+    case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false, 4>), grid, block, 0, st, t, vn); break;        \
     case 8:  hipLaunchKernelGGL((k_fuse_tri<8, K, false, 4>), grid, block, 0, st, t, vn); break;         \
     case 16: hipLaunchKernelGGL((k_fuse_tri<16, K, false, 4>), grid, block, 0, st, t, vn); break;        \
     default: hipLaunchKernelGGL((k_fuse_tri<24, K, false, 4>), grid, block, 0, st, t, vn); break;        \
