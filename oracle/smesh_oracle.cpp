@@ -70,25 +70,24 @@ inline ScreenVertex project_vertex(const smesh_camera_t& cam, const float* p) {
   return s;
 }
 
-// Edge function through two screen points, evaluated with the endpoints in a canonical order so
-// that the two triangles sharing an edge compute bit-identical magnitudes (watertightness, B-2).
+// Edge function through two screen points as a linear form E(p) = A px + B py + C, its coefficients taken from the endpoints in
+// a canonical order so that the two triangles sharing an edge compute bit-identical magnitudes (watertightness, B-2), evaluated
+// with two fused multiply-adds -- fma(A, px, fma(B, py, C)): every step one IEEE rounding, the same on the host and on the GPU.
+// (Round 1's form dx (py - ly) - dy (px - lx) cost five operations per edge and sample; the rasteriser is bound by them.)
 struct Edge {
-  double lx, ly, dx, dy;
-  double sign;  // -1 if the endpoints were swapped into canonical order
+  double A, B, C;
   inline void setup(double ax, double ay, double bx, double by) {
     const bool sw = (bx < ax) || (bx == ax && by < ay);
-    lx = sw ? bx : ax; ly = sw ? by : ay;
+    const double lx = sw ? bx : ax, ly = sw ? by : ay;
     const double hx = sw ? ax : bx, hy = sw ? ay : by;
-    dx = hx - lx; dy = hy - ly;
-    sign = sw ? -1.0 : 1.0;
+    const double dx = hx - lx, dy = hy - ly;
+    const double c0 = dx * ly;
+    const double c = std::fma(dy, lx, -c0);          // dy lx - dx ly
+    const double sign = sw ? -1.0 : 1.0;             // -1 if the endpoints were swapped into canonical order
+    A = sign * (-dy); B = sign * dx; C = sign * c;   // (multiplications by +-1: exact)
   }
-  inline double eval(double px, double py) const {
-    const double e = dx * (py - ly) - dy * (px - lx);
-    return sign * e;
-  }
-  // d(eval)/dpx and d(eval)/dpy
-  inline double gx() const { return sign * (-dy); }
-  inline double gy() const { return sign * dx; }
+  inline void flip() { A = -A; B = -B; C = -C; }
+  inline double eval(double px, double py) const { return std::fma(A, px, std::fma(B, py, C)); }
 };
 
 struct TriSetup {
@@ -123,8 +122,8 @@ inline TriSetup setup_triangle(const ScreenVertex& a, const ScreenVertex& b, con
   if (!(area2 != 0.0) || !std::isfinite(area2)) return t;  // degenerate; no back-face culling (a3)
   t.s = area2 > 0.0 ? 1.0 : -1.0;
   for (int i = 0; i < 3; i++) {
-    const double A = t.s * t.e[i].gx(), B = t.s * t.e[i].gy();
-    t.own[i] = (A > 0.0) || (A == 0.0 && B > 0.0);
+    if (t.s < 0.0) t.e[i].flip();                           // interior weights positive whatever the orientation
+    t.own[i] = (t.e[i].A > 0.0) || (t.e[i].A == 0.0 && t.e[i].B > 0.0);
   }
   t.iz[0] = a.iz; t.iz[1] = b.iz; t.iz[2] = c.iz;
   t.ok = true;
@@ -134,7 +133,7 @@ inline TriSetup setup_triangle(const ScreenVertex& a, const ScreenVertex& b, con
 // Returns true and the weights if sample (px,py) is covered.
 inline bool cover(const TriSetup& t, double px, double py, double w[3]) {
   for (int i = 0; i < 3; i++) {
-    w[i] = t.s * t.e[i].eval(px, py);
+    w[i] = t.e[i].eval(px, py);
     if (!(w[i] > 0.0 || (w[i] == 0.0 && t.own[i]))) return false;
   }
   return true;
@@ -143,7 +142,7 @@ inline bool cover(const TriSetup& t, double px, double py, double w[3]) {
 // perspective-correct camera-space depth (B-3)
 inline bool depth_at(const TriSetup& t, const double w[3], float* z) {
   const double num = (w[0] + w[1]) + w[2];
-  const double den = (w[0] * t.iz[0] + w[1] * t.iz[1]) + w[2] * t.iz[2];
+  const double den = std::fma(w[2], t.iz[2], std::fma(w[1], t.iz[1], w[0] * t.iz[0]));
   const float zf = (float)(num / den);
   if (!(zf > 0.0f) || !std::isfinite(zf)) return false;
   *z = zf;

@@ -122,46 +122,43 @@ __global__ void k_project_vertices_group(ProjectGroup g) {
 }
 
 // ---- triangle setup --------------------------------------------------------------------------------
-// Edge through A,B evaluated from canonically ordered endpoints: both triangles sharing the edge get the
-// same |value|, so a sample is claimed by exactly one of them (with the tie rule below).
+// Edge through two screen points as the linear form E(p) = A px + B py + C, the coefficients taken from canonically ordered
+// endpoints (both triangles sharing the edge get the same |value|, so a sample is claimed by exactly one of them, with the
+// tie rule below) and evaluated as fma(A, px, fma(B, py, C)): two FP64 instructions per edge and sample, each one IEEE
+// rounding -- the oracle's Edge::setup / Edge::eval, operation for operation.
 struct EdgeEq {
-  double lx, ly, dx, dy, sign;
+  double A, B, C;
 };
 
 __device__ __forceinline__ EdgeEq make_edge(double ax, double ay, double bx, double by) {
   EdgeEq e;
   const bool sw = (bx < ax) || (bx == ax && by < ay);
-  e.lx = sw ? bx : ax;
-  e.ly = sw ? by : ay;
-  const double hx = sw ? ax : bx;
-  const double hy = sw ? ay : by;
-  e.dx = hx - e.lx;
-  e.dy = hy - e.ly;
-  e.sign = sw ? -1.0 : 1.0;
+  const double lx = sw ? bx : ax, ly = sw ? by : ay;
+  const double hx = sw ? ax : bx, hy = sw ? ay : by;
+  const double dx = hx - lx, dy = hy - ly;
+  const double c0 = dx * ly;
+  const double c = __builtin_fma(dy, lx, -c0);
+  e.A = sw ? dy : -dy;      // sign * (-dy), sign = -1 for swapped endpoints
+  e.B = sw ? -dx : dx;
+  e.C = sw ? -c : c;
   return e;
 }
 
 __device__ __forceinline__ double eval_edge(const EdgeEq& e, double px, double py) {
-  const double a = e.dx * (py - e.ly);
-  const double b = e.dy * (px - e.lx);
-  return e.sign * (a - b);
+  return __builtin_fma(e.A, px, __builtin_fma(e.B, py, e.C));
 }
 
+__device__ __forceinline__ void flip_edge(EdgeEq& e) { e.A = -e.A; e.B = -e.B; e.C = -e.C; }
+
 struct Tri {
-  EdgeEq e0, e1, e2;   // e_i is opposite vertex i
-  double s;            // orientation sign
+  EdgeEq e0, e1, e2;   // e_i is opposite vertex i; oriented so that interior samples have positive values
   bool own0, own1, own2;
   double iz0, iz1, iz2;
   int x0, x1, y0, y1;
 };
 
-// Tie rule: a sample exactly on the edge belongs to the triangle whose edge normal (A, B) = s * sign * (-dy, dx) satisfies
-// A > 0 || (A == 0 && B > 0).  s and sign are +-1, so only the signs of dy / dx and of s * sign matter (no multiplications).
-__device__ __forceinline__ bool owns(double s, const EdgeEq& e) {
-  const bool pos = (s > 0.0) == (e.sign > 0.0);   // s * sign == +1
-  if (e.dy != 0.0) return (e.dy < 0.0) == pos;     // A = s * sign * (-dy) > 0
-  return e.dx != 0.0 && (e.dx > 0.0) == pos;       // A == 0: B = s * sign * dx > 0
-}
+// Tie rule: a sample exactly on the edge belongs to the triangle whose (oriented) edge normal satisfies A > 0 || (A == 0 && B > 0).
+__device__ __forceinline__ bool owns(const EdgeEq& e) { return e.A > 0.0 || (e.A == 0.0 && e.B > 0.0); }
 
 __device__ __forceinline__ bool setup_tri(const ScreenVertex& a, const ScreenVertex& b, const ScreenVertex& c,
                                           uint32_t W, uint32_t H, Tri& t) {
@@ -177,10 +174,10 @@ __device__ __forceinline__ bool setup_tri(const ScreenVertex& a, const ScreenVer
   t.e2 = make_edge(a.u, a.v, b.u, b.v);
   const double area2 = eval_edge(t.e2, c.u, c.v);
   if (!(area2 != 0.0) || !isfinite(area2)) return false;
-  t.s = area2 > 0.0 ? 1.0 : -1.0;
-  t.own0 = owns(t.s, t.e0);
-  t.own1 = owns(t.s, t.e1);
-  t.own2 = owns(t.s, t.e2);
+  if (area2 < 0.0) { flip_edge(t.e0); flip_edge(t.e1); flip_edge(t.e2); }   // no back-face culling: orient instead
+  t.own0 = owns(t.e0);
+  t.own1 = owns(t.e1);
+  t.own2 = owns(t.e2);
   t.iz0 = a.iz; t.iz1 = b.iz; t.iz2 = c.iz;
   return true;
 }
@@ -191,14 +188,14 @@ struct Shaded { bool ok; float z; double b1, b2; };
 __device__ __forceinline__ Shaded shade(const Tri& t, int x, int y, bool want_bary) {
   Shaded r; r.ok = false; r.z = 0.0f; r.b1 = 0.0; r.b2 = 0.0;
   const double px = (double)x + 0.5, py = (double)y + 0.5;
-  const double w0 = t.s * eval_edge(t.e0, px, py);
+  const double w0 = eval_edge(t.e0, px, py);
   if (!(w0 > 0.0 || (w0 == 0.0 && t.own0))) return r;
-  const double w1 = t.s * eval_edge(t.e1, px, py);
+  const double w1 = eval_edge(t.e1, px, py);
   if (!(w1 > 0.0 || (w1 == 0.0 && t.own1))) return r;
-  const double w2 = t.s * eval_edge(t.e2, px, py);
+  const double w2 = eval_edge(t.e2, px, py);
   if (!(w2 > 0.0 || (w2 == 0.0 && t.own2))) return r;
   const double num = (w0 + w1) + w2;
-  const double den = (w0 * t.iz0 + w1 * t.iz1) + w2 * t.iz2;
+  const double den = __builtin_fma(w2, t.iz2, __builtin_fma(w1, t.iz1, w0 * t.iz0));
   const float zf = (float)(num / den);
   if (!(zf > 0.0f) || !isfinite(zf)) return r;
   r.ok = true; r.z = zf;
@@ -209,11 +206,11 @@ __device__ __forceinline__ Shaded shade(const Tri& t, int x, int y, bool want_ba
 // The coverage part of shade() alone (same expressions, same order).
 __device__ __forceinline__ bool covered(const Tri& t, int x, int y) {
   const double px = (double)x + 0.5, py = (double)y + 0.5;
-  const double w0 = t.s * eval_edge(t.e0, px, py);
+  const double w0 = eval_edge(t.e0, px, py);
   if (!(w0 > 0.0 || (w0 == 0.0 && t.own0))) return false;
-  const double w1 = t.s * eval_edge(t.e1, px, py);
+  const double w1 = eval_edge(t.e1, px, py);
   if (!(w1 > 0.0 || (w1 == 0.0 && t.own1))) return false;
-  const double w2 = t.s * eval_edge(t.e2, px, py);
+  const double w2 = eval_edge(t.e2, px, py);
   return w2 > 0.0 || (w2 == 0.0 && t.own2);
 }
 
@@ -402,14 +399,9 @@ __device__ __forceinline__ Claim wave_claim_prepare(uint32_t tile, uint32_t cnt)
   return c;
 }
 
-__device__ __forceinline__ double flip_sign(double v, uint32_t hi_mask) {
-  return __hiloint2double(__double2hiint(v) ^ (int)hi_mask, __double2loint(v));
-}
-
 // One lane per triangle (bounding box <= 8 x 8; larger ones: see the end of the kernel): coverage walk, slot
 // reservation in the (at most 2 x 2) tiles the box overlaps, then depth per covered sample and the queue stores.
-// The edge functions are shade()'s, regrouped: s * (sign * (a - b)) is +-(a - b) exactly, so the two sign
-// multiplications become one XOR of the sign bit, and b = dy * (px - lx) is hoisted out of the row loop.
+// The edge functions are shade()'s, expression for expression.
 __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint64_t wave_id) {
   // a.tpw triangles per wave (64 for large meshes; fewer for small ones, so that the cooperative medium-triangle
   // loop below has enough waves to spread over the chip)
@@ -422,16 +414,11 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
   Tri t;
   t.x0 = 0; t.y0 = 0;
   unsigned long long cover = 0ull;
-  uint32_t n0 = 0u, n1 = 0u, n2 = 0u;   // sign-bit masks of the three edge functions
   bool medium = false;
   const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // value written to the index image
   if (f < a.F && load_tri(a, f, t)) {
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
     rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
-    const uint32_t shi = (uint32_t)__double2hiint(t.s);   // s and sign are +-1.0: their product is negative iff the sign bits differ
-    n0 = (shi ^ (uint32_t)__double2hiint(t.e0.sign)) & 0x80000000u;
-    n1 = (shi ^ (uint32_t)__double2hiint(t.e1.sign)) & 0x80000000u;
-    n2 = (shi ^ (uint32_t)__double2hiint(t.e2.sign)) & 0x80000000u;
     if (bw > 8 || bh > 8) {
       const uint32_t slot = atomicAdd(a.big_count, 1u);          // every such triangle: the fusion walks this queue
       if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
@@ -449,9 +436,9 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
       const double py0 = (double)t.y0 + 0.5;
       double px = (double)t.x0 + 0.5, py = py0;   // advanced by exact steps of 1.0
       for (int k = 0; k < area; k++) {
-        const double w0 = flip_sign(t.e0.dx * (py - t.e0.ly) - t.e0.dy * (px - t.e0.lx), n0);
-        const double w1 = flip_sign(t.e1.dx * (py - t.e1.ly) - t.e1.dy * (px - t.e1.lx), n1);
-        const double w2 = flip_sign(t.e2.dx * (py - t.e2.ly) - t.e2.dy * (px - t.e2.lx), n2);
+        const double w0 = eval_edge(t.e0, px, py);
+        const double w1 = eval_edge(t.e1, px, py);
+        const double w2 = eval_edge(t.e2, px, py);
         const bool in = (w0 > 0.0 || (w0 == 0.0 && t.own0)) & (w1 > 0.0 || (w1 == 0.0 && t.own1)) &
                         (w2 > 0.0 || (w2 == 0.0 && t.own2));
         if (in) cover |= 1ull << (dx * 8 + dy);
@@ -494,11 +481,11 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
     const int dx = bit >> 3, dy = bit & 7;
     const int x = t.x0 + dx, y = t.y0 + dy;
     const double px = (double)x + 0.5, py = (double)y + 0.5;
-    const double w0 = flip_sign(t.e0.dx * (py - t.e0.ly) - t.e0.dy * (px - t.e0.lx), n0);
-    const double w1 = flip_sign(t.e1.dx * (py - t.e1.ly) - t.e1.dy * (px - t.e1.lx), n1);
-    const double w2 = flip_sign(t.e2.dx * (py - t.e2.ly) - t.e2.dy * (px - t.e2.lx), n2);
+    const double w0 = eval_edge(t.e0, px, py);
+    const double w1 = eval_edge(t.e1, px, py);
+    const double w2 = eval_edge(t.e2, px, py);
     const double num = (w0 + w1) + w2;
-    const double den = (w0 * t.iz0 + w1 * t.iz1) + w2 * t.iz2;
+    const double den = __builtin_fma(w2, t.iz2, __builtin_fma(w1, t.iz1, w0 * t.iz0));
     const float zf = (float)(num / den);
     unsigned long long key = kNullKey;
     if (zf > 0.0f && isfinite(zf)) {
@@ -551,11 +538,10 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
     auto bi = [&](int v) -> int { return __builtin_amdgcn_readlane(v, src); };
     auto bd = [&](double v) -> double { return __hiloint2double(bi(__double2hiint(v)), bi(__double2loint(v))); };
     const int X0 = bi(t.x0), X1 = bi(t.x1), Y0 = bi(t.y0), Y1 = bi(t.y1);
-    const double e0lx = bd(t.e0.lx), e0ly = bd(t.e0.ly), e0dx = bd(t.e0.dx), e0dy = bd(t.e0.dy);
-    const double e1lx = bd(t.e1.lx), e1ly = bd(t.e1.ly), e1dx = bd(t.e1.dx), e1dy = bd(t.e1.dy);
-    const double e2lx = bd(t.e2.lx), e2ly = bd(t.e2.ly), e2dx = bd(t.e2.dx), e2dy = bd(t.e2.dy);
+    const double e0A = bd(t.e0.A), e0B = bd(t.e0.B), e0C = bd(t.e0.C);
+    const double e1A = bd(t.e1.A), e1B = bd(t.e1.B), e1C = bd(t.e1.C);
+    const double e2A = bd(t.e2.A), e2B = bd(t.e2.B), e2C = bd(t.e2.C);
     const double iz0 = bd(t.iz0), iz1 = bd(t.iz1), iz2 = bd(t.iz2);
-    const uint32_t m0 = (uint32_t)bi((int)n0), m1 = (uint32_t)bi((int)n1), m2 = (uint32_t)bi((int)n2);
     const int owns = bi((t.own0 ? 1 : 0) | (t.own1 ? 2 : 0) | (t.own2 ? 4 : 0));
     const uint32_t fb = (uint32_t)wave0 + (uint32_t)src;
     const uint32_t fbid = (uint32_t)bi((int)pid);
@@ -569,15 +555,15 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
       const bool in_box = i < area;
       const int x = X0 + (in_box ? i / bh : 0), y = Y0 + (in_box ? i % bh : 0);
       const double px = (double)x + 0.5, py = (double)y + 0.5;
-      const double w0 = flip_sign(e0dx * (py - e0ly) - e0dy * (px - e0lx), m0);
-      const double w1 = flip_sign(e1dx * (py - e1ly) - e1dy * (px - e1lx), m1);
-      const double w2 = flip_sign(e2dx * (py - e2ly) - e2dy * (px - e2lx), m2);
+      const double w0 = __builtin_fma(e0A, px, __builtin_fma(e0B, py, e0C));
+      const double w1 = __builtin_fma(e1A, px, __builtin_fma(e1B, py, e1C));
+      const double w2 = __builtin_fma(e2A, px, __builtin_fma(e2B, py, e2C));
       const bool cov = (w0 > 0.0 || (w0 == 0.0 && (owns & 1))) & (w1 > 0.0 || (w1 == 0.0 && (owns & 2))) &
                        (w2 > 0.0 || (w2 == 0.0 && (owns & 4)));
       unsigned long long key = kNullKey;
       if (in_box && cov) {
         const double num = (w0 + w1) + w2;
-        const double den = (w0 * iz0 + w1 * iz1) + w2 * iz2;
+        const double den = __builtin_fma(w2, iz2, __builtin_fma(w1, iz1, w0 * iz0));
         const float zf = (float)(num / den);
         if (zf > 0.0f && isfinite(zf)) {
           uint32_t prim = fbid;
