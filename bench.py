@@ -257,10 +257,12 @@ def main():
     if os.environ.get("SMESH_BENCH_NO_PROFILE"):   # experiment: what do the HIP events around the kernel cost?
         prof_mask = 0
     # HIP events on the library's stream around every 8th launch of the dominant kernel when every view is its own call (an event
-    # pair costs ~4 us of stream time = 5 % of a cfg2 view); with fuse_views around the fusion launches of EVERY group (one launch of
-    # eight views for class counts up to 24: 4 us in 600).  The library counts the launches and views inside the bracketed
-    # regions itself (smesh_profile_read_ex).
-    _lib.check(_lib.lib().smesh_profile_sample_every(device, int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "1"))))
+    # pair costs ~4 us of stream time = 5 % of a cfg2 view); with fuse_views around the fusion launches of every THIRD group, the
+    # first one included (measured: the two events of a group keep the stream idle for 2 x 6 us = 2 % of a group of eight cfg2
+    # views; bracketing all of them lowered `value` from 14.3 k to 14.0 k views/s).  The library counts the launches and views
+    # inside the bracketed regions itself (smesh_profile_read_ex), so the averages below are over exactly the regions that were timed.
+    prof_every = int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "3"))
+    _lib.check(_lib.lib().smesh_profile_sample_every(device, prof_every))
     _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
     barrier()
     _lib.synchronize(device)
@@ -302,10 +304,12 @@ def main():
         # which launches those were: a call of n views is cut into launches of 8 / 4 / 2 / 1 views, largest first (the library's
         # rule, smesh_fuse_views); cross-checked against the library's own counters
         mix = {}
-        if B > 1 and int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "1")) == 1 and prof_mask:
+        if B > 1 and prof_mask:
             cap = 8 if C <= 40 else (2 if C <= 48 else 1)
             cap = min(cap, int(os.environ.get("SMESH_FUSE_VIEWS", "8")))
-            for i in range(args.warmup, total_views, B):
+            for call, i in enumerate(range(args.warmup, total_views, B)):
+                if call % prof_every:
+                    continue           # (not one of the bracketed calls)
                 left = min(i + B, total_views) - i
                 while left:
                     nv = 1
@@ -361,6 +365,7 @@ def main():
                          "launches_by_views": {str(k): v for k, v in sorted(mix.items(), reverse=True)} or None,
                          "avg_launch_us": round(1e6 * t_launch, 2), "us_per_view": round(1e3 * k_ms / max(k_views, 1), 3),
                          "launches_timed": k_launches, "views_timed": k_views, "regions_timed": k_regions,
+                         "regions_in_timed_loop": len(range(args.warmup, total_views, B)),
                          "distinct_primitives_per_view": int(T_mean), "visible_pixels_per_view": int(NV_mean),
                          "other_kernels_us_per_view": ({"histogram+pixel_weights": round(1e3 * hist_ms / max(args.steps, 1), 2),
                                                         "raster": round(1e3 * raster_ms / max(raster_regions, 1) / max(1, min(B, 8)), 2)}

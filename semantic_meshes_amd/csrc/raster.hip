@@ -152,13 +152,18 @@ __device__ __forceinline__ void flip_edge(EdgeEq& e) { e.A = -e.A; e.B = -e.B; e
 
 struct Tri {
   EdgeEq e0, e1, e2;   // e_i is opposite vertex i; oriented so that interior samples have positive values
-  bool own0, own1, own2;
+  int cls0, cls1, cls2;   // v_cmp_class masks of the accepted edge values: positive, plus the zeros on an owned edge
   double iz0, iz1, iz2;
   int x0, x1, y0, y1;
 };
 
 // Tie rule: a sample exactly on the edge belongs to the triangle whose (oriented) edge normal satisfies A > 0 || (A == 0 && B > 0).
 __device__ __forceinline__ bool owns(const EdgeEq& e) { return e.A > 0.0 || (e.A == 0.0 && e.B > 0.0); }
+// The coverage test of one edge, w > 0 || (w == 0 && owned), as ONE instruction: v_cmp_class_f64 with the set of accepted
+// classes (+normal, +denormal, +inf; with ownership also +0 and -0).  NaN is in no set, as it fails both comparisons.
+constexpr int kClsPositive = 0x380, kClsZero = 0x060;
+__device__ __forceinline__ int edge_classes(const EdgeEq& e) { return owns(e) ? (kClsPositive | kClsZero) : kClsPositive; }
+__device__ __forceinline__ bool edge_accepts(double w, int cls) { return __builtin_amdgcn_class(w, cls); }
 
 __device__ __forceinline__ bool setup_tri(const ScreenVertex& a, const ScreenVertex& b, const ScreenVertex& c,
                                           uint32_t W, uint32_t H, Tri& t) {
@@ -175,9 +180,9 @@ __device__ __forceinline__ bool setup_tri(const ScreenVertex& a, const ScreenVer
   const double area2 = eval_edge(t.e2, c.u, c.v);
   if (!(area2 != 0.0) || !isfinite(area2)) return false;
   if (area2 < 0.0) { flip_edge(t.e0); flip_edge(t.e1); flip_edge(t.e2); }   // no back-face culling: orient instead
-  t.own0 = owns(t.e0);
-  t.own1 = owns(t.e1);
-  t.own2 = owns(t.e2);
+  t.cls0 = edge_classes(t.e0);
+  t.cls1 = edge_classes(t.e1);
+  t.cls2 = edge_classes(t.e2);
   t.iz0 = a.iz; t.iz1 = b.iz; t.iz2 = c.iz;
   return true;
 }
@@ -189,11 +194,11 @@ __device__ __forceinline__ Shaded shade(const Tri& t, int x, int y, bool want_ba
   Shaded r; r.ok = false; r.z = 0.0f; r.b1 = 0.0; r.b2 = 0.0;
   const double px = (double)x + 0.5, py = (double)y + 0.5;
   const double w0 = eval_edge(t.e0, px, py);
-  if (!(w0 > 0.0 || (w0 == 0.0 && t.own0))) return r;
+  if (!edge_accepts(w0, t.cls0)) return r;
   const double w1 = eval_edge(t.e1, px, py);
-  if (!(w1 > 0.0 || (w1 == 0.0 && t.own1))) return r;
+  if (!edge_accepts(w1, t.cls1)) return r;
   const double w2 = eval_edge(t.e2, px, py);
-  if (!(w2 > 0.0 || (w2 == 0.0 && t.own2))) return r;
+  if (!edge_accepts(w2, t.cls2)) return r;
   const double num = (w0 + w1) + w2;
   const double den = __builtin_fma(w2, t.iz2, __builtin_fma(w1, t.iz1, w0 * t.iz0));
   const float zf = (float)(num / den);
@@ -207,11 +212,11 @@ __device__ __forceinline__ Shaded shade(const Tri& t, int x, int y, bool want_ba
 __device__ __forceinline__ bool covered(const Tri& t, int x, int y) {
   const double px = (double)x + 0.5, py = (double)y + 0.5;
   const double w0 = eval_edge(t.e0, px, py);
-  if (!(w0 > 0.0 || (w0 == 0.0 && t.own0))) return false;
+  if (!edge_accepts(w0, t.cls0)) return false;
   const double w1 = eval_edge(t.e1, px, py);
-  if (!(w1 > 0.0 || (w1 == 0.0 && t.own1))) return false;
+  if (!edge_accepts(w1, t.cls1)) return false;
   const double w2 = eval_edge(t.e2, px, py);
-  return w2 > 0.0 || (w2 == 0.0 && t.own2);
+  return edge_accepts(w2, t.cls2);
 }
 
 __device__ __forceinline__ uint32_t texel_of(uint32_t res, double b1, double b2) {
@@ -439,8 +444,7 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
         const double w0 = eval_edge(t.e0, px, py);
         const double w1 = eval_edge(t.e1, px, py);
         const double w2 = eval_edge(t.e2, px, py);
-        const bool in = (w0 > 0.0 || (w0 == 0.0 && t.own0)) & (w1 > 0.0 || (w1 == 0.0 && t.own1)) &
-                        (w2 > 0.0 || (w2 == 0.0 && t.own2));
+        const bool in = edge_accepts(w0, t.cls0) && edge_accepts(w1, t.cls1) && edge_accepts(w2, t.cls2);
         if (in) cover |= 1ull << (dx * 8 + dy);
         py += 1.0;
         if (++dy == bh) { dy = 0; dx++; py = py0; px += 1.0; }
@@ -495,10 +499,10 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
       mask |= 1ull << bit;
     }
     const bool hx = dx >= bx, hy = dy >= by;
-    uint32_t e, lim;   // this fragment's entry, and one past the last entry of its sub-queue
-    if (hy) { if (hx) { e = e3++; lim = sq3; } else { e = e2++; lim = sq2; } }
-    else    { if (hx) { e = e1++; lim = sq1; } else { e = e0++; lim = sq0; } }
-    lim += a.q.cap;
+    // this fragment's entry, and one past the last entry of its sub-queue (selects, not branches: the four cases diverge in every wave)
+    const uint32_t e = hy ? (hx ? e3 : e2) : (hx ? e1 : e0);
+    const uint32_t lim = (hy ? (hx ? sq3 : sq2) : (hx ? sq1 : sq0)) + a.q.cap;
+    e0 += (!hx && !hy) ? 1u : 0u; e1 += (hx && !hy) ? 1u : 0u; e2 += (!hx && hy) ? 1u : 0u; e3 += (hx && hy) ? 1u : 0u;
     if (a.dbg & 1) continue;
     // pixel inside its tile: (x mod 32) * 64 + (y mod 64)
     const uint16_t pin = (uint16_t)((((uint32_t)x & (kQW - 1)) * kQH) | ((uint32_t)y & (kQH - 1)));
@@ -542,7 +546,7 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
     const double e1A = bd(t.e1.A), e1B = bd(t.e1.B), e1C = bd(t.e1.C);
     const double e2A = bd(t.e2.A), e2B = bd(t.e2.B), e2C = bd(t.e2.C);
     const double iz0 = bd(t.iz0), iz1 = bd(t.iz1), iz2 = bd(t.iz2);
-    const int owns = bi((t.own0 ? 1 : 0) | (t.own1 ? 2 : 0) | (t.own2 ? 4 : 0));
+    const int c0 = bi(t.cls0), c1 = bi(t.cls1), c2 = bi(t.cls2);
     const uint32_t fb = (uint32_t)wave0 + (uint32_t)src;
     const uint32_t fbid = (uint32_t)bi((int)pid);
     uint32_t tfirst = 0u, tres = 0u;
@@ -558,8 +562,7 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
       const double w0 = __builtin_fma(e0A, px, __builtin_fma(e0B, py, e0C));
       const double w1 = __builtin_fma(e1A, px, __builtin_fma(e1B, py, e1C));
       const double w2 = __builtin_fma(e2A, px, __builtin_fma(e2B, py, e2C));
-      const bool cov = (w0 > 0.0 || (w0 == 0.0 && (owns & 1))) & (w1 > 0.0 || (w1 == 0.0 && (owns & 2))) &
-                       (w2 > 0.0 || (w2 == 0.0 && (owns & 4)));
+      const bool cov = edge_accepts(w0, c0) && edge_accepts(w1, c1) && edge_accepts(w2, c2);
       unsigned long long key = kNullKey;
       if (in_box && cov) {
         const double num = (w0 + w1) + w2;

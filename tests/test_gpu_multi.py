@@ -280,4 +280,6 @@ def test_bench_under_the_drivers_launcher_world_one(variant):
     assert out["n_gpus"] == 1 and out["steps"] == 16 and out["value"] > 100
     assert out["config"]["allreduce"].startswith("native" if variant == "native" else "torch.distributed")
     assert out["config"]["host_syncs_in_timed_region"] == (1 if variant == "native" else 4)
-    assert out["roofline"]["launches_by_views"] == {"8": 2} and out["roofline"]["views_per_launch"] == 8 and 0 < out["roofline"]["frac"] < 1.5
+    # two calls of eight views; the fusion launches of every third call, the first included, are bracketed with events
+    assert out["roofline"]["regions_in_timed_loop"] == 2 and out["roofline"]["regions_timed"] == 1
+    assert out["roofline"]["launches_by_views"] == {"8": 1} and out["roofline"]["views_per_launch"] == 8 and 0 < out["roofline"]["frac"] < 1.5
