@@ -131,16 +131,19 @@ struct EdgeEq {
 };
 
 __device__ __forceinline__ EdgeEq make_edge(double ax, double ay, double bx, double by) {
+  // The oracle's Edge::setup with its selects folded away.  With l the canonically lower endpoint, h the other and
+  // sign = -1 if they were swapped: h - l = sign * (b - a) exactly (IEEE subtraction is antisymmetric), and sign changes pass
+  // through every rounding, so
+  //   A = sign * -(hy - ly) = ay - by,   B = sign * (hx - lx) = bx - ax,
+  //   C = sign * fma(hy - ly, lx, -((hx - lx) * ly)) = fma(by - ay, lx, -((bx - ax) * ly)):
+  // only the lower endpoint itself has to be selected.  Bit-identical to the oracle (the parity tests compare every pixel).
   EdgeEq e;
   const bool sw = (bx < ax) || (bx == ax && by < ay);
   const double lx = sw ? bx : ax, ly = sw ? by : ay;
-  const double hx = sw ? ax : bx, hy = sw ? ay : by;
-  const double dx = hx - lx, dy = hy - ly;
-  const double c0 = dx * ly;
-  const double c = __builtin_fma(dy, lx, -c0);
-  e.A = sw ? dy : -dy;      // sign * (-dy), sign = -1 for swapped endpoints
-  e.B = sw ? -dx : dx;
-  e.C = sw ? -c : c;
+  e.A = ay - by;
+  e.B = bx - ax;
+  const double c0 = e.B * ly;
+  e.C = __builtin_fma(-e.A, lx, -c0);
   return e;
 }
 
@@ -277,8 +280,8 @@ __device__ __forceinline__ uint64_t key_index(uint32_t x, uint32_t y, uint32_t H
 
 __device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t) {
   const int32_t i0 = a.faces[3 * f + 0], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
-  if (i0 < 0 || i1 < 0 || i2 < 0) return false;
-  if ((uint64_t)i0 >= a.V || (uint64_t)i1 >= a.V || (uint64_t)i2 >= a.V) return false;
+  // 0 <= i < V for all three, as one unsigned comparison (negative indices are huge as uint32; V <= 2^31 since indices are int32)
+  if ((uint64_t)max((uint32_t)i0, max((uint32_t)i1, (uint32_t)i2)) >= a.V) return false;
   if (a.tex_res && a.tex_res[f] == 0) return false;
   // all three vertices are fetched before any of them is tested: one memory round trip instead of three
   const ScreenVertex va = a.sv[i0], vb = a.sv[i1], vc = a.sv[i2];
