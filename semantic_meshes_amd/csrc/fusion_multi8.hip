@@ -6,6 +6,7 @@
 #include "common.hpp"
 
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 using namespace smesh;
@@ -18,21 +19,22 @@ namespace {
 
 void smesh_launch_fuse_tri_8(int kind, int tri_ct, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv) {
   const dim3 block(kWave);
+  static const unsigned pad = getenv("SMESH_FUSE_LDS_PAD") ? (unsigned)atoi(getenv("SMESH_FUSE_LDS_PAD")) : 0u;   // experiment: caps the waves a CU holds
   TriViews<8> vn;
   for (int v = 0; v < 8; v++) vn.v[v] = tv.v[v];
 #define SMESH_FTN(K)                                                                                     \
   switch (tri_ct) {                                                                                      \
-    case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K, true, 8>), grid, block, 0, st, t, vn); break;          \
-    case 13: hipLaunchKernelGGL((k_fuse_tri<13, K, true, 8>), grid, block, 0, st, t, vn); break;         \
-    case 19: hipLaunchKernelGGL((k_fuse_tri<19, K, true, 8>), grid, block, 0, st, t, vn); break;         \
-    case 20: hipLaunchKernelGGL((k_fuse_tri<20, K, true, 8>), grid, block, 0, st, t, vn); break;         \
-    case 21: hipLaunchKernelGGL((k_fuse_tri<21, K, true, 8>), grid, block, 0, st, t, vn); break;         \
-    case 40: hipLaunchKernelGGL((k_fuse_tri<40, K, true, 8>), grid, block, 0, st, t, vn); break;         \
-    case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false, 8>), grid, block, 0, st, t, vn); break;        \
-    case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false, 8>), grid, block, 0, st, t, vn); break;        \
-    case 8:  hipLaunchKernelGGL((k_fuse_tri<8, K, false, 8>), grid, block, 0, st, t, vn); break;         \
-    case 16: hipLaunchKernelGGL((k_fuse_tri<16, K, false, 8>), grid, block, 0, st, t, vn); break;        \
-    default: hipLaunchKernelGGL((k_fuse_tri<24, K, false, 8>), grid, block, 0, st, t, vn); break;        \
+    case 5:  hipLaunchKernelGGL((k_fuse_tri<5, K, true, 8>), grid, block, pad, st, t, vn); break;          \
+    case 13: hipLaunchKernelGGL((k_fuse_tri<13, K, true, 8>), grid, block, pad, st, t, vn); break;         \
+    case 19: hipLaunchKernelGGL((k_fuse_tri<19, K, true, 8>), grid, block, pad, st, t, vn); break;         \
+    case 20: hipLaunchKernelGGL((k_fuse_tri<20, K, true, 8>), grid, block, pad, st, t, vn); break;         \
+    case 21: hipLaunchKernelGGL((k_fuse_tri<21, K, true, 8>), grid, block, pad, st, t, vn); break;         \
+    case 40: hipLaunchKernelGGL((k_fuse_tri<40, K, true, 8>), grid, block, pad, st, t, vn); break;         \
+    case 32: hipLaunchKernelGGL((k_fuse_tri<32, K, false, 8>), grid, block, pad, st, t, vn); break;        \
+    case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false, 8>), grid, block, pad, st, t, vn); break;        \
+    case 8:  hipLaunchKernelGGL((k_fuse_tri<8, K, false, 8>), grid, block, pad, st, t, vn); break;         \
+    case 16: hipLaunchKernelGGL((k_fuse_tri<16, K, false, 8>), grid, block, pad, st, t, vn); break;        \
+    default: hipLaunchKernelGGL((k_fuse_tri<24, K, false, 8>), grid, block, pad, st, t, vn); break;        \
   }
   switch (kind) {
     case SMESH_AGG_SUM: SMESH_FTN(SMESH_AGG_SUM); break;

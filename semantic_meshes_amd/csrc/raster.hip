@@ -386,22 +386,24 @@ __device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v) {
   return (uint32_t)s;
 }
 
-// First half of a slot reservation: groups the lanes with cnt > 0 by tile; every lane learns its offset inside
-// its group (prefix), the group's total and its leader lane.  No memory traffic.  Whole wave must call.
-struct Claim { uint32_t prefix, total; int leader; };
-__device__ __forceinline__ Claim wave_claim_prepare(uint32_t tile, uint32_t cnt) {
-  Claim c; c.prefix = 0u; c.total = 0u; c.leader = 0;
-  const bool active = cnt != 0u;
+// First half of a slot reservation.  A lane's fragments fall into the (at most 2 x 2) tiles T0, T0 + tiles_y, T0 + 1, T0 + tiles_y + 1,
+// so lanes with the same T0 share all four: the lanes are grouped by T0 and every lane learns, per quadrant, its offset inside
+// its group and the group's total, and the group's leader lane.  The four counts travel through TWO wave scans, packed in pairs
+// of 16-bit halves (a wave holds at most 64 x 64 fragments per quadrant: no carry).  No memory traffic.  Whole wave must call.
+struct Claim4 { uint32_t pre01, pre23, tot01, tot23; int leader; };
+__device__ __forceinline__ Claim4 wave_claim_prepare4(uint32_t T0, uint32_t n01, uint32_t n23) {
+  Claim4 c; c.pre01 = 0u; c.pre23 = 0u; c.tot01 = 0u; c.tot23 = 0u; c.leader = 0;
+  const bool active = (n01 | n23) != 0u;
   unsigned long long todo = __ballot(active);
   while (todo) {
     const int first = __ffsll((long long)todo) - 1;
-    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)tile, first);
-    const bool in = active && tile == t0;
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)T0, first);
+    const bool in = active && T0 == t0;
     const unsigned long long same = __ballot(in);
-    const uint32_t v = in ? cnt : 0u;
-    const uint32_t s = wave_scan_incl(v);
-    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)s, 63);
-    if (in) { c.prefix = s - v; c.total = tot; c.leader = first; }
+    const uint32_t v01 = in ? n01 : 0u, v23 = in ? n23 : 0u;
+    const uint32_t s01 = wave_scan_incl(v01), s23 = wave_scan_incl(v23);
+    const uint32_t t01 = (uint32_t)__builtin_amdgcn_readlane((int)s01, 63), t23 = (uint32_t)__builtin_amdgcn_readlane((int)s23, 63);
+    if (in) { c.pre01 = s01 - v01; c.pre23 = s23 - v23; c.tot01 = t01; c.tot23 = t23; c.leader = first; }
     todo &= ~same;
   }
   return c;
@@ -462,25 +464,25 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
   const unsigned long long loy = by >= 8 ? ~0ull : (0x0101010101010101ull * ((1ull << by) - 1ull));
   const uint32_t T0 = tx0 * a.q.tiles_y + ty0;
   // quadrant q: bit 0 = next tile in x, bit 1 = next tile in y.  Group, then ALL reservations of the wave in
-  // four back-to-back atomics (one round trip), then fetch the bases from the group leaders.
-  const Claim c0 = wave_claim_prepare(T0, (uint32_t)__popcll(cover & lox & loy));
-  const Claim c1 = wave_claim_prepare(T0 + a.q.tiles_y, (uint32_t)__popcll(cover & ~lox & loy));
-  const Claim c2 = wave_claim_prepare(T0 + 1u, (uint32_t)__popcll(cover & lox & ~loy));
-  const Claim c3 = wave_claim_prepare(T0 + a.q.tiles_y + 1u, (uint32_t)__popcll(cover & ~lox & ~loy));
+  // four back-to-back atomics per group leader (one round trip), then fetch the bases from the leaders.
+  const uint32_t n0 = (uint32_t)__popcll(cover & lox & loy), n1 = (uint32_t)__popcll(cover & ~lox & loy);
+  const uint32_t n2 = (uint32_t)__popcll(cover & lox & ~loy), n3 = (uint32_t)__popcll(cover & ~lox & ~loy);
+  const Claim4 c = wave_claim_prepare4(T0, n0 | (n1 << 16), n2 | (n3 << 16));
+  const uint32_t tot0 = c.tot01 & 0xFFFFu, tot1 = c.tot01 >> 16, tot2 = c.tot23 & 0xFFFFu, tot3 = c.tot23 >> 16;
   uint32_t g0 = 0u, g1 = 0u, g2 = 0u, g3 = 0u;
-  if (!(a.dbg & 16)) {   // (ablation bit 16: grouping without the reservations)
-    if (c0.total && lane == c0.leader) g0 = atomicAdd(&a.q.count[T0 * kQSub + sub], c0.total);
-    if (c1.total && lane == c1.leader) g1 = atomicAdd(&a.q.count[(T0 + a.q.tiles_y) * kQSub + sub], c1.total);
-    if (c2.total && lane == c2.leader) g2 = atomicAdd(&a.q.count[(T0 + 1u) * kQSub + sub], c2.total);
-    if (c3.total && lane == c3.leader) g3 = atomicAdd(&a.q.count[(T0 + a.q.tiles_y + 1u) * kQSub + sub], c3.total);
+  if (!(a.dbg & 16) && cover != 0ull && lane == c.leader) {   // (ablation bit 16: grouping without the reservations)
+    if (tot0) g0 = atomicAdd(&a.q.count[T0 * kQSub + sub], tot0);
+    if (tot1) g1 = atomicAdd(&a.q.count[(T0 + a.q.tiles_y) * kQSub + sub], tot1);
+    if (tot2) g2 = atomicAdd(&a.q.count[(T0 + 1u) * kQSub + sub], tot2);
+    if (tot3) g3 = atomicAdd(&a.q.count[(T0 + a.q.tiles_y + 1u) * kQSub + sub], tot3);
   }
   // entry index (into key[] / pix[]) of this lane's next fragment in each quadrant, and the end of that sub-queue
   const uint32_t sq0 = (T0 * kQSub + sub) * a.q.cap, sq1 = ((T0 + a.q.tiles_y) * kQSub + sub) * a.q.cap,
                  sq2 = ((T0 + 1u) * kQSub + sub) * a.q.cap, sq3 = ((T0 + a.q.tiles_y + 1u) * kQSub + sub) * a.q.cap;
-  uint32_t e0 = sq0 + (uint32_t)__shfl((int)g0, c0.leader) + c0.prefix;
-  uint32_t e1 = sq1 + (uint32_t)__shfl((int)g1, c1.leader) + c1.prefix;
-  uint32_t e2 = sq2 + (uint32_t)__shfl((int)g2, c2.leader) + c2.prefix;
-  uint32_t e3 = sq3 + (uint32_t)__shfl((int)g3, c3.leader) + c3.prefix;
+  uint32_t e0 = sq0 + (uint32_t)__shfl((int)g0, c.leader) + (c.pre01 & 0xFFFFu);
+  uint32_t e1 = sq1 + (uint32_t)__shfl((int)g1, c.leader) + (c.pre01 >> 16);
+  uint32_t e2 = sq2 + (uint32_t)__shfl((int)g2, c.leader) + (c.pre23 & 0xFFFFu);
+  uint32_t e3 = sq3 + (uint32_t)__shfl((int)g3, c.leader) + (c.pre23 >> 16);
   unsigned long long mask = 0ull;
   if (a.dbg & 8) cover = 0ull;   // ablation: setup + coverage + slot reservation, no depth / stores
   for (unsigned long long m = cover; m; m &= m - 1ull) {
