@@ -288,6 +288,9 @@ def main():
 
     fuse_kernel = _lib.lib().smesh_last_fuse_kernel().decode()
     k_ms, k_regions, k_launches, k_views = prof_read(device, _lib.PROF_FUSE_SCATTER)
+    entered = ctypes.c_uint64(0)       # regions of the dominant kernel the timed loop went through, bracketed or not
+    _lib.check(_lib.lib().smesh_profile_regions(device, _lib.PROF_FUSE_SCATTER, ctypes.byref(entered)))
+    k_entered = int(entered.value)
     hist_ms, hist_regions, _, _ = prof_read(device, _lib.PROF_FUSE_HIST)
     raster_ms, raster_regions, _, _ = prof_read(device, _lib.PROF_RASTER)
 
@@ -365,7 +368,7 @@ def main():
                          "launches_by_views": {str(k): v for k, v in sorted(mix.items(), reverse=True)} or None,
                          "avg_launch_us": round(1e6 * t_launch, 2), "us_per_view": round(1e3 * k_ms / max(k_views, 1), 3),
                          "launches_timed": k_launches, "views_timed": k_views, "regions_timed": k_regions,
-                         "regions_in_timed_loop": len(range(args.warmup, total_views, B)),
+                         "regions_in_timed_loop": k_entered,
                          "distinct_primitives_per_view": int(T_mean), "visible_pixels_per_view": int(NV_mean),
                          "other_kernels_us_per_view": ({"histogram+pixel_weights": round(1e3 * hist_ms / max(args.steps, 1), 2),
                                                         "raster": round(1e3 * raster_ms / max(raster_regions, 1) / max(1, min(B, 8)), 2)}
