@@ -144,7 +144,12 @@ def main():
     ap.add_argument("--no-host-path", action="store_true")
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("SMESH_BENCH_VIEWS_PER_CALL", "8")),
                     help="views handed to the library per call (fuse_views; 1 = one fuse_view call per view)")
+    ap.add_argument("--group-pipeline", action="store_true",
+                    help="SMESH_GROUP_PIPELINE=1: the rasteriser of group g+1 beside the fusion of group g (two streams, two banks of "
+                         "view slots); more views/s, but the fusion kernel's own duration -- the roofline divisor -- stretches")
     args = ap.parse_args()
+    if args.group_pipeline:
+        os.environ["SMESH_GROUP_PIPELINE"] = "1"      # (read by the library at its first grouped call)
     if args.steps is None:
         args.steps = {"cfg5": 24}.get(args.workload, 200)
     if args.warmup is None:
@@ -351,6 +356,7 @@ def main():
             "config": {"workload": "%s: %d-triangle grid mesh%s, %d views/GPU at %dx%d, %d classes, probs resident in HBM"
                                    % (args.workload, F, " as %d texel primitives" % P if texels else "", args.steps, W, H, C),
                        "views_per_call": B,
+                       "group_pipeline": bool(int(os.environ.get("SMESH_GROUP_PIPELINE", "0") or 0)),
                        "sharding": "views dp%d, one RCCL all-reduce of float32[P,C]" % world,
                        "allreduce": allreduce_impl,
                        "host_syncs_in_timed_region": 1 if (comm is not None or dist is None) else 4,

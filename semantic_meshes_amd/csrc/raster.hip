@@ -1056,6 +1056,27 @@ bool queues_fit_group(uint64_t W, uint64_t H) {
 // triangles, per-triangle records and index plane r->fused[v]) through the fragment-queue rasteriser with ONE launch per
 // stage: the vertex stage and the tile resolve are short kernels that fill a fraction of the chip, and every launch has a
 // ramp and a tail, so n views' worth of blocks take less than n launches.  Index planes only.
+// Everything a group of views needs in view slots base .. base + n - 1 (records, scratch, fragment queues, index planes), allocated
+// and initialised on `st` -- what render_group_into does on first use, callable ahead of time for the OTHER bank of the group
+// pipeline so that no allocation falls between two groups.
+int prepare_group_slots(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st, int base) {
+  for (int v = 0; v < n; v++) {
+    const uint64_t W = cams[v].width, H = cams[v].height, N = W * H;
+    SMESH_HIP(alloc_side(r, base + v));
+    SMESH_HIP(alloc_scratch(r, base + v));
+    smesh_renderer::ViewScratch& vs = r->vs[base + v];
+    SMESH_TRY(ensure_keys(vs, W, H, st));
+    int qs = SMESH_OK;
+    if (!ensure_queues(r, vs, W, H, st, &qs)) return qs != SMESH_OK ? qs : fail(SMESH_ERR_RUNTIME, "fragment queues unavailable");
+    if (r->fused[base + v].bytes < N * 8) {
+      SMESH_HIP(hipStreamSynchronize(st));   // growing a slot frees the old buffer: nothing may still be reading it
+      SMESH_HIP(hipStreamSynchronize(r->ctx->stream));
+      SMESH_TRY(r->fused[base + v].reserve(N * 8));
+    }
+  }
+  return SMESH_OK;
+}
+
 int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st, int base = 0) {
   DeviceCtx* ctx = r->ctx;
   ProjectGroup pg;
@@ -1620,6 +1641,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
         SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, r->ev_main_fence, 0));
         r->main_pending = false;
       }
+      if (!r->bank_used[bank ^ 1]) SMESH_TRY(prepare_group_slots(r, &cams[i], gn, ctx->raster_stream, (bank ^ 1) * kMaxGroup));
       SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->raster_stream, base));
       SMESH_HIP(hipEventRecord(r->ev_bank_rendered[bank], ctx->raster_stream));
       SMESH_HIP(hipStreamWaitEvent(ctx->stream, r->ev_bank_rendered[bank], 0));

@@ -20,6 +20,23 @@ for w in cfg4 cfg5; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$w -o bench -- python bench.py --workload $w --no-host-path > $out/bench_kt_$w.log 2>&1
   cp $out/kt_$w/bench_kernel_stats.csv $out/r02_bench_${w}_kernel_stats.csv
 done
+# the group pipeline (opt-in): bench line, kernel stats and a trace excerpt showing the rasteriser of group g+1 beside the fusion of group g
+python bench.py --group-pipeline --no-cpu-baseline --no-host-path > $out/bench_gp.log 2>&1; last $out/bench_gp.log > $out/r02_bench_group_pipeline.json
+python bench.py --group-pipeline --steps 20 --warmup 5 --no-cpu-baseline --no-host-path > $out/bench_gp20.log 2>&1; last $out/bench_gp20.log > $out/r02_bench_group_pipeline_steps20.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_gp -o bench -- python bench.py --group-pipeline --steps 80 --warmup 16 --no-cpu-baseline --no-host-path > $out/bench_kt_gp.log 2>&1
+cp $out/kt_gp/bench_kernel_stats.csv $out/r02_bench_group_pipeline_kernel_stats.csv
+OUT=$out python - <<'PY' > $out/r02_group_pipeline_trace_excerpt.txt
+import csv, os
+rows = list(csv.DictReader(open(os.environ["OUT"] + "/kt_gp/bench_kernel_trace.csv")))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+idx = [i for i, r in enumerate(rows) if "k_fuse_tri<19, 0, true, 8>" in r["Kernel_Name"]]
+i0 = idx[len(idx) // 2]
+t0 = int(rows[i0 - 6]["Start_Timestamp"])
+print("# rocprofv3 --kernel-trace of `python bench.py --group-pipeline --steps 80 --warmup 16`: consecutive dispatches in the middle of the timed loop (us)")
+for r in rows[i0 - 6:i0 + 11]:
+    b = int(r["Start_Timestamp"]); e = int(r["End_Timestamp"])
+    print("%-40s start %8.1f  end %8.1f  duration %7.1f  queue %s" % (r["Kernel_Name"].replace("(anonymous namespace)::", "")[:40], (b - t0) / 1e3, (e - t0) / 1e3, (e - b) / 1e3, r.get("Queue_Id", "?")))
+PY
 OUT=$out python - <<'PY'
 import csv, collections, json, os
 out = os.environ["OUT"]
