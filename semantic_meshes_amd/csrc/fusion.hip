@@ -721,66 +721,106 @@ __device__ __forceinline__ void accumulate_slice(float (&accr)[N], const float (
 // Big triangles for any C: one wave per queued triangle, lanes over its pixels.  First sweep: per pixel row sum /
 // arg-max / weight into the per-view scratch images (each lane re-reads only what it wrote itself); then one sweep
 // per kSlice-class chunk with per-lane partial sums and a butterfly over the wave.
+// One view of one such triangle: the pixels of primitive f inside the box [x0, x1] x [y0, y1] of view `a`.
 template <int KIND>
-__device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, uint32_t worker, uint32_t nworkers,
+__device__ __attribute__((noinline)) void fuse_box_any(const TriFuseArgs& a, const uint32_t f, const int x0, const int y0, const int x1, const int y1,
                                                        float* __restrict__ pw, uint32_t* __restrict__ amax) {
   const int l = threadIdx.x;
   const uint32_t C = a.C;
-  const uint32_t nbig = min(*a.big_len, a.big_capacity);
-  for (uint32_t q = worker; q < nbig; q += nworkers) {
-    const uint32_t fi = a.big_queue[q];                       // position in the renderer's triangle order
-    const TriFrag rec = a.frags[fi];
-    if (rec.kind != 2) continue;
-    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
-    const int x0 = rec.x0, y0 = rec.y0, x1 = (int)(rec.mask & 0xFFFFu), y1 = (int)((rec.mask >> 16) & 0xFFFFu);
-    const int bh = y1 - y0 + 1;
-    const long long npx = (long long)(x1 - x0 + 1) * bh;
-    uint32_t n = 0;
-    for (long long i = l; i < npx; i += kWave) {
-      const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
-      n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
+  const int bh = y1 - y0 + 1;
+  const long long npx = (long long)(x1 - x0 + 1) * bh;
+  uint32_t n = 0;
+  for (long long i = l; i < npx; i += kWave) {
+    const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+    n += a.idx[(uint64_t)x * a.H + y] == f ? 1u : 0u;
+  }
+  n = wave_sum_u(n);
+  if (n == 0) return;
+  const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
+  for (long long i = l; i < npx; i += kWave) {
+    const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+    const uint64_t pix = (uint64_t)x * a.H + y;
+    if (a.idx[pix] != f) continue;
+    const float* __restrict__ pr = a.probs + pix * C;
+    float sum = 0.0f, best = 0.0f;
+    uint32_t am = 0;
+    for (uint32_t c = 0; c < C; c++) {
+      const float p = pr[c];
+      sum = sum + p;
+      if (KIND == SMESH_AGG_SUMMAX && (c == 0 || p > best)) { best = p; am = c; }
     }
-    n = wave_sum_u(n);
-    if (n == 0) continue;
-    const float w0 = a.iew * (1.0f / (float)n) + (1 - a.iew) * 1.0f;
+    pw[pix] = sum > 0.5f ? w0 * (a.weights ? a.weights[pix] : 1.0f) : __uint_as_float(kSkipPixel);
+    if (KIND == SMESH_AGG_SUMMAX) amax[pix] = am;
+  }
+  for (uint32_t c0 = 0; c0 < C; c0 += kSlice) {
+    const int cw = (int)min((uint32_t)kSlice, C - c0);
+    float part[kSlice];
+#pragma unroll
+    for (int j = 0; j < kSlice; j++) part[j] = 0.0f;
     for (long long i = l; i < npx; i += kWave) {
       const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
       const uint64_t pix = (uint64_t)x * a.H + y;
       if (a.idx[pix] != f) continue;
-      const float* __restrict__ pr = a.probs + pix * C;
-      float sum = 0.0f, best = 0.0f;
-      uint32_t am = 0;
-      for (uint32_t c = 0; c < C; c++) {
-        const float p = pr[c];
-        sum = sum + p;
-        if (KIND == SMESH_AGG_SUMMAX && (c == 0 || p > best)) { best = p; am = c; }
-      }
-      pw[pix] = sum > 0.5f ? w0 * (a.weights ? a.weights[pix] : 1.0f) : __uint_as_float(kSkipPixel);
-      if (KIND == SMESH_AGG_SUMMAX) amax[pix] = am;
+      const float w = pw[pix];
+      if (__float_as_uint(w) == kSkipPixel) continue;
+      float p[kSlice];
+      load_slice(a.probs + pix * C + c0, cw, p);
+      const int am_local = KIND == SMESH_AGG_SUMMAX ? (int)amax[pix] - (int)c0 : 0;
+      accumulate_slice<KIND>(part, p, cw, w, am_local);
     }
-    for (uint32_t c0 = 0; c0 < C; c0 += kSlice) {
-      const int cw = (int)min((uint32_t)kSlice, C - c0);
-      float part[kSlice];
+    float mine = 0.0f;
 #pragma unroll
-      for (int j = 0; j < kSlice; j++) part[j] = 0.0f;
-      for (long long i = l; i < npx; i += kWave) {
-        const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
-        const uint64_t pix = (uint64_t)x * a.H + y;
-        if (a.idx[pix] != f) continue;
-        const float w = pw[pix];
-        if (__float_as_uint(w) == kSkipPixel) continue;
-        float p[kSlice];
-        load_slice(a.probs + pix * C + c0, cw, p);
-        const int am_local = KIND == SMESH_AGG_SUMMAX ? (int)amax[pix] - (int)c0 : 0;
-        accumulate_slice<KIND>(part, p, cw, w, am_local);
-      }
-      float mine = 0.0f;
+    for (int j = 0; j < kSlice; j++) {
+      const float v = wave_sum(part[j]);
+      if (l == j) mine = v;
+    }
+    if (l < cw) a.acc[(uint64_t)f * C + c0 + l] += mine;   // this wave owns the row: plain read-modify-write
+  }
+}
+
+// The queues of the `nv` views of a launch, walked as one: a triangle that is big in ANY of the views is left to one wave for
+// ALL of them (first view first, as separate launches would do it; the views in which it is small are scanned as 8 x 8 boxes), so
+// that nobody else touches its row; a triangle queued by several views is taken from the queue of the first of them only
+// (fuse_big_triangles in fuse_tri.inc.hpp: same rule).  View v parks its per-pixel weights in its own scratch image.
+template <int KIND>
+__device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, const TriViews<8>& vw, const int nv, uint32_t worker, uint32_t nworkers,
+                                                       float* __restrict__ pw, uint32_t* __restrict__ amax, const uint64_t scratch_stride) {
+  uint32_t len[8], total = 0u;
 #pragma unroll
-      for (int j = 0; j < kSlice; j++) {
-        const float v = wave_sum(part[j]);
-        if (l == j) mine = v;
+  for (int v = 0; v < 8; v++) { len[v] = v < nv ? min(*vw.v[v].big_len, a.big_capacity) : 0u; total += len[v]; }
+  for (uint32_t q = worker; q < total; q += nworkers) {
+    uint32_t fi = 0u;
+    bool take = false;
+    {
+      uint32_t qq = q;
+      bool located = false;
+#pragma unroll
+      for (int j = 0; j < 8; j++) {   // wave-uniform: q is
+        if (!located) {
+          if (qq < len[j]) {
+            fi = vw.v[j].big_queue[qq];
+            take = vw.v[j].frags[fi].kind == 2;
+#pragma unroll
+            for (int i = 0; i < 8; i++) if (i < j && vw.v[i].frags[fi].kind == 2) take = false;   // an earlier view's queue has it
+            located = true;
+          } else {
+            qq -= len[j];
+          }
+        }
       }
-      if (l < cw) a.acc[(uint64_t)f * C + c0 + l] += mine;   // this wave owns the row: plain read-modify-write
+    }
+    if (!take) continue;
+    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      if (j >= nv) continue;
+      const TriFrag rec = vw.v[j].frags[fi];
+      if (rec.kind == 0) continue;
+      const TriFuseArgs x = with_view(a, vw.v[j]);
+      int x1, y1;
+      if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
+      else { x1 = min((int)rec.x0 + 7, (int)x.W - 1); y1 = min((int)rec.y0 + 7, (int)x.H - 1); }
+      fuse_box_any<KIND>(x, f, rec.x0, rec.y0, x1, y1, pw + (uint64_t)j * scratch_stride, amax ? amax + (uint64_t)j * scratch_stride : nullptr);
     }
   }
 }
@@ -788,8 +828,9 @@ __device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, uin
 // The big triangles of the any-C paths run as their own launch: inlined into the kernels below, their kSlice-wide
 // partial sums set the register allocation (148 VGPRs) of waves that never execute them.
 template <int KIND>
-__global__ __launch_bounds__(kWave) void k_fuse_big_any(TriFuseArgs a, float* __restrict__ pw, uint32_t* __restrict__ amax) {
-  fuse_big_triangles_any<KIND>(a, blockIdx.x, gridDim.x, pw, amax);
+__global__ __launch_bounds__(kWave) void k_fuse_big_any(TriFuseArgs a, TriViews<8> vw, int nv, float* __restrict__ pw, uint32_t* __restrict__ amax,
+                                                        uint64_t scratch_stride) {
+  fuse_big_triangles_any<KIND>(a, vw, nv, blockIdx.x, gridDim.x, pw, amax, scratch_stride);
 }
 
 template <int KIND, int G>
@@ -980,84 +1021,140 @@ __device__ __forceinline__ void fuse_pixel_wide(fvec4 (&ac)[NCH], const fvec4 (&
   }
 }
 
+// Up to eight views of the same mesh in one launch (`nv`, a run-time count: one instance per row width), in order: a triangle's
+// accumulator row -- 600 bytes each way at C = 150, two thirds of what a cfg5 view moves -- makes ONE round trip for all of them, and
+// the additions happen in the order `nv` launches would have made them (a store and a load of a float32 row change nothing).  The
+// per-view state of the wave's 64 triangles (box origin, mask of visible pixels) and the views' pointers are parked in LDS, so
+// that the view loop is a run-time loop over broadcast reads instead of eight copies of the code.  A triangle that is big in any
+// of the views belongs to k_fuse_big_any for all of them.
+struct WideViewState {
+  TriView view[8];
+  uint32_t org[8][kWave], lo[8][kWave], hi[8][kWave];
+};
+
 template <int KIND, int NCH>
-__global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a) {
-  constexpr int B = NCH == 1 ? 4 : 2;      // visible triangles whose rows and first pixels are in flight together
+__global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews<8> vw, int nv) {
+  constexpr int B = NCH == 1 ? 4 : 2;      // visible triangles whose rows and next pixels are in flight together
+  __shared__ WideViewState S;
   const int l = threadIdx.x;
   const uint32_t C = a.C;
   const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
   const uint64_t f = f0 + l;
-  TriFrag rec;
-  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
-  if (f < a.F) rec = a.frags[f];
   const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // primitive id (index image value, accumulator row)
-  auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
-  unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
-  unsigned long long win = 0ull;   // pass 1, lane = triangle: the emitted fragments that won the depth test
-  if (!a.prim_id && a.big_len[1] == 0u) { win = m; m = 0ull; }   // the tile resolve has cleared the losers out of the masks (k_fuse_tri)
-  while (__ballot(m != 0ull) != 0ull) {
-    int k[4];
-    uint32_t got[4];
+  unsigned long long win[8];
+  bool big = false;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      k[j] = -1;
-      if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
-      got[j] = a.idx[k[j] >= 0 ? pixel(k[j]) : 0];
+  for (int v = 0; v < 8; v++) {
+    if (l == 0) S.view[v] = vw.v[v];
+    win[v] = 0ull;
+    uint32_t origin = 0u;
+    if (v < nv) {
+      TriFrag rec;
+      rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
+      if (f < a.F) rec = vw.v[v].frags[f];
+      origin = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
+      big = big || rec.kind == 2;
+      unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
+      // pass 1, lane = triangle, normally skipped: the tile resolve has cleared the losers out of the masks (k_fuse_tri)
+      if (!a.prim_id && vw.v[v].big_len[1] == 0u) { win[v] = m; m = 0ull; }
+      const uint32_t* __restrict__ idx = vw.v[v].idx;
+      const uint32_t Hv = vw.v[v].H;
+      while (__ballot(m != 0ull) != 0ull) {
+        int k[4];
+        uint32_t got[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          k[j] = -1;
+          if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
+          got[j] = idx[k[j] >= 0 ? (uint64_t)(rec.x0 + (k[j] >> 3)) * Hv + rec.y0 + (k[j] & 7) : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (k[j] >= 0 && got[j] == pid) win[v] |= 1ull << k[j];
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (k[j] >= 0 && got[j] == pid) win |= 1ull << k[j];
+    S.org[v][l] = origin;
   }
-  unsigned long long vis = __ballot(win != 0ull);
+  unsigned long long any_win = 0ull;
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    if (big) win[v] = 0ull;
+    any_win |= win[v];
+    S.lo[v][l] = (uint32_t)win[v];
+    S.hi[v][l] = (uint32_t)(win[v] >> 32);
+  }
+  unsigned long long vis = __ballot(any_win != 0ull);
   if (vis == 0ull || (a.dbg & 1)) return;
-  const uint32_t origin = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
-  const uint32_t win_lo = (uint32_t)win, win_hi = (uint32_t)(win >> 32);
+  wave_sync();
 
-  // From here on the wave works on one triangle's row at a time; the triangle's pixel set travels in scalar
-  // registers (readlane of its owner lane's mask and box origin), so the control flow is wave-uniform.
+  // From here on the wave works on a few triangles' rows at a time; a triangle's pixel sets are read from its owner lane's LDS
+  // entries into scalar registers, so the control flow is wave-uniform.
+  auto pix_of = [&](uint32_t o, int k, uint32_t Hv) -> uint64_t { return (uint64_t)((o & 0xFFFFu) + (uint32_t)(k >> 3)) * Hv + (o >> 16) + (uint32_t)(k & 7); };
   while (vis) {
-    // a batch of up to B visible triangles: their accumulator rows and first pixels are requested together
     int t[B];
-    unsigned long long pm[B];
-    uint32_t org[B], nt[B], rowid[B];
-    fvec4 ac[B][NCH], p[B][NCH];
-    float wt[B];
+    uint32_t rowid[B];
+    fvec4 ac[B][NCH];
 #pragma unroll
     for (int b = 0; b < B; b++) {
-      t[b] = -1; pm[b] = 0ull; org[b] = 0u; nt[b] = 0u; rowid[b] = 0u;
+      t[b] = -1; rowid[b] = 0u;
       if (vis) {
         t[b] = __ffsll((long long)vis) - 1;
         vis &= vis - 1ull;
-        pm[b] = (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)win_lo, t[b]) |
-                ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)win_hi, t[b]) << 32);
-        org[b] = (uint32_t)__builtin_amdgcn_readlane((int)origin, t[b]);
         rowid[b] = (uint32_t)__builtin_amdgcn_readlane((int)pid, t[b]);
-        nt[b] = (uint32_t)__popcll(pm[b]);
       }
     }
-    auto pix_of = [&](uint32_t o, int k) -> uint64_t { return (uint64_t)((o & 0xFFFFu) + (uint32_t)(k >> 3)) * a.H + (o >> 16) + (uint32_t)(k & 7); };
 #pragma unroll
-    for (int b = 0; b < B; b++) {
-      if (t[b] < 0) continue;
-      if (!(a.dbg & 4)) load_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
-      const uint64_t pix = pix_of(org[b], __ffsll((long long)pm[b]) - 1);
-      pm[b] &= pm[b] - 1ull;
-      if (!(a.dbg & 8)) load_wide<NCH>(a.probs + pix * C, C, l, p[b]);
-      wt[b] = a.weights ? a.weights[pix] : 1.0f;
-    }
+    for (int b = 0; b < B; b++)
+      if (t[b] >= 0 && !(a.dbg & 4)) load_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
+    // (a software-pipelined variant -- one pixel stream per triangle across the views, the next pixel's class vector requested
+    // before the current one is added -- was slower at cfg5: 423 vs 500 views/s, 124 VGPRs instead of 88)
+    for (int v = 0; v < nv; v++) {
+      const float* __restrict__ probs = S.view[v].probs;
+      const float* __restrict__ weights = S.view[v].weights;
+      const uint32_t Hv = S.view[v].H;
+      unsigned long long pm[B];
+      uint32_t org[B];
+      float w0[B];
+      unsigned long long left = 0ull;
 #pragma unroll
-    for (int b = 0; b < B; b++) {
-      if (t[b] < 0) continue;
-      const float w0 = a.iew * (1.0f / ((float)nt[b])) + (1 - a.iew) * 1.0f;     // Mesh.h:100-102
-      fuse_pixel_wide<KIND, NCH>(ac[b], p[b], C, l, w0 * wt[b]);                // :103
-      for (; pm[b]; pm[b] &= pm[b] - 1ull) {                                      // further pixels of this triangle, in image order
-        const uint64_t pix = pix_of(org[b], __ffsll((long long)pm[b]) - 1);
-        fvec4 q[NCH];
-        load_wide<NCH>(a.probs + pix * C, C, l, q);
-        fuse_pixel_wide<KIND, NCH>(ac[b], q, C, l, w0 * (a.weights ? a.weights[pix] : 1.0f));
+      for (int b = 0; b < B; b++) {
+        pm[b] = 0ull; org[b] = 0u; w0[b] = 0.0f;
+        if (t[b] >= 0) {
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lo[v][t[b]]);
+          const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.hi[v][t[b]]);
+          pm[b] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+          org[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.org[v][t[b]]);
+          const uint32_t nt = (uint32_t)__popcll(pm[b]);                                    // this primitive's pixels in this view (Mesh.h:90-93)
+          if (nt) w0[b] = a.iew * (1.0f / ((float)nt)) + (1 - a.iew) * 1.0f;               // Mesh.h:100-102
+        }
+        left |= pm[b];
       }
-      if (!(a.dbg & 2)) store_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
+      while (left) {   // one pixel of each of the B triangles per round, in image order per triangle
+        fvec4 p[B][NCH];
+        float wt[B];
+        bool have[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          have[b] = pm[b] != 0ull;
+          wt[b] = 1.0f;
+          if (have[b]) {
+            const uint64_t pix = pix_of(org[b], __ffsll((long long)pm[b]) - 1, Hv);
+            pm[b] &= pm[b] - 1ull;
+            if (!(a.dbg & 8)) load_wide<NCH>(probs + pix * C, C, l, p[b]);
+            if (weights) wt[b] = weights[pix];
+          }
+        }
+        left = 0ull;
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          if (have[b]) fuse_pixel_wide<KIND, NCH>(ac[b], p[b], C, l, w0[b] * wt[b]);     // :103
+          left |= pm[b];
+        }
+      }
     }
+#pragma unroll
+    for (int b = 0; b < B; b++)
+      if (t[b] >= 0 && !(a.dbg & 2)) store_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
   }
 }
 
@@ -1622,14 +1719,16 @@ const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordere
   return "k_fuse_tri_any";
 }
 
-bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a) { return a->C <= (uint32_t)kFuseTriMaxC; }
+int smesh_aggregator_max_fused_views(smesh_aggregator* a);
+bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a) { return smesh_aggregator_max_fused_views(a) >= 2; }
 
 // How many views one k_fuse_tri launch takes for this aggregator: 8 for class counts up to 40 (the per-view state is 3 registers:
 // 149 VGPRs at C = 19, 206 at C = 40 -- the occupancy of the two-view instance or one wave less), 2 up to kFuseTriMaxC (the 48-slot
 // instance has no registers left), else 1.  Instances exist for 1, 2, 4 and 8 views.
 int smesh_aggregator_max_fused_views(smesh_aggregator* a) {
   static const int cap = getenv("SMESH_FUSE_VIEWS") ? std::max(1, atoi(getenv("SMESH_FUSE_VIEWS"))) : 8;
-  const int m = a->C <= 40u ? 8 : (a->C <= (uint32_t)kFuseTriMaxC ? 2 : 1);
+  int m = a->C <= 40u ? 8 : (a->C <= (uint32_t)kFuseTriMaxC ? 2 : 1);
+  if (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) m = 8;   // k_fuse_tri_wide: any count up to eight
   return std::min(m, cap);
 }
 
@@ -1669,15 +1768,17 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   const bool specialised = tri_ct != 0;
   float* pw = nullptr;
   uint32_t* amax = nullptr;
+  uint64_t scratch_stride = N;   // per-view scratch images of the big-triangle waves
   int G = 1;
   const int wide_chunks = (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) ? (a->C <= 256 ? 1 : a->C <= 512 ? 2 : 4) : 0;   // k_fuse_tri_wide
   if (!specialised) {
     while ((((a->C + G - 1) / G + 3u) & ~3u) > (uint32_t)kSliceAny) G *= 2;   // lanes per accumulator row (can_fuse_triangles: G <= 64)
     // the big-triangle waves park per-pixel weights (and arg-max) here
-    SMESH_TRY(a->pw.reserve(N * 4));
+    for (int v = 0; v < nviews; v++) scratch_stride = std::max<uint64_t>(scratch_stride, views[v].W * views[v].H);
+    SMESH_TRY(a->pw.reserve(scratch_stride * (uint64_t)nviews * 4));
     pw = static_cast<float*>(a->pw.ptr);
     if (a->kind == SMESH_AGG_SUMMAX) {
-      SMESH_TRY(a->fb_amax.reserve(N * 4));
+      SMESH_TRY(a->fb_amax.reserve(scratch_stride * (uint64_t)nviews * 4));
       amax = static_cast<uint32_t*>(a->fb_amax.ptr);
     }
     t.tri_blocks = wide_chunks ? (uint32_t)div_up(F, kWave) : (uint32_t)div_up(F, kWave / G);
@@ -1702,9 +1803,9 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     }
 #define SMESH_FW(K)                                                                            \
     switch (wide_chunks) {                                                                     \
-      case 1:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 1>), tgrid, block, 0, st, t); break; \
-      case 2:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 2>), tgrid, block, 0, st, t); break; \
-      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4>), tgrid, block, 0, st, t); break; \
+      case 1:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 1>), tgrid, block, 0, st, t, tv, nviews); break; \
+      case 2:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 2>), tgrid, block, 0, st, t, tv, nviews); break; \
+      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4>), tgrid, block, 0, st, t, tv, nviews); break; \
     }
 #define SMESH_FT(K)                                                                           \
     switch (tri_ct) {                                                                         \
@@ -1722,12 +1823,12 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
       case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
       default:                                                                                \
         if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                               \
-        hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, pw, amax);             \
+        hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, tv, nviews, pw, amax, scratch_stride);             \
         break;                                                                                \
     }
     TriViews<1> tv1;
     tv1.v[0] = tv.v[0];
-    if (nviews >= 2) {   // the several-view instances of k_fuse_tri live in fusion_pair.hip / fusion_multi*.hip
+    if (nviews >= 2 && specialised) {   // the several-view instances of k_fuse_tri live in fusion_pair.hip / fusion_multi*.hip
       smesh_launch_fuse_tri_multi(a->kind, tri_ct, nviews, grid, st, t, tv);
     } else
     switch (a->kind) {

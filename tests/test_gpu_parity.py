@@ -1051,6 +1051,84 @@ def test_fuse_views_pairs_equal_single_calls_bit_for_bit(sm, oracle, kind, C):
     assert_fused_close(batch.get(), want, rtol=1e-5)
 
 
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C", [150, 300, 520])
+def test_fuse_views_wide_rows_equal_single_calls_bit_for_bit(sm, oracle, kind, C):
+    """Wide rows (k_fuse_tri_wide, one / two / four 16-byte pieces per lane): up to eight views per launch, a triangle's row making
+    one round trip for all of them -- the same float32 additions in the same order as one call per view, so the raw accumulators
+    agree bit for bit with each other and (Sum / Summax) with the float32 oracle.  Eleven views: launches of 8, 2 and 1."""
+    import os
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(80, 40, 200, 150, views=4)        # ~1.5 px triangles: all bounding boxes <= 8 x 8
+    cams = cams + cams[:3] + cams
+    P = len(mesh.faces)
+    rng = np.random.default_rng(200 + C)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    batch, single = sm.fusion.MeshAggregator(P, C, kind, 0.5), sm.fusion.MeshAggregator(P, C, kind, 0.5)
+    probs = [random_probs(rng, *cam.resolution, C, 0.03) for cam in cams[:4]]
+    if kind == "mul":
+        probs = [np.maximum(p, 1e-3).astype(np.float32) for p in probs]
+    probs = probs + probs[:3] + probs
+    weights = [rng.random(cam.resolution, dtype=np.float32) for cam in cams]
+    dp, dw = [to_device(p) for p in probs[:4]], [to_device(w) for w in weights]
+    dp = dp + dp[:3] + dp
+    batch.fuse_views(r, cams, dp, dw)
+    oracle.set_accum_double(kind == "mul")
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, 0.5)
+        oidx = [o.render(cam)[0] for cam in cams[:4]]
+        oidx = oidx + oidx[:3] + oidx
+        for k, cam in enumerate(cams):
+            single.fuse_view(r, cam, dp[k], dw[k])
+            oagg.add(oidx[k], probs[k], weights[k])
+        want = oagg.get()
+        oraw = None if kind == "mul" else oagg.get_raw()
+    finally:
+        oracle.set_accum_double(False)
+    if os.environ.get("SMESH_FUSE") != "strip" and os.environ.get("SMESH_FUSE_WIDE") != "0":
+        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri_wide"
+        if kind != "mul":      # (Mul: the hi plane is re-centred once per launch, so the grouping shows in the last bits)
+            np.testing.assert_array_equal(batch.get_raw().view(np.uint32), single.get_raw().view(np.uint32))
+            np.testing.assert_array_equal(batch.get_raw().view(np.uint32), oraw.view(np.uint32))
+    assert_fused_close(batch.get(), want, rtol=1e-3 if kind == "mul" else 1e-5)
+    if kind == "mul":
+        assert_fused_close(batch.get(), single.get(), rtol=1e-3)
+
+
+def test_fuse_views_wide_rows_mixed_triangle_sizes(sm, oracle):
+    """C = 150 with triangles that are small in some views of a launch and big (box over 8 x 8) in others, one huge triangle, views of
+    different resolutions, a re-ordered mesh: rows of triangles that are big anywhere go to one wave of k_fuse_big_any for all views."""
+    from semantic_meshes_amd import synth
+    from semantic_meshes_amd.device import to_device
+    mesh = synth.grid_mesh(60, 30)
+    extra_v = np.array([[-6, -4, -0.5], [6, -4, -0.5], [0, 5, -0.5]], np.float32)
+    verts = np.concatenate([mesh.vertices, extra_v])
+    faces = np.concatenate([mesh.faces, [[len(mesh.vertices), len(mesh.vertices) + 1, len(mesh.vertices) + 2]]]).astype(np.int32)
+    rng = np.random.default_rng(17)
+    for shuffled in (False, True):
+        if shuffled:
+            faces = np.ascontiguousarray(faces[rng.permutation(len(faces))])
+        P, C = len(faces), 150
+        cams = [synth.ring_camera(k, 7, w, h) for k, (w, h) in enumerate([(400, 300), (200, 150), (640, 480), (400, 300), (200, 150),
+                                                                            (400, 300), (320, 240)])]
+        r = sm.render.triangles(sm.data.Mesh(verts, faces))
+        o = oracle.OracleRenderer(verts, faces)
+        for kind in ("sum", "summax"):
+            agg = sm.fusion.MeshAggregator(P, C, kind)
+            probs = [random_probs(rng, *cam.resolution, C, 0.03) for cam in cams]
+            weights = [rng.random(cam.resolution, dtype=np.float32) for cam in cams]
+            agg.fuse_views(r, cams, [to_device(p) for p in probs], [to_device(w) for w in weights])
+            oracle.set_accum_double(True)
+            try:
+                oagg = oracle.OracleAggregator(P, C, kind)
+                for k, cam in enumerate(cams):
+                    oagg.add(o.render(cam)[0], probs[k], weights[k])
+                assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+            finally:
+                oracle.set_accum_double(False)
+
+
 @pytest.mark.parametrize("kind", ["sum", "summax"])
 def test_fuse_views_mixed_triangle_sizes_and_image_sizes(sm, oracle, kind):
     """Pairs in which a triangle is small in one view and big (bounding box over 8 x 8) in the other, plus one huge
@@ -1095,7 +1173,7 @@ def test_fuse_views_shuffled_faces_and_fallbacks(sm, oracle):
     r = sm.render.triangles(mesh)
     o = oracle.OracleRenderer(base.vertices, faces)
     oidx = [o.render(cam)[0] for cam in cams]
-    for C, on_device in ((19, True), (19, False), (64, True)):
+    for C, on_device in ((19, True), (19, False), (64, True), (150, True)):
         agg, oagg = sm.fusion.MeshAggregator(P, C, "sum", 0.5), oracle.OracleAggregator(P, C, "sum", 0.5)
         probs = [random_probs(rng, *cam.resolution, C) for cam in cams]
         agg.fuse_views(r, cams, [to_device(p) for p in probs] if on_device else probs)
