@@ -1297,6 +1297,92 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel(TriFuseArgs a) {
   if (threadIdx.x < items) fuse_texel_pixel<KIND>(a, C, (uint64_t)s_pix[threadIdx.x], s_tex[threadIdx.x], 1u);
 }
 
+// Up to eight views of a texel renderer in one launch (smesh_fuse_views).  The workgroup first compacts, in order, the triangles
+// that emitted fragments in ANY of the views (one in eight per view at cfg4); then every lane takes one of them through all the
+// views: view by view, its visible pixels in image order, the accumulator row of the current texel kept in registers for as long
+// as consecutive pixels -- of the same view or the next -- carry the same texel.  A triangle seen in several views (most are:
+// the cameras of a group look at the same surface) then reads and writes its 160-byte rows once instead of once per view,
+// which is half of what a cfg4 view moves.  Per row the additions happen in the order of one launch per view: view order,
+// then image order.  Triangles with a box over 8 x 8 in a view: k_fuse_texel_big of that view, launched afterwards.
+template <int KIND>
+__global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a, TriViews<8> vw, int nv) {
+  __shared__ TriView s_view[8];
+  __shared__ uint32_t s_tri[kTexelBlock];
+  __shared__ uint32_t s_wave_count[kTexelBlock / kWave];
+  const uint32_t C = a.C;
+  const int t = threadIdx.x, l = t & (kWave - 1), wv = t / kWave;
+  const uint64_t f = (uint64_t)blockIdx.x * kTexelBlock + t;
+  if (t == 0) {
+#pragma unroll
+    for (int v = 0; v < 8; v++) s_view[v] = vw.v[v];
+  }
+  __syncthreads();
+  bool seen = false;
+  if (f < a.F)
+    for (int v = 0; v < nv; v++) seen = seen || s_view[v].frags[f].kind == 1;
+  const unsigned long long ballot = __ballot(seen);
+  if (l == 0) s_wave_count[wv] = (uint32_t)__popcll(ballot);
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < kTexelBlock / kWave; w++) {
+    const uint32_t c = s_wave_count[w];
+    if (w < wv) base += c;
+    total += c;
+  }
+  if (seen) s_tri[base + (uint32_t)__popcll(ballot & ((1ull << l) - 1ull))] = (uint32_t)f;
+  __syncthreads();
+  if ((uint32_t)t >= total) return;
+  const uint32_t g = s_tri[t];
+  const uint32_t first = a.tex_first[g], res = a.tex_res[g], cnt = res * (res + 1u) / 2u;
+  float accr[kSlice];
+  uint32_t cur = 0xFFFFFFFFu;   // texel whose row is in accr
+  bool dirty = false;
+  for (int v = 0; v < nv; v++) {
+    const TriFrag rec = s_view[v].frags[g];
+    if (rec.kind != 1) continue;
+    const uint32_t* __restrict__ idx = s_view[v].idx;
+    const float* __restrict__ probs = s_view[v].probs;
+    const float* __restrict__ weights = s_view[v].weights;
+    const uint32_t Hv = s_view[v].H;
+    auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * Hv + rec.y0 + (k & 7); };
+    // which emitted fragments won the depth test (the pixel then holds one of this triangle's texels)
+    unsigned long long win = 0ull;
+    for (unsigned long long m = rec.mask; m; m &= m - 1ull) {
+      const int k = __ffsll((long long)m) - 1;
+      if (idx[pixel(k)] - first < cnt) win |= 1ull << k;
+    }
+    for (unsigned long long m = win; m; m &= m - 1ull) {
+      const uint64_t pix = pixel(__ffsll((long long)m) - 1);
+      const uint32_t tex = idx[pix];
+      uint32_t n = 0;                                   // Mesh.h:90-93 restricted to this triangle's pixels
+      for (unsigned long long m2 = win; m2; m2 &= m2 - 1ull) n += idx[pixel(__ffsll((long long)m2) - 1)] == tex ? 1u : 0u;
+      if (tex != cur) {
+        if (dirty) store_slice(a.acc + (uint64_t)cur * C, (int)C, accr);
+        load_slice(a.acc + (uint64_t)tex * C, (int)C, accr);
+        cur = tex;
+        dirty = false;
+      }
+      float p[kSlice];
+      load_slice(probs + pix * C, (int)C, p);
+      const float wt = weights ? weights[pix] : 1.0f;
+      float sum = 0.0f, best = p[0];
+      int am = 0;
+#pragma unroll
+      for (int j = 0; j < kSlice; j++)
+        if (j < (int)C) {
+          sum = sum + p[j];
+          if (KIND == SMESH_AGG_SUMMAX && p[j] > best) { best = p[j]; am = j; }
+        }
+      if (!(sum > 0.5f)) continue;                        // Mesh.h:98
+      const float w = (a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f) * wt;   // :100-103
+      accumulate_slice<KIND>(accr, p, (int)C, w, am);
+      dirty = true;
+    }
+  }
+  if (dirty) store_slice(a.acc + (uint64_t)cur * C, (int)C, accr);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Fallback for class counts whose strip does not fit LDS: per-pixel weights, then a flat scatter.
 // ------------------------------------------------------------------------------------------------
@@ -1879,6 +1965,51 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
         hipLaunchKernelGGL((k_fuse_texel<SMESH_AGG_MUL>), tgrid, tblock, 0, st, t);
         hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_MUL>), bgrid, block, 0, st, t);
         break;
+    }
+  }
+  SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
+}
+
+// The same for up to eight views of the renderer in one launch (k_fuse_texel_multi), the big triangles of each view in a launch of
+// their own behind it (their scratch histogram serves one view at a time).
+int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const uint32_t* tex_first, const uint32_t* tex_res, uint32_t big_capacity,
+                                       const RenderedView* views, int nviews) {
+  DeviceCtx* ctx = a->ctx;
+  hipStream_t st = ctx->stream;
+  if (F == 0 || nviews <= 0) return SMESH_OK;
+  if (nviews > 8) return fail(SMESH_ERR_INVALID, "fuse_texels_multi: at most eight views per launch");
+  TriViews<8> tv;
+  for (int v = 0; v < 8; v++) {
+    const RenderedView& rv = views[v < nviews ? v : 0];
+    tv.v[v] = TriView{rv.frags, rv.idx, rv.probs, rv.weights, rv.big_queue, rv.big_len, (uint32_t)rv.W, (uint32_t)rv.H};
+  }
+  TriFuseArgs t;
+  t.frags = views[0].frags; t.idx = views[0].idx; t.probs = views[0].probs; t.weights = views[0].weights;
+  t.acc = a->acc; t.acc_lo = a->acc_lo; t.F = F; t.C = a->C; t.W = (uint32_t)views[0].W; t.H = (uint32_t)views[0].H; t.iew = a->iew;
+  t.big_queue = views[0].big_queue; t.big_len = views[0].big_len; t.big_capacity = big_capacity;
+  t.tri_blocks = (uint32_t)div_up(F, kWave);
+  t.dbg = 0; t.prim_id = nullptr;
+  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count;
+  const dim3 tgrid((uint32_t)div_up(F, kTexelBlock)), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave), tblock(kTexelBlock);
+  SMESH_TRY(mul_recentre(a));
+  {
+    ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
+    prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, (uint64_t)nviews);
+    switch (a->kind) {
+      case SMESH_AGG_SUM:    hipLaunchKernelGGL((k_fuse_texel_multi<SMESH_AGG_SUM>), tgrid, tblock, 0, st, t, tv, nviews); break;
+      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL((k_fuse_texel_multi<SMESH_AGG_SUMMAX>), tgrid, tblock, 0, st, t, tv, nviews); break;
+      default:               hipLaunchKernelGGL((k_fuse_texel_multi<SMESH_AGG_MUL>), tgrid, tblock, 0, st, t, tv, nviews); break;
+    }
+    for (int v = 0; v < nviews; v++) {
+      TriFuseArgs x = t;
+      x.frags = views[v].frags; x.idx = views[v].idx; x.probs = views[v].probs; x.weights = views[v].weights;
+      x.W = (uint32_t)views[v].W; x.H = (uint32_t)views[v].H; x.big_queue = views[v].big_queue; x.big_len = views[v].big_len;
+      switch (a->kind) {
+        case SMESH_AGG_SUM:    hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_SUM>), bgrid, block, 0, st, x); break;
+        case SMESH_AGG_SUMMAX: hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_SUMMAX>), bgrid, block, 0, st, x); break;
+        default:               hipLaunchKernelGGL((k_fuse_texel_big<SMESH_AGG_MUL>), bgrid, block, 0, st, x); break;
+      }
     }
   }
   SMESH_HIP(hipGetLastError());

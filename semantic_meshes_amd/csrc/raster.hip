@@ -47,6 +47,8 @@ bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P);
 int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
                                  const uint32_t* tex_res, const uint32_t* big_queue, const uint32_t* big_len,
                                  uint32_t big_capacity, const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t H);
+int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const uint32_t* tex_first, const uint32_t* tex_res, uint32_t big_capacity,
+                                       const RenderedView* views, int nviews);
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a);
 uint32_t smesh_aggregator_classes(smesh_aggregator* a);
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a);
@@ -1662,7 +1664,23 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
         SMESH_TRY(render_into(r, &cams[i + v], static_cast<uint32_t*>(r->fused[v].ptr), /*d_depth=*/nullptr, ctx->stream, v));
       }
     }
-    for (int j = 0; j < gn && !pairable; j++) {   // texel renderers, class counts beyond k_fuse_tri, foreign primitive counts
+    // texel renderers: the views of the group in ONE fusion launch (a triangle's texel rows make one round trip for all of them)
+    static const bool texel_multi_off = getenv("SMESH_TEXEL_MULTI") && atoi(getenv("SMESH_TEXEL_MULTI")) == 0;
+    bool texel_multi = false;
+    if (grouped && !pairable && r->texels && !texel_multi_off) texel_multi = smesh_aggregator_can_fuse_texels(a, r->num_primitives);
+    if (texel_multi) {
+      ProfScope fuse_region(ctx, SMESH_PROF_FUSE_SCATTER);
+      RenderedView rv[kMaxGroup];
+      for (int j = 0; j < gn; j++) {
+        const smesh_renderer::Side& sd = r->side[base + j];
+        const uint64_t k = i + (uint64_t)j;
+        rv[j] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[base + j].ptr), probs[k],
+                             weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
+      }
+      SMESH_TRY(smesh_aggregator_fuse_texels_multi(a, r->F, r->tex_first, r->tex_res, r->big_capacity, rv, gn));
+      g_last_fuse_kernel = "k_fuse_texel";
+    }
+    for (int j = 0; j < gn && !pairable && !texel_multi; j++) {   // class counts beyond k_fuse_tri, foreign primitive counts
       const uint64_t k = i + (uint64_t)j;
       SMESH_TRY(fuse_rendered(r, a, base + j, static_cast<const uint32_t*>(r->fused[base + j].ptr), probs[k], weights ? weights[k] : nullptr,
                               SMESH_MEM_DEVICE, cams[k].width, cams[k].height));

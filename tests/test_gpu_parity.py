@@ -536,7 +536,7 @@ def test_render_fragment_queue_overflow(sm, oracle, monkeypatch, cap):
 
 
 @pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE_PIPELINE=1", "SMESH_FUSE=strip", "SMESH_FUSE_WIDE=0",
-                                  "SMESH_RASTER_PAIRS=0", "SMESH_FUSE_PAIRS=0", "SMESH_GROUP_PIPELINE=1"])
+                                  "SMESH_RASTER_PAIRS=0", "SMESH_FUSE_PAIRS=0", "SMESH_GROUP_PIPELINE=1", "SMESH_TEXEL_MULTI=0"])
 def test_alternative_paths_in_subprocess(knob):
     """These knobs are read once per process: re-run the render / fuse_view parity tests with the direct rasteriser
     (global 64-bit atomicMin per fragment), with the two-stream raster/fusion pipeline, and with the generic
@@ -552,7 +552,7 @@ def test_alternative_paths_in_subprocess(knob):
         sel += " or triangle_order"
     if k in ("SMESH_RASTER", "SMESH_RASTER_PAIRS", "SMESH_FUSE_PAIRS", "SMESH_FUSE"):
         sel = "fuse_views" if k.endswith("PAIRS") else sel + " or fuse_views"
-    if k == "SMESH_GROUP_PIPELINE":
+    if k in ("SMESH_GROUP_PIPELINE", "SMESH_TEXEL_MULTI"):
         sel = "fuse_views"
     res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_parity.py"), "-q", "-x", "-m", "gpu",
                           "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
@@ -1094,6 +1094,75 @@ def test_fuse_views_wide_rows_equal_single_calls_bit_for_bit(sm, oracle, kind, C
     assert_fused_close(batch.get(), want, rtol=1e-3 if kind == "mul" else 1e-5)
     if kind == "mul":
         assert_fused_close(batch.get(), single.get(), rtol=1e-3)
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C,tpp", [(4, 1.5), (19, 2.2), (40, 0.8)])
+def test_fuse_views_texels_equal_single_calls_bit_for_bit(sm, oracle, kind, C, tpp):
+    """Texel renderers through fuse_views: the views of a group in ONE launch of k_fuse_texel_multi, a triangle's texel rows kept in
+    registers across its pixels and views -- per row the additions of one call per view, in their order: raw accumulators bit-equal
+    to the per-view path and (Sum / Summax) to the float32 oracle.  Eleven views: groups of 8 and 3; texel resolutions 1 .. 3."""
+    import os
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(160, 80, 330, 250, views=4)       # ~2 px triangles: every box <= 8 x 8 (no atomics anywhere), a few texels each
+    r = sm.render.texels(mesh, cams, tpp)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces, cams, tpp)
+    cams = cams + cams[:3] + cams
+    P = r.getPrimitivesNum()
+    assert P == o.getPrimitivesNum() and P > len(mesh.faces)
+    rng = np.random.default_rng(300 + C)
+    batch, single = sm.fusion.MeshAggregator(P, C, kind, 0.5), sm.fusion.MeshAggregator(P, C, kind, 0.5)
+    probs = [random_probs(rng, *cam.resolution, C) for cam in cams[:4]]
+    if kind == "mul":
+        probs = [np.maximum(p, 1e-3).astype(np.float32) for p in probs]
+    probs = probs + probs[:3] + probs
+    weights = [rng.random(cam.resolution, dtype=np.float32) for cam in cams]
+    dp, dw = [to_device(p) for p in probs[:4]], [to_device(w) for w in weights]
+    dp = dp + dp[:3] + dp
+    batch.fuse_views(r, cams, dp, dw)
+    assert sm._lib.lib().smesh_last_fuse_kernel().decode() in ("k_fuse_texel", "k_scatter_strip")
+    oracle.set_accum_double(kind == "mul")
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, 0.5)
+        oidx = [o.render(cam)[0] for cam in cams[:4]]
+        oidx = oidx + oidx[:3] + oidx
+        for k, cam in enumerate(cams):
+            single.fuse_view(r, cam, dp[k], dw[k])
+            oagg.add(oidx[k], probs[k], weights[k])
+        want = oagg.get()
+        oraw = None if kind == "mul" else oagg.get_raw()
+    finally:
+        oracle.set_accum_double(False)
+    if os.environ.get("SMESH_FUSE") != "strip" and kind != "mul":
+        np.testing.assert_array_equal(batch.get_raw().view(np.uint32), single.get_raw().view(np.uint32))
+        np.testing.assert_array_equal(batch.get_raw().view(np.uint32), oraw.view(np.uint32))
+    assert_fused_close(batch.get(), want, rtol=1e-3 if kind == "mul" else 1e-5)
+    assert_fused_close(batch.get(), single.get(), rtol=1e-3 if kind == "mul" else 1e-5)
+
+
+def test_fuse_views_texels_with_big_triangles(sm, oracle):
+    """Texel renderer, a group whose views see the same triangles small in one view and with a box over 8 x 8 in another: the small
+    records go through k_fuse_texel_multi, the big ones through each view's k_fuse_texel_big behind it."""
+    from semantic_meshes_amd import synth
+    from semantic_meshes_amd.device import to_device
+    mesh = synth.grid_mesh(40, 20)
+    cams = [synth.ring_camera(k, 5, w, h) for k, (w, h) in enumerate([(400, 300), (160, 120), (640, 480), (400, 300), (160, 120)])]
+    r = sm.render.texels(mesh, cams, 0.3)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces, cams, 0.3)
+    P, C = r.getPrimitivesNum(), 19
+    rng = np.random.default_rng(23)
+    for kind in ("sum", "summax"):
+        agg = sm.fusion.MeshAggregator(P, C, kind)
+        probs = [random_probs(rng, *cam.resolution, C) for cam in cams]
+        agg.fuse_views(r, cams, [to_device(p) for p in probs])
+        oracle.set_accum_double(True)
+        try:
+            oagg = oracle.OracleAggregator(P, C, kind)
+            for k, cam in enumerate(cams):
+                oagg.add(o.render(cam)[0], probs[k])
+            assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        finally:
+            oracle.set_accum_double(False)
 
 
 def test_fuse_views_wide_rows_mixed_triangle_sizes(sm, oracle):
