@@ -313,7 +313,7 @@ def main():
         # rule, smesh_fuse_views); cross-checked against the library's own counters
         mix = {}
         if B > 1 and prof_mask:
-            cap = 8 if (C <= 40 or 128 <= C <= 1024) else (2 if C <= 48 else 1)     # smesh_aggregator_max_fused_views
+            cap = 2 if 40 < C <= 48 else 8     # smesh_aggregator_max_fused_views
             cap = min(cap, int(os.environ.get("SMESH_FUSE_VIEWS", "8")))
             for call, i in enumerate(range(args.warmup, total_views, B)):
                 if call % prof_every:

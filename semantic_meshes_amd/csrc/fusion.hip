@@ -833,88 +833,131 @@ __global__ __launch_bounds__(kWave) void k_fuse_big_any(TriFuseArgs a, TriViews<
   fuse_big_triangles_any<KIND>(a, vw, nv, blockIdx.x, gridDim.x, pw, amax, scratch_stride);
 }
 
+// Per-view state of the wave's lanes, parked in LDS so that the view loop of the multi-view kernels is a run-time loop over
+// LDS reads instead of eight copies of the code (k_fuse_tri_any: every lane reads its own entries back; k_fuse_tri_wide: the
+// owner lane's entries are broadcast).
+struct ViewState {
+  TriView view[8];
+  uint32_t org[8][kWave], lo[8][kWave], hi[8][kWave];
+};
+
+// Up to eight views per launch (`nv`, a run-time count), in order: the row slices stay in registers from the first view's first
+// pixel to the last view's last, one load and one store of the row for all of them -- the additions are those of one launch per
+// view, in their order.  A triangle that is big in any of the views belongs to k_fuse_big_any for all of them.
 template <int KIND, int G>
-__global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a) {
+__global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, TriViews<8> vw, int nv) {
   constexpr int TPW = kWave / G;   // triangles per wave
+  __shared__ ViewState S;
   const int l = threadIdx.x;
   const uint32_t C = a.C;
   const int g = l % G;                                   // rank inside the group
   const uint64_t fi = (uint64_t)blockIdx.x * TPW + (uint32_t)(l / G);   // position in the renderer's triangle order
   const uint64_t f = (a.prim_id && fi < a.F) ? (uint64_t)a.prim_id[fi] : fi;   // primitive id (index image value, accumulator row)
-  const uint32_t S = G == 1 ? C : (((C + G - 1) / G + 3u) & ~3u);   // classes per lane (whole float4s when the row is split)
-  const uint32_t c_lo = (uint32_t)g * S;
-  const int cw = c_lo < C ? (int)min(S, C - c_lo) : 0;
-  TriFrag rec;
-  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
-  if (fi < a.F) rec = a.frags[fi];
-  auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * a.H + rec.y0 + (k & 7); };
-  // pass 1 (as k_fuse_tri; the lanes of a group do it redundantly -- same addresses, one request)
-  unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
-  unsigned long long win = 0ull;
-  uint32_t n = 0;
-  if (!a.prim_id && a.big_len[1] == 0u) { win = m; n = (uint32_t)__popcll(m); m = 0ull; }   // the tile resolve has cleared the losers (k_fuse_tri)
-  while (__ballot(m != 0ull) != 0ull) {
-    int k[4];
-    uint32_t got[4];
+  const uint32_t SL = G == 1 ? C : (((C + G - 1) / G + 3u) & ~3u);   // classes per lane (whole float4s when the row is split)
+  const uint32_t c_lo = (uint32_t)g * SL;
+  const int cw = c_lo < C ? (int)min(SL, C - c_lo) : 0;
+  // pass 1 per view (as k_fuse_tri; the lanes of a group do it redundantly -- same addresses, one request)
+  unsigned long long win[8];
+  bool big = false;
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      k[j] = -1;
-      if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
-      got[j] = a.idx[k[j] >= 0 ? pixel(k[j]) : 0];
+  for (int v = 0; v < 8; v++) {
+    if (l == 0) S.view[v] = vw.v[v];
+    win[v] = 0ull;
+    uint32_t origin = 0u;
+    if (v < nv) {
+      TriFrag rec;
+      rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
+      if (fi < a.F) rec = vw.v[v].frags[fi];
+      origin = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
+      big = big || rec.kind == 2;
+      unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
+      if (!a.prim_id && vw.v[v].big_len[1] == 0u) { win[v] = m; m = 0ull; }   // the tile resolve has cleared the losers (k_fuse_tri)
+      const uint32_t* __restrict__ idx = vw.v[v].idx;
+      const uint32_t Hv = vw.v[v].H;
+      while (__ballot(m != 0ull) != 0ull) {
+        int k[4];
+        uint32_t got[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          k[j] = -1;
+          if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
+          got[j] = idx[k[j] >= 0 ? (uint64_t)(rec.x0 + (k[j] >> 3)) * Hv + rec.y0 + (k[j] & 7) : 0];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (k[j] >= 0 && got[j] == (uint32_t)f) win[v] |= 1ull << k[j];
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      if (k[j] >= 0 && got[j] == (uint32_t)f) { n++; win |= 1ull << k[j]; }
+    S.org[v][l] = origin;
   }
-  if (__ballot(win != 0ull) == 0ull) return;
-  const float w0 = n ? a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f : 0.0f;      // Mesh.h:100-102
+  unsigned long long any_win = 0ull;
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    if (big) win[v] = 0ull;
+    any_win |= win[v];
+    S.lo[v][l] = (uint32_t)win[v];
+    S.hi[v][l] = (uint32_t)(win[v] >> 32);
+  }
+  if (__ballot(any_win != 0ull) == 0ull) return;
+  wave_sync();
   float* __restrict__ row = a.acc + f * C + c_lo;
   float accr[kSliceAny];
-  if (win) load_slice(row, cw, accr);
+  if (any_win) load_slice(row, cw, accr);
   else {
 #pragma unroll
     for (int j = 0; j < kSliceAny; j++) accr[j] = 0.0f;
   }
-  for (m = win; __ballot(m != 0ull) != 0ull; m &= m - 1ull) {   // wave-uniform trip count: shuffles inside
-    const bool have = m != 0ull;
-    const uint64_t pix = have ? pixel(__ffsll((long long)m) - 1) : 0;
-    float p[kSliceAny];
-    load_slice(a.probs + pix * C + c_lo, have ? cw : 0, p);
-    const float wt = (have && a.weights) ? a.weights[pix] : 1.0f;
-    // row sum (and arg-max) in class order: the running values travel through the group's lanes
-    float s = 0.0f, best = 0.0f;
-    uint32_t am = 0;
+  for (int v = 0; v < nv; v++) {
+    const unsigned long long wv = (unsigned long long)S.lo[v][l] | ((unsigned long long)S.hi[v][l] << 32);
+    if (__ballot(wv != 0ull) == 0ull) continue;   // (wave-uniform)
+    const uint32_t org = S.org[v][l];
+    const float* __restrict__ probs = S.view[v].probs;
+    const float* __restrict__ weights = S.view[v].weights;
+    const uint32_t Hv = S.view[v].H;
+    const uint32_t n = (uint32_t)__popcll(wv);
+    const float w0 = n ? a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f : 0.0f;      // Mesh.h:100-102
+    for (unsigned long long m = wv; __ballot(m != 0ull) != 0ull; m &= m - 1ull) {   // wave-uniform trip count: shuffles inside
+      const bool have = m != 0ull;
+      const int k = have ? __ffsll((long long)m) - 1 : 0;
+      const uint64_t pix = have ? (uint64_t)((org & 0xFFFFu) + (uint32_t)(k >> 3)) * Hv + (org >> 16) + (uint32_t)(k & 7) : 0;
+      float p[kSliceAny];
+      load_slice(probs + pix * C + c_lo, have ? cw : 0, p);
+      const float wt = (have && weights) ? weights[pix] : 1.0f;
+      // row sum (and arg-max) in class order: the running values travel through the group's lanes
+      float s = 0.0f, best = 0.0f;
+      uint32_t am = 0;
 #pragma unroll
-    for (int ph = 0; ph < G; ph++) {
-      if (ph > 0) {   // from the lane below (wave_shr:1)
-        const float s_in = dpp_f<kDppWaveShr1>(0.0f, s);
-        const float b_in = KIND == SMESH_AGG_SUMMAX ? dpp_f<kDppWaveShr1>(0.0f, best) : 0.0f;
-        const uint32_t a_in = KIND == SMESH_AGG_SUMMAX ? dpp_u<kDppWaveShr1>(0u, am) : 0u;
-        if (g == ph) { s = s_in; best = b_in; am = a_in; }
-      }
-      if (g == ph) {
+      for (int ph = 0; ph < G; ph++) {
+        if (ph > 0) {   // from the lane below (wave_shr:1)
+          const float s_in = dpp_f<kDppWaveShr1>(0.0f, s);
+          const float b_in = KIND == SMESH_AGG_SUMMAX ? dpp_f<kDppWaveShr1>(0.0f, best) : 0.0f;
+          const uint32_t a_in = KIND == SMESH_AGG_SUMMAX ? dpp_u<kDppWaveShr1>(0u, am) : 0u;
+          if (g == ph) { s = s_in; best = b_in; am = a_in; }
+        }
+        if (g == ph) {
 #pragma unroll
-        for (int j = 0; j < kSliceAny; j++)
-          if (j < cw) {
-            s = s + p[j];
-            if (KIND == SMESH_AGG_SUMMAX && ((ph == 0 && j == 0) || p[j] > best)) { best = p[j]; am = c_lo + (uint32_t)j; }
-          }
+          for (int j = 0; j < kSliceAny; j++)
+            if (j < cw) {
+              s = s + p[j];
+              if (KIND == SMESH_AGG_SUMMAX && ((ph == 0 && j == 0) || p[j] > best)) { best = p[j]; am = c_lo + (uint32_t)j; }
+            }
+        }
       }
+      if (G == 2) {          // the group's last lane holds the totals: quad_perm [1,1,3,3]
+        s = dpp_f<0xF5>(0.0f, s);
+        if (KIND == SMESH_AGG_SUMMAX) am = dpp_u<0xF5>(0u, am);
+      } else if (G == 4) {   // quad_perm [3,3,3,3]
+        s = dpp_f<0xFF>(0.0f, s);
+        if (KIND == SMESH_AGG_SUMMAX) am = dpp_u<0xFF>(0u, am);
+      } else if (G > 4) {
+        const int last = (l / G) * G + (G - 1);
+        s = __shfl(s, last);
+        if (KIND == SMESH_AGG_SUMMAX) am = (uint32_t)__shfl((int)am, last);
+      }
+      if (have && s > 0.5f) accumulate_slice<KIND>(accr, p, cw, w0 * wt, (int)am - (int)c_lo);
     }
-    if (G == 2) {          // the group's last lane holds the totals: quad_perm [1,1,3,3]
-      s = dpp_f<0xF5>(0.0f, s);
-      if (KIND == SMESH_AGG_SUMMAX) am = dpp_u<0xF5>(0u, am);
-    } else if (G == 4) {   // quad_perm [3,3,3,3]
-      s = dpp_f<0xFF>(0.0f, s);
-      if (KIND == SMESH_AGG_SUMMAX) am = dpp_u<0xFF>(0u, am);
-    } else if (G > 4) {
-      const int last = (l / G) * G + (G - 1);
-      s = __shfl(s, last);
-      if (KIND == SMESH_AGG_SUMMAX) am = (uint32_t)__shfl((int)am, last);
-    }
-    if (have && s > 0.5f) accumulate_slice<KIND>(accr, p, cw, w0 * wt, (int)am - (int)c_lo);
   }
-  if (win) store_slice(row, cw, accr);
+  if (any_win) store_slice(row, cw, accr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1027,15 +1070,10 @@ __device__ __forceinline__ void fuse_pixel_wide(fvec4 (&ac)[NCH], const fvec4 (&
 // per-view state of the wave's 64 triangles (box origin, mask of visible pixels) and the views' pointers are parked in LDS, so
 // that the view loop is a run-time loop over broadcast reads instead of eight copies of the code.  A triangle that is big in any
 // of the views belongs to k_fuse_big_any for all of them.
-struct WideViewState {
-  TriView view[8];
-  uint32_t org[8][kWave], lo[8][kWave], hi[8][kWave];
-};
-
 template <int KIND, int NCH>
 __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews<8> vw, int nv) {
   constexpr int B = NCH == 1 ? 4 : 2;      // visible triangles whose rows and next pixels are in flight together
-  __shared__ WideViewState S;
+  __shared__ ViewState S;
   const int l = threadIdx.x;
   const uint32_t C = a.C;
   const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
@@ -1814,7 +1852,7 @@ bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a) { return smesh_aggregat
 int smesh_aggregator_max_fused_views(smesh_aggregator* a) {
   static const int cap = getenv("SMESH_FUSE_VIEWS") ? std::max(1, atoi(getenv("SMESH_FUSE_VIEWS"))) : 8;
   int m = a->C <= 40u ? 8 : (a->C <= (uint32_t)kFuseTriMaxC ? 2 : 1);
-  if (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) m = 8;   // k_fuse_tri_wide: any count up to eight
+  if (a->C > (uint32_t)kFuseTriMaxC) m = 8;   // k_fuse_tri_any / k_fuse_tri_wide: any count up to eight
   return std::min(m, cap);
 }
 
@@ -1879,13 +1917,13 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, (uint64_t)nviews);
 #define SMESH_FA(K)                                                                            \
     switch (G) {                                                                               \
-      case 1:  hipLaunchKernelGGL((k_fuse_tri_any<K, 1>), tgrid, block, 0, st, t); break;  \
-      case 2:  hipLaunchKernelGGL((k_fuse_tri_any<K, 2>), tgrid, block, 0, st, t); break;  \
-      case 4:  hipLaunchKernelGGL((k_fuse_tri_any<K, 4>), tgrid, block, 0, st, t); break;  \
-      case 8:  hipLaunchKernelGGL((k_fuse_tri_any<K, 8>), tgrid, block, 0, st, t); break;  \
-      case 16: hipLaunchKernelGGL((k_fuse_tri_any<K, 16>), tgrid, block, 0, st, t); break; \
-      case 32: hipLaunchKernelGGL((k_fuse_tri_any<K, 32>), tgrid, block, 0, st, t); break; \
-      default: hipLaunchKernelGGL((k_fuse_tri_any<K, 64>), tgrid, block, 0, st, t); break; \
+      case 1:  hipLaunchKernelGGL((k_fuse_tri_any<K, 1>), tgrid, block, 0, st, t, tv, nviews); break;  \
+      case 2:  hipLaunchKernelGGL((k_fuse_tri_any<K, 2>), tgrid, block, 0, st, t, tv, nviews); break;  \
+      case 4:  hipLaunchKernelGGL((k_fuse_tri_any<K, 4>), tgrid, block, 0, st, t, tv, nviews); break;  \
+      case 8:  hipLaunchKernelGGL((k_fuse_tri_any<K, 8>), tgrid, block, 0, st, t, tv, nviews); break;  \
+      case 16: hipLaunchKernelGGL((k_fuse_tri_any<K, 16>), tgrid, block, 0, st, t, tv, nviews); break; \
+      case 32: hipLaunchKernelGGL((k_fuse_tri_any<K, 32>), tgrid, block, 0, st, t, tv, nviews); break; \
+      default: hipLaunchKernelGGL((k_fuse_tri_any<K, 64>), tgrid, block, 0, st, t, tv, nviews); break; \
     }
 #define SMESH_FW(K)                                                                            \
     switch (wide_chunks) {                                                                     \

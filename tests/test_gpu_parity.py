@@ -1060,11 +1060,12 @@ def test_fuse_views_pairs_equal_single_calls_bit_for_bit(sm, oracle, kind, C):
 
 
 @pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
-@pytest.mark.parametrize("C", [150, 300, 520])
+@pytest.mark.parametrize("C", [150, 300, 520, 64, 100])
 def test_fuse_views_wide_rows_equal_single_calls_bit_for_bit(sm, oracle, kind, C):
-    """Wide rows (k_fuse_tri_wide, one / two / four 16-byte pieces per lane): up to eight views per launch, a triangle's row making
-    one round trip for all of them -- the same float32 additions in the same order as one call per view, so the raw accumulators
-    agree bit for bit with each other and (Sum / Summax) with the float32 oracle.  Eleven views: launches of 8, 2 and 1."""
+    """Rows beyond k_fuse_tri -- k_fuse_tri_wide (one / two / four 16-byte pieces per lane) and k_fuse_tri_any (C = 64 / 100: a row over
+    two / four lanes): up to eight views per launch, a triangle's row making one round trip for all of them -- the same float32
+    additions in the same order as one call per view, so the raw accumulators agree bit for bit with each other and (Sum / Summax)
+    with the float32 oracle.  Eleven views: launches of 8, 2 and 1."""
     import os
     from semantic_meshes_amd.device import to_device
     mesh, cams = small_scene(80, 40, 200, 150, views=4)        # ~1.5 px triangles: all bounding boxes <= 8 x 8
@@ -1094,8 +1095,9 @@ def test_fuse_views_wide_rows_equal_single_calls_bit_for_bit(sm, oracle, kind, C
         oraw = None if kind == "mul" else oagg.get_raw()
     finally:
         oracle.set_accum_double(False)
-    if os.environ.get("SMESH_FUSE") != "strip" and os.environ.get("SMESH_FUSE_WIDE") != "0":
-        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri_wide"
+    if os.environ.get("SMESH_FUSE") != "strip":
+        wide = C >= 128 and os.environ.get("SMESH_FUSE_WIDE") != "0"
+        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == ("k_fuse_tri_wide" if wide else "k_fuse_tri_any")
         if kind != "mul":      # (Mul: the hi plane is re-centred once per launch, so the grouping shows in the last bits)
             np.testing.assert_array_equal(batch.get_raw().view(np.uint32), single.get_raw().view(np.uint32))
             np.testing.assert_array_equal(batch.get_raw().view(np.uint32), oraw.view(np.uint32))
@@ -1173,8 +1175,9 @@ def test_fuse_views_texels_with_big_triangles(sm, oracle):
             oracle.set_accum_double(False)
 
 
-def test_fuse_views_wide_rows_mixed_triangle_sizes(sm, oracle):
-    """C = 150 with triangles that are small in some views of a launch and big (box over 8 x 8) in others, one huge triangle, views of
+@pytest.mark.parametrize("C", [150, 70])
+def test_fuse_views_wide_rows_mixed_triangle_sizes(sm, oracle, C):
+    """C = 150 (k_fuse_tri_wide) / 70 (k_fuse_tri_any) with triangles that are small in some views of a launch and big (box over 8 x 8) in others, one huge triangle, views of
     different resolutions, a re-ordered mesh: rows of triangles that are big anywhere go to one wave of k_fuse_big_any for all views."""
     from semantic_meshes_amd import synth
     from semantic_meshes_amd.device import to_device
@@ -1186,7 +1189,7 @@ def test_fuse_views_wide_rows_mixed_triangle_sizes(sm, oracle):
     for shuffled in (False, True):
         if shuffled:
             faces = np.ascontiguousarray(faces[rng.permutation(len(faces))])
-        P, C = len(faces), 150
+        P = len(faces)
         cams = [synth.ring_camera(k, 7, w, h) for k, (w, h) in enumerate([(400, 300), (200, 150), (640, 480), (400, 300), (200, 150),
                                                                             (400, 300), (320, 240)])]
         r = sm.render.triangles(sm.data.Mesh(verts, faces))
