@@ -313,7 +313,7 @@ def main():
         # rule, smesh_fuse_views); cross-checked against the library's own counters
         mix = {}
         if B > 1 and prof_mask:
-            cap = 2 if 40 < C <= 48 else 8     # smesh_aggregator_max_fused_views
+            cap = 8     # smesh_aggregator_max_fused_views (Mul with 41 .. 48 classes: 2 -- not a bench workload)
             cap = min(cap, int(os.environ.get("SMESH_FUSE_VIEWS", "8")))
             for call, i in enumerate(range(args.warmup, total_views, B)):
                 if call % prof_every:

@@ -208,7 +208,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
 /* A batch of `n` views: smesh_fuse_view(r, a, &cameras[i], probs[i], weights ? weights[i] : NULL, memkind) for i = 0 .. n-1, in
  * that order (the loop of python/scripts/colorize_cityscapes_mesh.py:54-67 handed over whole).  `probs` / `weights` are arrays of n
  * image pointers (weights, or single entries of it, may be NULL).  With a triangle renderer and device-resident images, up to eight
- * views share each rasteriser launch and each fusion launch (eight, except two for class counts 41 .. 48): every accumulator row
+ * views share each rasteriser launch and each fusion launch (two for the Mul aggregator with 41 .. 48 classes): every accumulator row
  * makes ONE round trip for all of them, with the additions in the order of n separate calls. */
 int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cameras, uint64_t n,
                      const float* const* probs, const float* const* weights, int memkind);

@@ -1829,7 +1829,7 @@ bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F) {
 
 // Largest class count the LDS-block kernel k_fuse_tri takes (a 64-slot instance needs 292 VGPRs and is no faster than
 // k_fuse_tri_any: C = 64 0.311 vs 0.292 ms/view; 48 slots: C = 48 0.184 vs 0.252).
-constexpr uint32_t kFuseTriMaxC = 48;
+static const uint32_t kFuseTriMaxC = getenv("SMESH_FUSE_TRI_MAXC") ? (uint32_t)std::min(48, std::max(1, atoi(getenv("SMESH_FUSE_TRI_MAXC")))) : 48u;   // (experiment knob)
 
 // Which kernel smesh_aggregator_fuse_triangles dispatches for this aggregator (reporting only).
 static bool fuse_wide_enabled() {
@@ -1853,6 +1853,9 @@ int smesh_aggregator_max_fused_views(smesh_aggregator* a) {
   static const int cap = getenv("SMESH_FUSE_VIEWS") ? std::max(1, atoi(getenv("SMESH_FUSE_VIEWS"))) : 8;
   int m = a->C <= 40u ? 8 : (a->C <= (uint32_t)kFuseTriMaxC ? 2 : 1);
   if (a->C > (uint32_t)kFuseTriMaxC) m = 8;   // k_fuse_tri_any / k_fuse_tri_wide: any count up to eight
+  // 41 .. 48: four or eight views go through k_fuse_tri_any (0.124-0.133 vs 0.138-0.146 ms per view at cfg2's geometry), one or two
+  // through the 48-slot k_fuse_tri; not for Mul, whose (hi, lo) state only k_fuse_tri keeps
+  if (a->C > 40u && a->C <= (uint32_t)kFuseTriMaxC && a->kind != SMESH_AGG_MUL) m = 8;
   return std::min(m, cap);
 }
 
@@ -1885,7 +1888,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   // k_fuse_tri (row in registers; the wave's 64-row block staged through LDS unless the mesh was re-ordered) takes C <= 48: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 48 for the rest
   // (tri_ct 41 = the run-time instance with 40 slots).
   int tri_ct = 0;
-  if (a->C <= kFuseTriMaxC) {
+  if (a->C <= kFuseTriMaxC && !(a->C > 40u && nviews > 2)) {
     if (a->C == 5 || a->C == 13 || a->C == 19 || a->C == 20 || a->C == 21 || a->C == 40) tri_ct = (int)a->C;   // common label sets
     else tri_ct = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : a->C <= 40 ? 41 : 48;
   }
