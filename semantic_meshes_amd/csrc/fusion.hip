@@ -752,6 +752,49 @@ __device__ __attribute__((noinline)) void fuse_box_any(const TriFuseArgs& a, con
     pw[pix] = sum > 0.5f ? w0 * (a.weights ? a.weights[pix] : 1.0f) : __uint_as_float(kSkipPixel);
     if (KIND == SMESH_AGG_SUMMAX) amax[pix] = am;
   }
+  if constexpr (KIND == SMESH_AGG_MUL) {
+    // Mul ("Mul state", fuse_tri.inc.hpp; as fuse_box does it for k_fuse_tri): the view's contributions are summed from zero in
+    // double and meet the (hi, lo) row, re-centred on its largest finite element, once -- in chunks of kMulSlice classes
+    constexpr int kMulSlice = 16;
+    float m = -INFINITY;
+    for (uint32_t c = (uint32_t)l; c < C; c += kWave) {
+      const float h = a.acc[(uint64_t)f * C + c];
+      if (h > m && h < INFINITY) m = h;
+    }
+    m = wave_max(m);
+    const float centre = m > -INFINITY ? m : 0.0f;
+    for (uint32_t c0 = 0; c0 < C; c0 += kMulSlice) {
+      const int cw = (int)min((uint32_t)kMulSlice, C - c0);
+      double part[kMulSlice];
+#pragma unroll
+      for (int j = 0; j < kMulSlice; j++) part[j] = 0.0;
+      for (long long i = l; i < npx; i += kWave) {
+        const int x = x0 + (int)(i / bh), y = y0 + (int)(i % bh);
+        const uint64_t pix = (uint64_t)x * a.H + y;
+        if (a.idx[pix] != f) continue;
+        const float w = pw[pix];
+        if (__float_as_uint(w) == kSkipPixel) continue;
+        float p[kMulSlice];
+        load_slice(a.probs + pix * C + c0, cw, p);
+#pragma unroll
+        for (int j = 0; j < kMulSlice; j++) if (j < cw) part[j] += (double)contribution<KIND>(p[j], w);
+      }
+      double mine = 0.0;
+#pragma unroll
+      for (int j = 0; j < kMulSlice; j++) {
+        const double v = wave_sum_d(part[j]);
+        if (l == j) mine = v;
+      }
+      if (l < cw) {   // this wave owns the row
+        const uint64_t at = (uint64_t)f * C + c0 + l;
+        float hi = a.acc[at], lo = a.acc_lo[at];
+        mul_fold(hi, lo, centre, mine);
+        a.acc[at] = hi;
+        a.acc_lo[at] = lo;
+      }
+    }
+    return;
+  }
   for (uint32_t c0 = 0; c0 < C; c0 += kSlice) {
     const int cw = (int)min((uint32_t)kSlice, C - c0);
     float part[kSlice];
@@ -916,6 +959,12 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, TriViews<
     const uint32_t Hv = S.view[v].H;
     const uint32_t n = (uint32_t)__popcll(wv);
     const float w0 = n ? a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f : 0.0f;      // Mesh.h:100-102
+    // Mul ("Mul state", fuse_tri.inc.hpp): the view's contributions are summed separately, from zero, and meet the re-centred
+    // (hi, lo) row once per view, in double -- as in k_fuse_tri
+    constexpr int PT = KIND == SMESH_AGG_MUL ? kSliceAny : 1;
+    double part[PT];
+#pragma unroll
+    for (int j = 0; j < PT; j++) part[j] = 0.0;
     for (unsigned long long m = wv; __ballot(m != 0ull) != 0ull; m &= m - 1ull) {   // wave-uniform trip count: shuffles inside
       const bool have = m != 0ull;
       const int k = have ? __ffsll((long long)m) - 1 : 0;
@@ -954,7 +1003,31 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, TriViews<
         s = __shfl(s, last);
         if (KIND == SMESH_AGG_SUMMAX) am = (uint32_t)__shfl((int)am, last);
       }
-      if (have && s > 0.5f) accumulate_slice<KIND>(accr, p, cw, w0 * wt, (int)am - (int)c_lo);
+      if (have && s > 0.5f) {
+        if constexpr (KIND == SMESH_AGG_MUL) {
+#pragma unroll
+          for (int j = 0; j < PT; j++) if (j < cw) part[j] += (double)contribution<KIND>(p[j], w0 * wt);
+        } else {
+          accumulate_slice<KIND>(accr, p, cw, w0 * wt, (int)am - (int)c_lo);
+        }
+      }
+    }
+    if constexpr (KIND == SMESH_AGG_MUL) {
+      // the row's largest finite element, over the G lanes that share it (every lane takes part in the shuffles)
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < kSliceAny; j++) if (j < cw && accr[j] > mx && accr[j] < INFINITY) mx = accr[j];
+#pragma unroll
+      for (int o = 1; o < G; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+      const float centre = mx > -INFINITY ? mx : 0.0f;
+      if (wv != 0ull) {
+        float* __restrict__ lo_row = a.acc_lo + f * C + c_lo;
+        float lo[kSliceAny];
+        load_slice(lo_row, cw, lo);
+#pragma unroll
+        for (int j = 0; j < kSliceAny; j++) if (j < cw) mul_fold(accr[j], lo[j], centre, part[j]);
+        store_slice(lo_row, cw, lo);
+      }
     }
   }
   if (any_win) store_slice(row, cw, accr);
@@ -997,8 +1070,10 @@ __device__ __forceinline__ void store_wide(float* __restrict__ dst, uint32_t C, 
 }
 
 // Mesh.h:94-106 for one pixel whose class vector is spread over the wave (wave-uniform control flow).
-template <int KIND, int NCH>
-__device__ __forceinline__ void fuse_pixel_wide(fvec4 (&ac)[NCH], const fvec4 (&p)[NCH], uint32_t C, int l, float w) {
+typedef double dvec4 __attribute__((ext_vector_type(4)));
+template <int KIND, int NCH, typename ACC4>   // ACC4: fvec4 (the accumulator row itself), or dvec4 (Mul: a view's partial sums)
+__device__ __forceinline__ void fuse_pixel_wide(ACC4 (&ac)[NCH], const fvec4 (&p)[NCH], uint32_t C, int l, float w) {
+  typedef decltype(ac[0].x + ac[0].x) acc_t;
   float ps = 0.0f, pa = 0.0f;
 #pragma unroll
   for (int k = 0; k < NCH; k++) {
@@ -1048,18 +1123,18 @@ __device__ __forceinline__ void fuse_pixel_wide(fvec4 (&ac)[NCH], const fvec4 (&
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
       const uint32_t c = 4u * ((uint32_t)l + 64u * k);
-      ac[k].x = (am == c) ? ac[k].x + p[k].x * w : ac[k].x;
-      ac[k].y = (am == c + 1) ? ac[k].y + p[k].y * w : ac[k].y;
-      ac[k].z = (am == c + 2) ? ac[k].z + p[k].z * w : ac[k].z;
-      ac[k].w = (am == c + 3) ? ac[k].w + p[k].w * w : ac[k].w;
+      ac[k].x = (am == c) ? ac[k].x + (acc_t)(p[k].x * w) : ac[k].x;
+      ac[k].y = (am == c + 1) ? ac[k].y + (acc_t)(p[k].y * w) : ac[k].y;
+      ac[k].z = (am == c + 2) ? ac[k].z + (acc_t)(p[k].z * w) : ac[k].z;
+      ac[k].w = (am == c + 3) ? ac[k].w + (acc_t)(p[k].w * w) : ac[k].w;
     }
   } else {
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
-      ac[k].x = ac[k].x + contribution<KIND>(p[k].x, w);
-      ac[k].y = ac[k].y + contribution<KIND>(p[k].y, w);
-      ac[k].z = ac[k].z + contribution<KIND>(p[k].z, w);
-      ac[k].w = ac[k].w + contribution<KIND>(p[k].w, w);
+      ac[k].x = ac[k].x + (acc_t)contribution<KIND>(p[k].x, w);
+      ac[k].y = ac[k].y + (acc_t)contribution<KIND>(p[k].y, w);
+      ac[k].z = ac[k].z + (acc_t)contribution<KIND>(p[k].z, w);
+      ac[k].w = ac[k].w + (acc_t)contribution<KIND>(p[k].w, w);
     }
   }
 }
@@ -1154,8 +1229,17 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
       uint32_t org[B];
       float w0[B];
       unsigned long long left = 0ull;
+      // Mul: the view's contributions are summed separately, from zero, and folded into the re-centred (hi, lo) row once per view
+      constexpr int PB = KIND == SMESH_AGG_MUL ? B : 1;
+      dvec4 part[PB][NCH];
+      bool touched[B];
+#pragma unroll
+      for (int b = 0; b < PB; b++)
+#pragma unroll
+        for (int k = 0; k < NCH; k++) part[b][k] = dvec4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int b = 0; b < B; b++) {
+        touched[b] = false;
         pm[b] = 0ull; org[b] = 0u; w0[b] = 0.0f;
         if (t[b] >= 0) {
           const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lo[v][t[b]]);
@@ -1164,6 +1248,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
           org[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.org[v][t[b]]);
           const uint32_t nt = (uint32_t)__popcll(pm[b]);                                    // this primitive's pixels in this view (Mesh.h:90-93)
           if (nt) w0[b] = a.iew * (1.0f / ((float)nt)) + (1 - a.iew) * 1.0f;               // Mesh.h:100-102
+          touched[b] = nt != 0u;
         }
         left |= pm[b];
       }
@@ -1185,8 +1270,41 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
         left = 0ull;
 #pragma unroll
         for (int b = 0; b < B; b++) {
-          if (have[b]) fuse_pixel_wide<KIND, NCH>(ac[b], p[b], C, l, w0[b] * wt[b]);     // :103
+          if (have[b]) {
+            if constexpr (KIND == SMESH_AGG_MUL) fuse_pixel_wide<KIND, NCH>(part[b], p[b], C, l, w0[b] * wt[b]);
+            else fuse_pixel_wide<KIND, NCH>(ac[b], p[b], C, l, w0[b] * wt[b]);     // :103
+          }
           left |= pm[b];
+        }
+      }
+      if constexpr (KIND == SMESH_AGG_MUL) {
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          if (!touched[b]) continue;   // (wave-uniform)
+          float mx = -INFINITY;
+#pragma unroll
+          for (int k = 0; k < NCH; k++) {
+            const uint32_t c = 4u * ((uint32_t)l + 64u * k);
+            const float e[4] = {ac[b][k].x, ac[b][k].y, ac[b][k].z, ac[b][k].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) if (c + q < C && e[q] > mx && e[q] < INFINITY) mx = e[q];
+          }
+          mx = wave_max(mx);
+          const float centre = mx > -INFINITY ? mx : 0.0f;
+          fvec4 lo[NCH];
+          float* __restrict__ lo_row = a.acc_lo + (uint64_t)rowid[b] * C;
+          load_wide<NCH>(lo_row, C, l, lo);
+#pragma unroll
+          for (int k = 0; k < NCH; k++) {
+            float h[4] = {ac[b][k].x, ac[b][k].y, ac[b][k].z, ac[b][k].w};
+            float r[4] = {lo[k].x, lo[k].y, lo[k].z, lo[k].w};
+            const double pt[4] = {part[b][k].x, part[b][k].y, part[b][k].z, part[b][k].w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) mul_fold(h[q], r[q], centre, pt[q]);
+            ac[b][k] = fvec4{h[0], h[1], h[2], h[3]};
+            lo[k] = fvec4{r[0], r[1], r[2], r[3]};
+          }
+          store_wide<NCH>(lo_row, C, l, lo);
         }
       }
     }
