@@ -247,6 +247,12 @@ int smesh_renderer_seal_render(smesh_renderer_t* r, const uint32_t* indices_dev)
  * gather-accumulate, no atomics; "k_fuse_tri_any": the same for any class count; "k_scatter_strip": generic segmented scatter-add).  For reporting. */
 const char* smesh_last_fuse_kernel(void);
 
+/* Where the last add / fuse call on this thread got its per-primitive pixel lists from: "render-records" (left by the rasteriser:
+ * smesh_fuse_view(s), smesh_aggregator_add_rendered / _add_matched), "image-records" (rebuilt from the index image itself:
+ * smesh_aggregator_add on any dense image -- Mesh.h:90-106 on an image from anywhere, e.g. eval_scannet.py:168-185's .npz cache),
+ * "scatter" (atomic scatter-add: what the triangle-order kernels do not take), "none".  For reporting. */
+const char* smesh_last_add_path(void);
+
 /* ---- timing hooks (tracing) -------------------------------------------- */
 /* `slot_mask` is a bitmask of SMESH_PROF_* slots (bit s = slot s; 0 = off, 0xFF = all).
  * For every enabled slot the library brackets the kernels with HIP events on its own stream.

@@ -665,6 +665,7 @@ int smesh_aggregator_add_matched(smesh_aggregator_t*, smesh_renderer_t*, const v
 }
 int smesh_renderer_seal_render(smesh_renderer_t*, const uint32_t*) { return SMESH_OK; }
 const char* smesh_last_fuse_kernel(void) { return "oracle"; }
+const char* smesh_last_add_path(void) { return "oracle"; }
 int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, const uint32_t* idx, const float* probs,
                                   const int64_t ps[3], int pmem, const float* weights, const int64_t ws[2], int wmem,
                                   uint64_t W, uint64_t H) {

@@ -80,6 +80,7 @@ SIGNATURES = {
                                              c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64, P(c_int)]),
     "smesh_renderer_seal_render": (c_int, [c_void_p, c_void_p]),
     "smesh_last_fuse_kernel": (ctypes.c_char_p, []),
+    "smesh_last_add_path": (ctypes.c_char_p, []),
     "smesh_profile_enable": (c_int, [c_int, c_int]),
     "smesh_profile_sample_every": (c_int, [c_int, ctypes.c_uint32]),
     "smesh_profile_read": (c_int, [c_int, c_int, P(ctypes.c_double), P(c_u64)]),

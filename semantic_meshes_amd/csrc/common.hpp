@@ -145,4 +145,22 @@ struct RenderedView {
   uint64_t W, H;
 };
 
+// Per-primitive records built from an arbitrary index image (image_records.hip): what lets MeshAggregator::add() run the
+// triangle-order fusion on images the library did not render.  Scratch of one aggregator, all zero between calls.
+struct ImageRecords {
+  TriFrag* frags = nullptr;        // [P] (start of the one allocation)
+  uint32_t* cand = nullptr;        // [P] ~(x << 16 | y) of the primitive's first pixel in (x, y) order; 0 = none
+  uint4* big4 = nullptr;           // [P] primitives with runs outside the 8 x 8 box: largest x + 1, largest y + 1, pixels in those
+                                   //     runs, 65536 - smallest y; zero otherwise
+  uint32_t* big_queue = nullptr;   // [P] those primitives
+  uint32_t* big_count = nullptr;   // [4] [0] queue length, [1] stays 0: the masks are exact, [2] nonzero: there are sparse primitives
+  uint64_t P = 0;
+  bool clean = false;
+  void release();
+};
+int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, uint64_t P);
+int image_records_scatter_sparse(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
+                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc);
+int image_records_clear(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H);
+
 }  // namespace smesh

@@ -1760,8 +1760,15 @@ struct smesh_aggregator {
   Scratch pw;                            // per-pixel weight image of the current view
   hipEvent_t ev_staged = nullptr;        // host inputs have been copied into the staging buffers
   Scratch out_tmp;                       // get(): normalised result before the D2H copy
+  ImageRecords rec;                      // add() on an image the library did not render: per-primitive records (image_records.hip)
   std::mutex mu;
 };
+
+bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
+const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
+int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
+                                    const RenderedView* views, int nviews);
+void smesh_note_fuse(const char* kernel, const char* path);   // raster.hip: what smesh_last_fuse_kernel / smesh_last_add_path report
 
 namespace {
 
@@ -1782,6 +1789,14 @@ int stage_in(DeviceCtx* ctx, Scratch& st, const void* host, size_t bytes, const 
 }
 
 size_t idx_itemsize(int dt) { return (dt == SMESH_IDX_U64 || dt == SMESH_IDX_I64) ? 8 : 4; }
+
+// Class count from which add() on a foreign image rebuilds per-primitive records and fuses in triangle order (image_records.hip):
+// building them costs a fixed ~3 integer atomics per run of pixels (~100 us per cfg2-sized image), the scatter-add float atomics
+// in proportion to the row width.  At cfg2's geometry, ms per view records / scatter: C = 19 0.149 / 0.122, 24 0.163 / 0.168,
+// 28 0.175 / 0.167, 32 0.196 / 0.391, 36 0.202 / 0.303, 48 0.230 / 0.498, 64 0.357 / 0.805, 150 0.780 / 1.511
+// (tools/generic_add_sweep.py); cfg5: 3.5 / 7.4.  Below the threshold the records path is still available (SMESH_ADD_RECORDS_MIN_C=0)
+// for callers who want the deterministic, reference-ordered sums more than the last 20 %.
+constexpr uint32_t kAddRecordsMinC = 32;
 
 // Core of add() once every buffer is in device memory.
 int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int64_t is[2],
@@ -1828,6 +1843,27 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
     SMESH_HIP(hipGetLastError());
     weights = static_cast<const float*>(a->nm_w.ptr);
   }
+
+  // ---- triangle-order fusion on records built from the image (image_records.hip) ------------------
+  // Every accumulator row gets one owner and the reference's order of additions: deterministic, Sum / Summax bit-equal to the
+  // single-threaded float32 reference loop, and faster than the atomic scatter-add below, which remains for what the triangle-order
+  // kernels do not take (padded rows, SMESH_FUSE=strip, SMESH_ADD_RECORDS=0).
+  static const bool records_off = getenv("SMESH_ADD_RECORDS") && atoi(getenv("SMESH_ADD_RECORDS")) == 0;
+  const char* min_c_env = getenv("SMESH_ADD_RECORDS_MIN_C");      // (read per call: tests and tools move the threshold at run time)
+  const uint32_t records_min_c = min_c_env ? (uint32_t)atoi(min_c_env) : kAddRecordsMinC;
+  if (!records_off && C >= records_min_c && a->P > 0 && W <= 65535 && H <= 65535 && smesh_aggregator_can_fuse_triangles(a, a->P)) {
+    {
+      ProfScope prof(ctx, SMESH_PROF_FUSE_HIST);
+      SMESH_TRY(image_records_build(ctx, a->rec, idx, W, H, a->P));
+    }
+    const RenderedView rv{a->rec.frags, a->rec.big_queue, a->rec.big_count, idx, probs, weights, W, H};
+    SMESH_TRY(smesh_aggregator_fuse_triangles(a, a->P, nullptr, (uint32_t)a->P, &rv, 1));
+    SMESH_TRY(image_records_scatter_sparse(ctx, a->rec, a->kind, idx, probs, weights, W, H, C, a->iew, a->acc));
+    SMESH_TRY(image_records_clear(ctx, a->rec, idx, W, H));
+    smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, false), "image-records");
+    return SMESH_OK;
+  }
+  smesh_note_fuse(strip_path(C) ? "k_scatter_strip" : "k_scatter_flat", "scatter");
 
   ScatterArgs args;
   args.idx = idx; args.probs = probs; args.weights = weights; args.pw = nullptr;
@@ -2231,6 +2267,7 @@ int smesh_aggregator_destroy(smesh_aggregator_t* a) {
   if (a->ev_staged) (void)hipEventDestroy(a->ev_staged);
   for (Scratch* s : {&a->st_idx, &a->st_probs, &a->st_w, &a->nm_idx, &a->nm_probs, &a->nm_w, &a->fb_w, &a->fb_amax, &a->pw, &a->out_tmp})
     s->release();
+  a->rec.release();
   delete a;
   return SMESH_OK;
 }

@@ -1260,6 +1260,8 @@ static bool spatial_order(const float* v, uint64_t V, const int32_t* f, uint64_t
 }
 
 static thread_local const char* g_last_fuse_kernel = "none";
+static thread_local const char* g_last_add_path = "none";   // "render-records" (the rasteriser's per-triangle records), or what add_device reports
+void smesh_note_fuse(const char* kernel, const char* path) { g_last_fuse_kernel = kernel; g_last_add_path = path; }
 
 // The fusion half of smesh_fuse_view / smesh_aggregator_add_rendered: `d_idx` is the index plane of the render
 // whose per-triangle records sit in r->side[slot].
@@ -1287,15 +1289,14 @@ static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const
     // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
     const RenderedView rv{r->side[slot].frags, r->side[slot].big_queue, r->side[slot].big_count, d_idx, d_probs, d_w, W, H};
     SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, &rv, 1));
-    g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
+    smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr), "render-records");
   } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
     // texel primitives: a triangle owns its texel rows, its lane read-modify-writes them without atomics
     SMESH_TRY(smesh_aggregator_fuse_texels(a, r->side[slot].frags, r->F, r->tex_first, r->tex_res, r->side[slot].big_queue,
                                            r->side[slot].big_count, r->big_capacity, d_idx, d_probs, d_w, H));
-    g_last_fuse_kernel = "k_fuse_texel";
+    smesh_note_fuse("k_fuse_texel", "render-records");
   } else {
-    g_last_fuse_kernel = "k_scatter_strip";
-    SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));
+    SMESH_TRY(smesh_aggregator_add_device_contig(a, d_idx, d_probs, d_w, W, H));   // (reports its path itself)
   }
   return SMESH_OK;
 }
@@ -1303,6 +1304,7 @@ static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const
 extern "C" {
 
 const char* smesh_last_fuse_kernel(void) { return g_last_fuse_kernel; }
+const char* smesh_last_add_path(void) { return g_last_add_path; }
 
 int smesh_renderer_create_triangles(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F, int device,
                                     smesh_renderer_t** out) {
@@ -1678,7 +1680,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
                              weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
       }
       SMESH_TRY(smesh_aggregator_fuse_texels_multi(a, r->F, r->tex_first, r->tex_res, r->big_capacity, rv, gn));
-      g_last_fuse_kernel = "k_fuse_texel";
+      smesh_note_fuse("k_fuse_texel", "render-records");
     }
     for (int j = 0; j < gn && !pairable && !texel_multi; j++) {   // class counts beyond k_fuse_tri, foreign primitive counts
       const uint64_t k = i + (uint64_t)j;
@@ -1705,7 +1707,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
         j += nv;
       }
     }
-    if (pairable) g_last_fuse_kernel = smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr);
+    if (pairable) smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr), "render-records");
     if (grouped && group_pipeline) SMESH_HIP(hipEventRecord(r->ev_bank_consumed[base / kMaxGroup], ctx->stream));
     r->fused_seq += (uint64_t)gn;
     i += (uint64_t)gn;
@@ -1745,7 +1747,6 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
     }
   }
   const int64_t is[2] = {(int64_t)H, 1};
-  g_last_fuse_kernel = "k_scatter_strip";
   return smesh_aggregator_add(a, idx_dev, SMESH_IDX_U32, is, SMESH_MEM_DEVICE, probs, probs_strides, probs_mem, weights, w_strides,
                               w_mem, W, H);
 }
@@ -1761,7 +1762,7 @@ int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
                                  const float* weights, const int64_t w_strides[2], int w_mem, uint64_t W, uint64_t H, int* matched) {
   if (!a || !r || !indices || !idx_strides || !probs || !probs_strides || !matched) return fail(SMESH_ERR_INVALID, "NULL argument");
   *matched = 0;
-  g_last_fuse_kernel = "k_scatter_strip";   // (reporting: unless a render matches below, the caller goes on to smesh_aggregator_add)
+  smesh_note_fuse("none", "none");   // (reporting: unless a render matches below, the caller goes on to smesh_aggregator_add, which reports itself)
   if (weights && !w_strides) return fail(SMESH_ERR_INVALID, "weights without strides");
   DeviceCtx* ctx = r->ctx;
   const int64_t C = (int64_t)smesh_aggregator_classes(a);

@@ -1,0 +1,230 @@
+"""MeshAggregator.add() on index images the library did not render (image_records.hip): the per-primitive records the
+triangle-order kernels need are rebuilt from the image alone -- the reference's add() takes any (W,H) index image
+(Mesh.h:65-107; eval_scannet.py:168-185 reloads its renders from an .npz cache), and so does this path, with every
+accumulator row owned by one lane and the additions in the reference's pixel order."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import BG, assert_fused_close, random_probs, small_scene
+
+pytestmark = pytest.mark.gpu
+
+STRIP = os.environ.get("SMESH_FUSE") == "strip" or os.environ.get("SMESH_ADD_RECORDS") == "0"
+
+
+@pytest.fixture(autouse=True)
+def records_for_every_class_count():
+    """add() rebuilds records from the image for class counts from 32 by default (below that the scatter-add is ~20 % faster);
+    here every class count takes them.  SMESH_ADD_RECORDS_MIN_C is read per call."""
+    old = os.environ.get("SMESH_ADD_RECORDS_MIN_C")
+    os.environ["SMESH_ADD_RECORDS_MIN_C"] = "0"
+    yield
+    if old is None:
+        os.environ.pop("SMESH_ADD_RECORDS_MIN_C", None)
+    else:
+        os.environ["SMESH_ADD_RECORDS_MIN_C"] = old
+
+
+def path(sm):
+    return sm._lib.lib().smesh_last_add_path().decode()
+
+
+def blob_image(rng, W, H, P, seeds, background=0.1):
+    """Nearest-seed regions (compact blobs of very different sizes: a few pixels to thousands), a share of background
+    pixels and a few out-of-range values (skipped by Mesh.h:95)."""
+    sx, sy = rng.integers(0, W, seeds), rng.integers(0, H, seeds)
+    prim = rng.permutation(P)[:seeds] if seeds <= P else rng.integers(0, P, seeds)
+    xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="ij")
+    d = (xs[..., None] - sx) ** 2 + (ys[..., None] - sy) ** 2
+    img = prim[d.argmin(-1)].astype(np.uint32)
+    img[rng.random((W, H)) < background] = BG
+    img[rng.random((W, H)) < 0.01] = np.uint32(P + 5)
+    return img
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax"])
+@pytest.mark.parametrize("C", [5, 19, 40, 33, 48, 64, 150])
+def test_add_foreign_image_small_primitives_bit_exact(sm, oracle, kind, C):
+    """Index images rendered elsewhere (here: by the oracle, handed over as numpy arrays) of a mesh whose triangles stay
+    inside 8 x 8 pixels: the raw accumulator equals the single-threaded float32 reference loop bit for bit -- the atomic
+    scatter-add could only promise 1e-5."""
+    mesh, cams = small_scene(120, 60, 320, 240, views=3)
+    P = len(mesh.faces)
+    rng = np.random.default_rng(1000 + C)
+    agg = sm.fusion.MeshAggregator(P, C, kind, 0.5)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    oagg = oracle.OracleAggregator(P, C, kind, 0.5)
+    for k, cam in enumerate(cams):
+        idx = o.render(cam)[0]
+        probs = random_probs(rng, *cam.resolution, C)
+        weights = rng.random(cam.resolution, dtype=np.float32) if k else None
+        if k == 1:
+            agg.add(idx.astype(np.int64), probs, weights)       # another index dtype: normalised on the device first
+        else:
+            agg.add(idx, probs, weights)
+        assert path(sm) == ("scatter" if STRIP else "image-records")
+        oagg.add(idx, probs, weights)
+    if not STRIP:
+        np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+    assert_fused_close(agg.get(), oagg.get())
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C", [3, 19, 70, 130])
+def test_add_foreign_image_mixed_primitive_sizes(sm, oracle, kind, C):
+    """Small, medium and one screen-filling primitive in the same image (big primitives: one wave scans the bounding box,
+    tree-ordered sums -> 1e-5 instead of bit equality), device-resident inputs included."""
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(12, 6, 400, 300, views=2)
+    extra_v = np.array([[-6, -4, -0.5], [6, -4, -0.5], [0, 5, -0.5]], np.float32)
+    verts = np.concatenate([mesh.vertices, extra_v])
+    faces = np.concatenate([mesh.faces, [[len(mesh.vertices), len(mesh.vertices) + 1, len(mesh.vertices) + 2]]]).astype(np.int32)
+    P = len(faces)
+    rng = np.random.default_rng(C)
+    agg = sm.fusion.MeshAggregator(P, C, kind)
+    o = oracle.OracleRenderer(verts, faces)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind)
+        for k, cam in enumerate(cams):
+            idx = o.render(cam)[0]
+            probs = random_probs(rng, *cam.resolution, C)
+            if kind == "mul":
+                probs = np.maximum(probs, 1e-3).astype(np.float32)
+            if k:
+                agg.add(to_device(idx), to_device(probs))
+            else:
+                agg.add(idx, probs)
+            assert path(sm) == ("scatter" if STRIP else "image-records")
+            oagg.add(idx, probs)
+        assert_fused_close(agg.get(), oagg.get(), rtol=5e-3 if (kind == "mul" and STRIP) else 1e-5)
+    finally:
+        oracle.set_accum_double(False)
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("shape,P,seeds", [((97, 61), 50, 40), ((320, 200), 3000, 2500), ((256, 256), 40, 400), ((64, 48), 100000, 300)])
+def test_add_blob_images(sm, oracle, kind, shape, P, seeds):
+    """Images that are no rendering of anything: nearest-seed blobs (sizes from a pixel to thousands, several blobs per
+    primitive when there are more seeds than primitives: primitives whose pixels lie far apart), background, out-of-range
+    values, far more primitives than pixels (records cleared per pixel instead of by memset)."""
+    W, H = shape
+    C = 7
+    rng = np.random.default_rng(W * H + P)
+    agg = sm.fusion.MeshAggregator(P, C, kind, 0.5)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, 0.5)
+        for k in range(3):
+            img = blob_image(rng, W, H, P, seeds)
+            probs = random_probs(rng, W, H, C)
+            if kind == "mul":
+                probs = np.maximum(probs, 1e-3).astype(np.float32)
+            weights = rng.random((W, H), dtype=np.float32) if k == 1 else None
+            agg.add(img, probs, weights)
+            oagg.add(img, probs, weights)
+        # Mul: primitives made of several blobs far apart are "sparse" (image_records.hip) and add their thousands of log terms with
+        # float32 atomics on the hi plane, like the generic scatter-add: the float32 LogProb state of the reference (Fusion.cu:85)
+        mul_tol = 2e-2 if seeds > P else (5e-3 if STRIP else 1e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=mul_tol if kind == "mul" else 1e-5)
+    finally:
+        oracle.set_accum_double(False)
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax"])
+def test_add_noise_image(sm, oracle, kind):
+    """Every pixel an independent random primitive: all primitives are sparse (bounding box = the image, a handful of
+    pixels each), none of them may be scanned box by box -- they take the pixel-order atomics, and the call returns promptly."""
+    import time
+    W, H, P, C = 640, 480, 20000, 5
+    rng = np.random.default_rng(3)
+    agg = sm.fusion.MeshAggregator(P, C, kind, 0.5)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, 0.5)
+        img = rng.integers(0, P, (W, H)).astype(np.uint32)
+        probs = random_probs(rng, W, H, C)
+        agg.add(img, probs)
+        t0 = time.perf_counter()
+        agg.add(img, probs)
+        sm._lib.synchronize(0)
+        assert time.perf_counter() - t0 < 0.5
+        oagg.add(img, probs)
+        oagg.add(img, probs)
+        assert_fused_close(agg.get(), oagg.get())
+    finally:
+        oracle.set_accum_double(False)
+
+
+def test_add_records_scratch_is_clean_between_calls(sm, oracle):
+    """A primitive seen in one image must leave nothing behind for the next (records, origins, queue), whatever its size."""
+    W, H, P, C = 200, 150, 500, 19
+    rng = np.random.default_rng(9)
+    agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+    oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
+    imgs = [blob_image(rng, W, H, P, 300), blob_image(rng, W, H, P, 20), np.full((W, H), BG, np.uint32), blob_image(rng, W, H, P, 450)]
+    imgs.append(imgs[0])
+    for img in imgs:
+        probs = random_probs(rng, W, H, C)
+        agg.add(img, probs)
+        oagg.add(img, probs)
+    assert_fused_close(agg.get_raw(), oagg.get_raw(), rtol=1e-5, atol=1e-6)
+
+
+def test_reloaded_render_cache_takes_image_records(sm, oracle, tmp_path):
+    """eval_scannet.py:168-185 in miniature: renders are saved to an .npz cache, a later run loads them and calls add() --
+    no render of THIS process matches, the records come from the images."""
+    mesh, cams = small_scene(120, 60, 320, 240, views=3)
+    P, C = len(mesh.faces), 19
+    rng = np.random.default_rng(21)
+    r = sm.render.triangles(mesh)
+    cache = tmp_path / "renders.npz"
+    np.savez_compressed(cache, **{"view%d" % k: np.asarray(r.render(cam)[0]) for k, cam in enumerate(cams)})
+    loaded = np.load(cache)
+    del r                                # "a later run": the renderer that made the cache is gone, and its records with it
+    import gc
+    gc.collect()
+    agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+    ref = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+    r2 = sm.render.triangles(mesh)       # a fresh renderer: nothing rendered yet, so nothing to match
+    for k, cam in enumerate(cams):
+        probs = random_probs(rng, *cam.resolution, C)
+        agg.add(loaded["view%d" % k], probs)
+        assert path(sm) == ("scatter" if STRIP else "image-records")
+        ref.fuse_view(r2, cam, probs)
+    if not STRIP:
+        np.testing.assert_array_equal(agg.get_raw().view(np.uint32), ref.get_raw().view(np.uint32))
+
+
+def test_scatter_path_in_subprocess():
+    """SMESH_ADD_RECORDS=0 (read once per process): the same images, and the add() tests of test_gpu_parity.py, through the
+    atomic scatter-add that add() took before the records could be rebuilt from the image -- it remains the path for padded
+    rows and for SMESH_FUSE=strip."""
+    import subprocess
+    import sys
+    if STRIP:
+        pytest.skip("already on the scatter path")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SMESH_ADD_RECORDS="0")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_image_records.py"), os.path.join(here, "test_gpu_parity.py"),
+                          "-q", "-x", "-m", "gpu", "-k", "(test_add_ or test_fusion_ or add_after_render) and not subprocess", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
+
+
+def test_default_threshold(sm, oracle):
+    """Without the knob: narrow rows take the scatter-add, rows of 32 classes and more the image records."""
+    os.environ.pop("SMESH_ADD_RECORDS_MIN_C", None)
+    W, H, P = 160, 120, 300
+    rng = np.random.default_rng(4)
+    img = blob_image(rng, W, H, P, 250)
+    for C, want in ((19, "scatter"), (31, "scatter"), (32, "image-records"), (150, "image-records")):
+        agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+        oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
+        probs = random_probs(rng, W, H, C)
+        agg.add(img, probs)
+        oagg.add(img, probs)
+        assert path(sm) == ("scatter" if STRIP else want)
+        assert_fused_close(agg.get(), oagg.get())

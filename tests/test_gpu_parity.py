@@ -663,7 +663,8 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
     """The reference's two-call loop `idx, depth = renderer.render(cam); aggregator.add(idx, probs)`
     (colorize_cityscapes_mesh.py:65-67): add() recognises the output of one of the last six renders -- by identity when it
     is the untouched DeviceArray, by CONTENT when it went through another framework or numpy -- and runs the triangle-order
-    fusion; an older render, or an image that was changed, takes the generic scatter-add.  All give the oracle's result."""
+    fusion on the records that render left ("render-records"); an older render, or an image that was changed, has its
+    records rebuilt from the image ("image-records", image_records.hip).  All give the oracle's result."""
     import os
     from semantic_meshes_amd.device import to_device
     mesh, cams = small_scene(120, 60, 320, 240, views=8)
@@ -671,17 +672,20 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
     rng = np.random.default_rng(5)
     r = sm.render.triangles(mesh)
     last = lambda: sm._lib.lib().smesh_last_fuse_kernel().decode()
+    path = lambda: sm._lib.lib().smesh_last_add_path().decode()
     agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
     o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
     oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
     forced_generic = os.environ.get("SMESH_FUSE") == "strip"
     fast = "k_scatter_strip" if forced_generic else "k_fuse_tri"
+    matched = "scatter" if forced_generic else "render-records"
+    generic = "scatter"        # (C = 19: below the class count from which add() rebuilds records from the image, test_gpu_image_records.py)
     for cam in cams[:3]:
         probs = random_probs(rng, *cam.resolution, C)
         weights = rng.random(cam.resolution, dtype=np.float32)
         idx, depth = r.render(cam)
         agg.add(idx, probs, weights)
-        assert last() == fast
+        assert last() == fast and path() == matched
         oagg.add(o.render(cam)[0], probs, weights)
     if not forced_generic:
         np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
@@ -690,17 +694,17 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
     probs = random_probs(rng, *cams[0].resolution, C)
     kept = [r.render(cams[k])[0] for k in range(7)]
     agg.add(kept[0], probs)
-    assert last() == "k_scatter_strip"
+    assert path() == generic
     oagg.add(o.render(cams[0])[0], probs)
     for k in (1, 6, 3):
         agg.add(kept[k], probs)
-        assert last() == fast
+        assert last() == fast and path() == matched
         oagg.add(o.render(cams[k])[0], probs)
     # 2. exported through __cuda_array_interface__: identity no longer proves anything, the content does
     _ = kept[5].__cuda_array_interface__
     assert kept[5]._exported
     agg.add(kept[5], probs)
-    assert last() == fast
+    assert last() == fast and path() == matched
     oagg.add(o.render(cams[5])[0], probs)
     # ... and after someone changed a single pixel of it the generic path takes over (and honours the change)
     _ = kept[4].__cuda_array_interface__          # exported (the library takes the plane's checksum at this point) ...
@@ -709,22 +713,23 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
     changed[x, y] = (changed[x, y] + 17) % P
     sm._lib.check(sm._lib.lib().smesh_memcpy(kept[4].ptr, changed.ctypes.data, changed.nbytes, sm._lib.MEM_DEVICE, sm._lib.MEM_HOST, 0))
     agg.add(kept[4], probs)                       # ... then modified in place by its new co-owner
-    assert last() == "k_scatter_strip"
+    assert path() == generic
     oagg.add(changed, probs)
     # 3. a numpy COPY of a render (DLPack -> framework -> .numpy() in the reference's harness) with host probs
     agg.add(np.asarray(kept[2]), probs)
-    assert last() == fast
+    assert last() == fast and path() == matched
     oagg.add(o.render(cams[2])[0], probs)
     agg.add(np.asarray(kept[2]).astype(np.int32), probs)          # int32 copies too (-1 == 0xFFFFFFFF)
-    assert last() == fast
+    assert last() == fast and path() == matched
     oagg.add(o.render(cams[2])[0], probs)
-    agg.add(np.asarray(kept[2]).astype(np.int64), probs)          # 64-bit images are never a copy of a plane: generic scatter-add
+    agg.add(np.asarray(kept[2]).astype(np.int64), probs)          # 64-bit images are never a copy of a plane: records from the image
+    assert path() == generic
     oagg.add(o.render(cams[2])[0], probs)
     del kept
     # 4. device-resident probs and the latest render -> fast path again
     idx1b, _ = r.render(cams[1])
     agg.add(idx1b, to_device(probs))
-    assert last() == fast
+    assert last() == fast and path() == matched
     oagg.add(o.render(cams[1])[0], probs)
     assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
 
