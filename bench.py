@@ -133,6 +133,32 @@ def host_path(renderer, agg, cams, W, H, C, device, views=6):
     return out
 
 
+def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
+    """add() on index images the library did not render (the reference's add() takes any (W,H) image, Mesh.h:65-107; its
+    harness reloads renders from an .npz cache, eval_scannet.py:168-185): device-resident COPIES of renders -- no render
+    matches by identity, content matching off -- with device-resident probs.  Per-primitive records are rebuilt from the image
+    and fused in triangle order from 32 classes up, the atomic scatter-add runs below (fusion.hip, kAddRecordsMinC).  Never `value`."""
+    from semantic_meshes_amd.device import to_device
+    images = [to_device(np.asarray(renderer.render(cams[k % len(cams)])[0]), device) for k in range(views)]
+    agg = fusion.MeshAggregator(primitives=P, classes=C, device=device)
+    keep = fusion._MeshAggregator.match_renders
+    fusion._MeshAggregator.match_renders = False
+    try:
+        for rep in range(2):
+            _lib.synchronize(device)
+            t0 = time.perf_counter()
+            for k, img in enumerate(images):
+                agg.add(img, probs[k % len(probs)])
+            _lib.synchronize(device)
+            dt = (time.perf_counter() - t0) / views
+    finally:
+        fusion._MeshAggregator.match_renders = keep
+    bytes_per_view = 4 * W * H + 4 * W * H * C + 8 * C * T_mean           # SURVEY.md 8(d)
+    return {"ms_per_view": round(1e3 * dt, 4), "views_per_s": round(1.0 / dt, 1), "path": _lib.lib().smesh_last_add_path().decode(),
+            "kernel": _lib.lib().smesh_last_fuse_kernel().decode(), "frac": round(bytes_per_view / dt / 1e9 / HBM_PEAK_GBS, 4),
+            "what": "add(device copy of a render, device probs), one call per view, %d views, host-timed" % views}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -382,6 +408,8 @@ def main():
         }
         if world == 1 and not args.no_host_path:
             out["host_path"] = host_path(renderer, agg, cams, W, H, C, device, views=6 if args.workload != "cfg5" else 2)
+            if not texels:
+                out["foreign_images"] = foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8 if args.workload != "cfg5" else 4)
         if world == 1 and ((args.workload == "cfg2" and not args.no_cpu_baseline) or args.cpu_baseline):
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)

@@ -1380,6 +1380,18 @@ __global__ __launch_bounds__(kWave) void k_fuse_texel_big(TriFuseArgs a) { fuse_
 // order, as before (the reference's order of additions; a row with a single contribution has no order to keep).
 constexpr int kTexelBlock = 512;
 
+// Mul ("Mul state", fuse_tri.inc.hpp): a texel receives a pixel or two per view, so every term is folded into the (hi, lo) row on its
+// own, in double, the row re-centred on its largest finite element.
+template <int N>
+__device__ __forceinline__ void mul_fold_pixel(float (&hi)[N], float (&lo)[N], const float (&p)[N], int cw, float w) {
+  float m = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < N; j++) if (j < cw && hi[j] > m && hi[j] < INFINITY) m = hi[j];
+  const float centre = m > -INFINITY ? m : 0.0f;
+#pragma unroll
+  for (int j = 0; j < N; j++) if (j < cw) mul_fold(hi[j], lo[j], centre, (double)contribution<SMESH_AGG_MUL>(p[j], w));
+}
+
 template <int KIND>
 __device__ __forceinline__ void fuse_texel_pixel(const TriFuseArgs& a, const uint32_t C, const uint64_t pix, const uint32_t v, const uint32_t n) {
   float p[kSlice];
@@ -1388,6 +1400,9 @@ __device__ __forceinline__ void fuse_texel_pixel(const TriFuseArgs& a, const uin
   float* row = a.acc + (uint64_t)v * C;
   float accr[kSlice];
   load_slice(row, (int)C, accr);
+  constexpr int NL = KIND == SMESH_AGG_MUL ? kSlice : 1;
+  float lo[NL];
+  if constexpr (KIND == SMESH_AGG_MUL) load_slice(a.acc_lo + (uint64_t)v * C, (int)C, lo);
   const float wt = a.weights ? a.weights[pix] : 1.0f;
   float sum = 0.0f, best = p[0];
   int am = 0;
@@ -1399,7 +1414,12 @@ __device__ __forceinline__ void fuse_texel_pixel(const TriFuseArgs& a, const uin
     }
   if (!(sum > 0.5f)) return;                          // Mesh.h:98
   const float w = (a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f) * wt;   // :100-103
-  accumulate_slice<KIND>(accr, p, (int)C, w, am);
+  if constexpr (KIND == SMESH_AGG_MUL) {
+    mul_fold_pixel(accr, lo, p, (int)C, w);
+    store_slice(a.acc_lo + (uint64_t)v * C, (int)C, lo);
+  } else {
+    accumulate_slice<KIND>(accr, p, (int)C, w, am);
+  }
   store_slice(row, (int)C, accr);
 }
 
@@ -1492,6 +1512,8 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a,
   const uint32_t g = s_tri[t];
   const uint32_t first = a.tex_first[g], res = a.tex_res[g], cnt = res * (res + 1u) / 2u;
   float accr[kSlice];
+  constexpr int NL = KIND == SMESH_AGG_MUL ? kSlice : 1;
+  float lo[NL];                 // Mul: the row's second plane
   uint32_t cur = 0xFFFFFFFFu;   // texel whose row is in accr
   bool dirty = false;
   for (int v = 0; v < nv; v++) {
@@ -1514,8 +1536,12 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a,
       uint32_t n = 0;                                   // Mesh.h:90-93 restricted to this triangle's pixels
       for (unsigned long long m2 = win; m2; m2 &= m2 - 1ull) n += idx[pixel(__ffsll((long long)m2) - 1)] == tex ? 1u : 0u;
       if (tex != cur) {
-        if (dirty) store_slice(a.acc + (uint64_t)cur * C, (int)C, accr);
+        if (dirty) {
+          store_slice(a.acc + (uint64_t)cur * C, (int)C, accr);
+          if constexpr (KIND == SMESH_AGG_MUL) store_slice(a.acc_lo + (uint64_t)cur * C, (int)C, lo);
+        }
         load_slice(a.acc + (uint64_t)tex * C, (int)C, accr);
+        if constexpr (KIND == SMESH_AGG_MUL) load_slice(a.acc_lo + (uint64_t)tex * C, (int)C, lo);
         cur = tex;
         dirty = false;
       }
@@ -1532,11 +1558,15 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a,
         }
       if (!(sum > 0.5f)) continue;                        // Mesh.h:98
       const float w = (a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f) * wt;   // :100-103
-      accumulate_slice<KIND>(accr, p, (int)C, w, am);
+      if constexpr (KIND == SMESH_AGG_MUL) mul_fold_pixel(accr, lo, p, (int)C, w);
+      else accumulate_slice<KIND>(accr, p, (int)C, w, am);
       dirty = true;
     }
   }
-  if (dirty) store_slice(a.acc + (uint64_t)cur * C, (int)C, accr);
+  if (dirty) {
+    store_slice(a.acc + (uint64_t)cur * C, (int)C, accr);
+    if constexpr (KIND == SMESH_AGG_MUL) store_slice(a.acc_lo + (uint64_t)cur * C, (int)C, lo);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2008,7 +2038,7 @@ int smesh_aggregator_max_fused_views(smesh_aggregator* a) {
   int m = a->C <= 40u ? 8 : (a->C <= (uint32_t)kFuseTriMaxC ? 2 : 1);
   if (a->C > (uint32_t)kFuseTriMaxC) m = 8;   // k_fuse_tri_any / k_fuse_tri_wide: any count up to eight
   // 41 .. 48: four or eight views go through k_fuse_tri_any (0.124-0.133 vs 0.138-0.146 ms per view at cfg2's geometry), one or two
-  // through the 48-slot k_fuse_tri; not for Mul, whose (hi, lo) state only k_fuse_tri keeps
+  // through the 48-slot k_fuse_tri; Mul stays there (the Mul instances of k_fuse_tri_any carry a view's partial sums in double: 220 VGPRs)
   if (a->C > 40u && a->C <= (uint32_t)kFuseTriMaxC && a->kind != SMESH_AGG_MUL) m = 8;
   return std::min(m, cap);
 }
