@@ -20,6 +20,19 @@ for w in cfg4 cfg5; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$w -o bench -- python bench.py --workload $w --no-host-path > $out/bench_kt_$w.log 2>&1
   cp $out/kt_$w/bench_kernel_stats.csv $out/r02_bench_${w}_kernel_stats.csv
 done
+# add() on index images the library did not render (image_records.hip): records + triangle-order fusion against the scatter-add
+{
+  echo "# python tools/generic_add_sweep.py (cfg2 geometry, device images and probs, ms per view) -- SMESH_ADD_RECORDS_MIN_C=0, then SMESH_ADD_RECORDS=0"
+  SMESH_ADD_RECORDS_MIN_C=0 python tools/generic_add_sweep.py 2>&1 | grep ms/view
+  SMESH_ADD_RECORDS=0 python tools/generic_add_sweep.py 2>&1 | grep ms/view
+  echo "# python tools/generic_add_bench.py cfg5 8 -- default (records from 32 classes), then SMESH_ADD_RECORDS=0"
+  python tools/generic_add_bench.py cfg5 8 2>&1 | grep "add()"
+  SMESH_ADD_RECORDS=0 python tools/generic_add_bench.py cfg5 8 2>&1 | grep "add()"
+} > $out/r02_foreign_images.txt
+SMESH_ADD_RECORDS_MIN_C=0 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_fi -o gab -- python tools/generic_add_bench.py cfg2 16 > $out/gab_kt.log 2>&1
+cp $out/kt_fi/gab_kernel_stats.csv $out/r02_foreign_images_cfg2_records_kernel_stats.csv
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_fi5 -o gab -- python tools/generic_add_bench.py cfg5 8 > $out/gab_kt5.log 2>&1
+cp $out/kt_fi5/gab_kernel_stats.csv $out/r02_foreign_images_cfg5_kernel_stats.csv
 # the group pipeline (opt-in): bench line, kernel stats and a trace excerpt showing the rasteriser of group g+1 beside the fusion of group g
 python bench.py --group-pipeline --no-cpu-baseline --no-host-path > $out/bench_gp.log 2>&1; last $out/bench_gp.log > $out/r02_bench_group_pipeline.json
 python bench.py --group-pipeline --steps 20 --warmup 5 --no-cpu-baseline --no-host-path > $out/bench_gp20.log 2>&1; last $out/bench_gp20.log > $out/r02_bench_group_pipeline_steps20.json
