@@ -88,7 +88,7 @@ class _MeshAggregator:
                 None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H))
             release_to(self.device, streams)
             return
-        if idt.itemsize == 4 and tuple(istr) == (H, 1) and self.match_renders:
+        if idt.itemsize == 4 and tuple(istr) == (H, 1) and self.match_renders and not self._records_from_image():
             # An index image that went through another framework or numpy (DLPack -> TF -> .numpy() -> add in the reference's
             # harness, eval-scannet/eval_scannet.py:211-238): if its content checksum still equals that of one of the last renders of
             # a renderer with this many primitives on this GPU, the triangle-order fusion applies (smesh_aggregator_add_matched)
@@ -110,6 +110,17 @@ class _MeshAggregator:
 
     # class-wide switch for the content check above
     match_renders = os.environ.get("SMESH_MATCH_RENDERS", "1") != "0"
+
+    def _records_from_image(self):
+        """From 32 classes up smesh_aggregator_add rebuilds the per-primitive records from ANY dense image (image_records.hip) and
+        runs the same triangle-order kernels as a matched render would -- without the content checksum's read-back, which costs more
+        than the records do.  (Texel renderers keep the match: their records carry the texel tables.)"""
+        if os.environ.get("SMESH_ADD_RECORDS") == "0" or os.environ.get("SMESH_FUSE") == "strip":
+            return False
+        from .render import _live_renderers
+        if any(getattr(rb, "is_texel", False) and rb.getPrimitivesNum() == self.primitives for rb in list(_live_renderers)):
+            return False
+        return self.classes >= int(os.environ.get("SMESH_ADD_RECORDS_MIN_C", "32"))
 
     def reset(self):
         _lib.check(_lib.lib().smesh_aggregator_reset(self._h))

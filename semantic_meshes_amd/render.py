@@ -107,6 +107,7 @@ class PlyRendererTriangles(_Renderer):
 
 class PlyRendererTexels(_Renderer):
     """Texel primitives (TexturedTriangleRenderer.h:87-182)."""
+    is_texel = True      # (MeshAggregator.add: copies of a texel render keep going through the content match)
 
     def __init__(self, mesh, cameras, texels_per_pixel=0.1, device=0):
         v, f = _mesh_arrays(mesh)

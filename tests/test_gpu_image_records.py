@@ -228,3 +228,75 @@ def test_default_threshold(sm, oracle):
         oagg.add(img, probs)
         assert path(sm) == ("scatter" if STRIP else want)
         assert_fused_close(agg.get(), oagg.get())
+
+
+def test_foreign_image_cfg2_size_equals_fuse_view_bit_for_bit(sm):
+    """BASELINE cfg2's geometry (1 M triangles, 1920x1080) with 32 classes -- the class count from which add() rebuilds records by
+    default: device copies of two renders through add() against fuse_view on the renderer's own records.  Same kernel, same
+    masks, so the raw accumulators agree bit for bit (the records of every triangle were rebuilt exactly)."""
+    from semantic_meshes_amd import synth
+    from semantic_meshes_amd.device import to_device
+    os.environ.pop("SMESH_ADD_RECORDS_MIN_C", None)
+    cfg = synth.CONFIGS["cfg2"]
+    W, H, C = cfg["width"], cfg["height"], 32
+    mesh = synth.grid_mesh(cfg["a"], cfg["b"])
+    P = len(mesh.faces)
+    r = sm.render.triangles(mesh)
+    a, b = sm.fusion.MeshAggregator(P, C), sm.fusion.MeshAggregator(P, C)
+    keep = sm.fusion._MeshAggregator.match_renders
+    sm.fusion._MeshAggregator.match_renders = False
+    try:
+        for k in (3, 77):
+            cam = synth.ring_camera(k, cfg["views"], W, H)
+            probs = synth.device_probs(W, H, C, synth.probs_seed(2, k), zero_fraction=0.03)
+            a.add(to_device(np.asarray(r.render(cam)[0])), probs)
+            assert path(sm) == ("scatter" if STRIP else "image-records")
+            b.fuse_view(r, cam, probs)
+    finally:
+        sm.fusion._MeshAggregator.match_renders = keep
+    if not STRIP:
+        np.testing.assert_array_equal(a.get_raw().view(np.uint32), b.get_raw().view(np.uint32))
+    else:
+        np.testing.assert_allclose(a.get_raw(), b.get_raw(), rtol=1e-5, atol=1e-7)
+
+
+def test_foreign_image_cfg5_full_size(sm):
+    """BASELINE cfg5 at full size (20 M primitives: 720 MB of records and scratch, row offsets beyond 32 bits; 4096x2160; C = 150):
+    add() on a device copy of a render against fuse_view, through windows of accumulator rows."""
+    import ctypes
+    from semantic_meshes_amd import _lib, synth
+    from semantic_meshes_amd.device import to_device
+    cfg = synth.CONFIGS["cfg5"]
+    W, H, C = cfg["width"], cfg["height"], cfg["classes"]
+    mesh = synth.grid_mesh(cfg["a"], cfg["b"])
+    P = len(mesh.faces)
+    r = sm.render.triangles(mesh)
+    cam = synth.ring_camera(290, cfg["views"], W, H)
+    probs = synth.device_probs(W, H, C, synth.probs_seed(5, 1), 0.02)
+    img = np.asarray(r.render(cam)[0])
+    a, b = sm.fusion.MeshAggregator(P, C), sm.fusion.MeshAggregator(P, C)
+    keep = sm.fusion._MeshAggregator.match_renders
+    sm.fusion._MeshAggregator.match_renders = False
+    try:
+        a.add(to_device(img), probs)
+        assert path(sm) == ("scatter" if STRIP else "image-records")
+    finally:
+        sm.fusion._MeshAggregator.match_renders = keep
+    b.fuse_view(r, cam, probs)
+
+    def rows(agg, first, count):
+        raw = agg.raw_device_array()
+        out = np.empty((count, C), np.float32)
+        _lib.check(_lib.lib().smesh_memcpy(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(raw.ptr + first * C * 4), out.nbytes,
+                                           _lib.MEM_HOST, _lib.MEM_DEVICE, agg.device))
+        return out
+    valid = np.unique(img[img != BG])
+    assert int(valid[-1]) * C * 4 > 2 ** 33
+    for centre in (int(valid[0]), int(valid[len(valid) // 2]), int(valid[-1])):
+        first = max(0, min(P - 100_000, centre - 50_000))
+        ra, rb = rows(a, first, 100_000), rows(b, first, 100_000)
+        assert np.abs(rb).sum() > 0
+        if STRIP:
+            np.testing.assert_allclose(ra, rb, rtol=1e-5, atol=1e-7)
+        else:
+            np.testing.assert_array_equal(ra.view(np.uint32), rb.view(np.uint32))
