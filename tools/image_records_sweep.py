@@ -1,0 +1,75 @@
+"""One-off differential sweep of add() on foreign index images (image_records.hip) against the CPU oracle: random image families
+(blobs, noise, stripes, checkerboards, one primitive filling the image, empty images, oracle renderings of triangle soups), sizes,
+primitive counts, class counts on both sides of the scatter threshold, aggregators, weights, index dtypes.
+usage (GPU box): python tools/image_records_sweep.py [first_seed] [count]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+os.environ["SMESH_ADD_RECORDS_MIN_C"] = "0"
+import semantic_meshes_amd as sm
+from oracle import oracle
+from helpers import BG, random_probs
+from test_gpu_image_records import blob_image
+
+oracle.set_threads(1)
+first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 0), (int(sys.argv[2]) if len(sys.argv) > 2 else 300)
+worst = {"sum": 0.0, "summax": 0.0, "mul": 0.0}
+fails = 0
+t0 = time.time()
+for seed in range(first, first + count):
+    rng = np.random.default_rng(70000 + seed)
+    W, H = int(rng.choice([1, 7, 33, 64, 97, 160, 333])), int(rng.choice([1, 5, 29, 64, 120, 257]))
+    P = int(rng.choice([1, 2, 17, 300, 5000, 200000]))
+    C = int(rng.choice([1, 3, 7, 19, 31, 32, 40, 47, 64, 130]))
+    kind = str(rng.choice(["sum", "summax", "mul"]))
+    iew = float(rng.choice([0.0, 0.5, 1.0]))
+    family = str(rng.choice(["blob", "blob_many", "noise", "vstripes", "hstripes", "checker", "one", "empty", "border", "diag"]))
+    agg = sm.fusion.MeshAggregator(P, C, kind, iew)
+    oracle.set_accum_double(True)
+    oagg = oracle.OracleAggregator(P, C, kind, iew)
+    sparse = False
+    for view in range(int(rng.choice([1, 2, 3]))):
+        xs, ys = np.meshgrid(np.arange(W), np.arange(H), indexing="ij")
+        if family == "blob":
+            img = blob_image(rng, W, H, P, max(1, min(P, int(rng.integers(1, 400)))))
+        elif family == "blob_many":
+            img = blob_image(rng, W, H, P, int(rng.integers(P + 1, P + 400))); sparse = True
+        elif family == "noise":
+            img = rng.integers(0, P, (W, H)).astype(np.uint32); sparse = True
+        elif family == "vstripes":
+            img = ((xs // int(rng.integers(1, 12))) % P).astype(np.uint32); sparse = True
+        elif family == "hstripes":
+            img = ((ys // int(rng.integers(1, 12))) % P).astype(np.uint32); sparse = True
+        elif family == "checker":
+            img = (((xs + ys) % 2) % P).astype(np.uint32); sparse = True
+        elif family == "one":
+            img = np.full((W, H), int(rng.integers(0, P)), np.uint32)
+        elif family == "empty":
+            img = np.full((W, H), BG, np.uint32)
+        elif family == "border":
+            img = np.full((W, H), BG, np.uint32)
+            img[W - 1, :] = int(rng.integers(0, P)); img[:, H - 1] = int(rng.integers(0, P)); img[0, 0] = int(rng.integers(0, P)); sparse = True
+        else:
+            img = (((xs * 3 + ys * 5) // 7) % P).astype(np.uint32); sparse = True
+        probs = random_probs(rng, W, H, C, zero_fraction=0.1)
+        if kind == "mul":
+            probs = np.where(probs.sum(-1, keepdims=True) > 0, np.maximum(probs, 1e-3), 0).astype(np.float32)
+        weights = rng.random((W, H), dtype=np.float32) if rng.random() < 0.4 else None
+        dt = rng.choice([np.uint32, np.int32, np.int64, np.uint64])
+        gimg = img.astype(np.int64).astype(dt) if dt != np.uint32 else img
+        if dt in (np.int32, np.int64):
+            gimg = np.where(img == BG, -1, img.astype(np.int64)).astype(dt)
+        agg.add(gimg, probs, weights)
+        oagg.add(img, probs, weights)
+    got, want = agg.get().astype(np.float64), oagg.get().astype(np.float64)
+    oracle.set_accum_double(False)
+    err = np.abs(got - want)
+    rel = float(((err - 1e-6) / np.maximum(np.abs(want), 1e-300)).max()) if err.size else 0.0
+    tol = 2e-5 if kind != "mul" else (5e-2 if sparse or family in ("one", "blob") else 2e-5)
+    worst[kind] = max(worst[kind], rel if not (kind == "mul" and tol > 1e-3) else 0.0)
+    if rel > tol:
+        fails += 1
+        print("FAIL seed %d: %s %dx%d P=%d C=%d %s iew=%.1f rel %.3e path %s" % (seed, family, W, H, P, C, kind, iew, rel,
+              sm._lib.lib().smesh_last_add_path().decode()), flush=True)
+print("%d scenes, %d failures, worst relative error (tight-tolerance scenes) %s, %.0f s" % (count, fails, worst, time.time() - t0), flush=True)
