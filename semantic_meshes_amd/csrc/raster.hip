@@ -271,7 +271,8 @@ struct RasterArgs {
   uint32_t big_capacity;
   TriFrag* frags;             // per-triangle fragment records for the triangle-order fusion (may be null)
   FragQueues q;               // fragment-queue path only
-  uint32_t tpw;               // k_raster_frag: triangles per wave (power of two <= 64)
+  uint32_t tpw;               // k_raster_frag: triangles per group of a wave (power of two <= 64)
+  uint32_t groups;            // k_raster_frag: groups per wave (1; 2 with tpw = 64 when the launch has waves to spare)
   int dbg;                    // development ablation (SMESH_RDBG) of k_raster_frag: 1 = no stores, 2 = setup only, 4 = + coverage,
                               // 8 = + slot reservation, 16 = grouping without the reservation atomics
 };
@@ -280,8 +281,12 @@ struct RasterArgs {
 // make neighbouring fragments share cache lines: no change in k_raster_small, slower resolve.)
 __device__ __forceinline__ uint64_t key_index(uint32_t x, uint32_t y, uint32_t H) { return (uint64_t)x * H + y; }
 
+__device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t, const int32_t i0, const int32_t i1, const int32_t i2);
 __device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t) {
-  const int32_t i0 = a.faces[3 * f + 0], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
+  return load_tri(a, f, t, a.faces[3 * f + 0], a.faces[3 * f + 1], a.faces[3 * f + 2]);
+}
+// (vertex indices already in registers: k_raster_frag requests those of its next 64 triangles ahead of time)
+__device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t, const int32_t i0, const int32_t i1, const int32_t i2) {
   // 0 <= i < V for all three, as one unsigned comparison (negative indices are huge as uint32; V <= 2^31 since indices are int32)
   if ((uint64_t)max((uint32_t)i0, max((uint32_t)i1, (uint32_t)i2)) >= a.V) return false;
   if (a.tex_res && a.tex_res[f] == 0) return false;
@@ -414,13 +419,11 @@ __device__ __forceinline__ Claim4 wave_claim_prepare4(uint32_t T0, uint32_t n01,
 // One lane per triangle (bounding box <= 8 x 8; larger ones: see the end of the kernel): coverage walk, slot
 // reservation in the (at most 2 x 2) tiles the box overlaps, then depth per covered sample and the queue stores.
 // The edge functions are shade()'s, expression for expression.
-__device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint64_t wave_id) {
-  // a.tpw triangles per wave (64 for large meshes; fewer for small ones, so that the cooperative medium-triangle
-  // loop below has enough waves to spread over the chip)
+// `f`: this lane's triangle (a.F: none), `i0 .. i2` its vertex indices (valid when f < a.F); `wave0`: the triangle of lane 0;
+// `sub`: the wave's sub-queue in every tile.
+__device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64_t f, const int32_t i0, const int32_t i1, const int32_t i2,
+                                               const uint64_t wave0, const uint32_t sub) {
   const int lane = threadIdx.x & 63;
-  const uint64_t wave0 = wave_id * a.tpw;   // first triangle of this wave
-  const uint32_t sub = (uint32_t)wave_id & (kQSub - 1);   // this wave's sub-queue in every tile
-  const uint64_t f = lane < (int)a.tpw ? wave0 + lane : a.F;
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   Tri t;
@@ -428,7 +431,7 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
   unsigned long long cover = 0ull;
   bool medium = false;
   const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // value written to the index image
-  if (f < a.F && load_tri(a, f, t)) {
+  if (f < a.F && load_tri(a, f, t, i0, i1, i2)) {
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
     rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
     if (bw > 8 || bh > 8) {
@@ -601,8 +604,31 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
   }
 }
 
+// One wave = a.groups x a.tpw consecutive triangles (tpw: 64 for large meshes; fewer for small ones, so that the cooperative
+// medium-triangle loop has enough waves to spread over the chip).  With several groups per wave (LOOP: the grouped launches of
+// meshes of millions of triangles) the next group's vertex indices are requested before the current group is shaded (three
+// registers), so that it starts one memory round trip ahead: cfg4 666 -> 627 us per eight-view launch with four groups; nothing at
+// cfg2 (169 / 171 / 175 / 182 us with 1 / 2 / 4 / 8 groups, tools/raster_groups.sh), where one group per wave stays.
+template <bool LOOP>
+__device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint64_t wave_id) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t G = LOOP ? a.groups : 1u;
+  uint64_t wave0 = wave_id * G * a.tpw;
+  uint64_t f = lane < (int)a.tpw ? wave0 + lane : a.F;
+  int32_t n0 = 0, n1 = 0, n2 = 0;
+  if (f < a.F) { n0 = a.faces[3 * f + 0]; n1 = a.faces[3 * f + 1]; n2 = a.faces[3 * f + 2]; }
+  for (uint32_t g = 0; g < G; g++) {
+    const int32_t i0 = n0, i1 = n1, i2 = n2;
+    const uint64_t fn = f + 64u;          // (G > 1 only with 64 triangles per group)
+    if (g + 1 < G && fn < a.F) { n0 = a.faces[3 * fn + 0]; n1 = a.faces[3 * fn + 1]; n2 = a.faces[3 * fn + 2]; }
+    raster_frag_64(a, f, i0, i1, i2, wave0, (uint32_t)(wave_id * G + g) & (kQSub - 1));
+    f = fn < a.F ? fn : a.F;
+    wave0 += 64u;
+  }
+}
+
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_raster_frag(RasterArgs a) {
-  raster_frag_wave(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  raster_frag_wave<false>(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 }
 
 // Several views in one launch: blocks [v * blocks_per_view, (v + 1) * blocks_per_view) rasterise view v.
@@ -614,7 +640,7 @@ struct RasterGroup {
 };
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_raster_frag_group(RasterGroup g) {
   const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
-  raster_frag_wave(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
+  raster_frag_wave<true>(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
 }
 
 // One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
@@ -981,10 +1007,21 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   a.q = FragQueues();
   a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~2048 waves
   while (a.tpw > 1 && r->F / a.tpw < 2048) a.tpw >>= 1;
+  a.groups = 1;  // (frag_groups() decides per launch)
   return a;
 }
 
 // Rasterise into caller-provided device planes (d_depth may be null: index plane only).
+// Groups of 64 triangles per wave in the grouped launches (k_raster_frag_group; the next group's vertex indices prefetched): four for
+// meshes of four million triangles and more, when the launch still has four waves for every slot of the chip (1024 SIMDs x 5); else one.
+// SMESH_RASTER_GROUPS=n forces n.
+uint32_t frag_groups(uint64_t F, int views, uint32_t tpw) {
+  static const int knob = getenv("SMESH_RASTER_GROUPS") ? atoi(getenv("SMESH_RASTER_GROUPS")) : 0;
+  if (tpw != 64u) return 1u;
+  if (knob >= 1) return (uint32_t)knob;
+  return (F >= 4000000u && (uint64_t)views * div_up(F, 256u) >= 20480u) ? 4u : 1u;
+}
+
 int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, float* d_depth, hipStream_t st = nullptr,
                 int side = 0) {
   DeviceCtx* ctx = r->ctx;
@@ -1112,7 +1149,8 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   pg.verts = r->verts; pg.V = r->V;
   pg.n = (uint32_t)n;
   rg.n = (uint32_t)n;
-  rg.blocks_per_view = (uint32_t)div_up(div_up(r->F, rg.view[0].tpw), 4);
+  for (int v = 0; v < n; v++) rg.view[v].groups = frag_groups(r->F, n, rg.view[0].tpw);
+  rg.blocks_per_view = (uint32_t)div_up(div_up(r->F, rg.view[0].tpw * rg.view[0].groups), 4);
   ProfScope prof(ctx, SMESH_PROF_RASTER, st);
   hipLaunchKernelGGL(k_project_vertices_group, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, pg);
   SMESH_HIP(hipGetLastError());

@@ -282,3 +282,17 @@ def test_cfg5_full_size_properties(sm):
     touched = want.sum(axis=1) > 0.5
     np.testing.assert_allclose(tail[touched].sum(axis=1), 1.0, rtol=1e-5)                        # rows L1-normalised
     assert (tail[~touched] == 0).all() and touched.sum() > 1000
+
+
+def test_group_of_eight_cfg2_with_three_groups_of_triangles_per_wave():
+    """SMESH_RASTER_GROUPS=3 (read once per process): k_raster_frag_group's waves take three groups of 64 triangles each, the next
+    group's vertex indices prefetched -- the arrangement meshes of four million triangles and more get by default -- on the
+    full-size cfg2 test above, whose 1 M triangles are not a multiple of 192."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SMESH_RASTER_GROUPS="3")
+    res = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_gpu_configs.py"), "-q", "-x", "-m", "gpu", "-k",
+                          "group_of_eight_cfg2_full_size", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
