@@ -1075,13 +1075,18 @@ template <int KIND, int NCH, typename ACC4>   // ACC4: fvec4 (the accumulator ro
 __device__ __forceinline__ void fuse_pixel_wide(ACC4 (&ac)[NCH], const fvec4 (&p)[NCH], uint32_t C, int l, float w) {
   typedef decltype(ac[0].x + ac[0].x) acc_t;
   float ps = 0.0f, pa = 0.0f;
+  bool neg = false;
 #pragma unroll
   for (int k = 0; k < NCH; k++) {
     ps += (p[k].x + p[k].y) + (p[k].z + p[k].w);
     pa += (fabsf(p[k].x) + fabsf(p[k].y)) + (fabsf(p[k].z) + fabsf(p[k].w));
+    neg = neg || !(fminf(fminf(p[k].x, p[k].y), fminf(p[k].z, p[k].w)) >= 0.0f);   // (a NaN counts as negative: fminf drops it, the sum keeps it)
   }
+  neg = neg || !(ps >= 0.0f);
   ps = wave_sum(ps);
-  pa = wave_sum(pa);
+  // the sum of the absolute values -- the scale of the tree sum's error -- is the sum itself when no element is negative
+  // (every probability row): the second wave-wide reduction only runs for rows with negative entries
+  pa = __ballot(neg) != 0ull ? wave_sum(pa) : ps;
   bool counted = ps > 0.5f;
   if (!(fabsf(ps - 0.5f) > 1e-4f * (pa + 1.0f))) {
     // too close to call from a tree sum (or not finite): replay tt::sum, one class at a time
