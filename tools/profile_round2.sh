@@ -33,6 +33,13 @@ SMESH_ADD_RECORDS_MIN_C=0 timeout 600 rocprofv3 --kernel-trace --stats --output-
 cp $out/kt_fi/gab_kernel_stats.csv $out/r02_foreign_images_cfg2_records_kernel_stats.csv
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_fi5 -o gab -- python tools/generic_add_bench.py cfg5 8 > $out/gab_kt5.log 2>&1
 cp $out/kt_fi5/gab_kernel_stats.csv $out/r02_foreign_images_cfg5_kernel_stats.csv
+# class-count sweep at cfg2's geometry through fuse_views (every triangle-order kernel), groups of eight views and one launch per view
+{
+  echo "# python tools/class_sweep_views.py <C ...>: fuse_views at cfg2 geometry (1 M triangles, 1920x1080), rasteriser included, groups of eight views"
+  python tools/class_sweep_views.py 5 13 19 21 27 32 40 41 48 49 64 100 127 128 150 256 512 2>&1 | grep "C ="
+  echo "# the same with one fusion launch per view (SMESH_FUSE_VIEWS=1)"
+  SMESH_FUSE_VIEWS=1 python tools/class_sweep_views.py 5 19 40 48 64 100 127 150 256 2>&1 | grep "C ="
+} > $out/r02_class_count_sweep.txt
 # the group pipeline (opt-in): bench line, kernel stats and a trace excerpt showing the rasteriser of group g+1 beside the fusion of group g
 python bench.py --group-pipeline --no-cpu-baseline --no-host-path > $out/bench_gp.log 2>&1; last $out/bench_gp.log > $out/r02_bench_group_pipeline.json
 python bench.py --group-pipeline --steps 20 --warmup 5 --no-cpu-baseline --no-host-path > $out/bench_gp20.log 2>&1; last $out/bench_gp20.log > $out/r02_bench_group_pipeline_steps20.json
