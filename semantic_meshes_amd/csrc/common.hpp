@@ -117,6 +117,7 @@ struct TriFuseArgs {
   const uint32_t* tex_first;  // [F] first texel id of each triangle
   const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
   uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
+  double* acc_d;              // Mul + texel primitives: [P][C] sums of ONE view's terms, all zero between launches (big triangles only)
 };
 
 // What k_fuse_tri needs to know about ONE of the views it fuses in a launch (the per-view part of TriFuseArgs), and NV of them.

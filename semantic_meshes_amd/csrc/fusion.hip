@@ -1362,9 +1362,35 @@ __device__ __forceinline__ void fuse_big_texel_triangles(const TriFuseArgs& a, u
       const float w = (a.iew * (1.0f / ((float)n)) + (1 - a.iew) * 1.0f) * (a.weights ? a.weights[pix] : 1.0f);
       float* row = a.acc + (uint64_t)v * C;
       if (KIND == SMESH_AGG_SUMMAX) unsafeAtomicAdd(&row[am], best * w);
-      else for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(&row[c], contribution<KIND>(pr[c], w));
+      else if (KIND == SMESH_AGG_MUL) {
+        // a coarse texel of a big triangle receives thousands of pixels: this view's terms are summed in DOUBLE, from zero, in the
+        // aggregator's scratch rows (all zero between launches), and folded into the (hi, lo) row below
+        double* drow = a.acc_d + (uint64_t)v * C;
+        for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(&drow[c], (double)contribution<KIND>(pr[c], w));
+      } else {
+        for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(&row[c], contribution<KIND>(pr[c], w));
+      }
     }
     __threadfence();
+    if constexpr (KIND == SMESH_AGG_MUL) {
+      // Mul ("Mul state", fuse_tri.inc.hpp): the texels that received terms (one lane each: the triangle owns its rows) fold their
+      // double sums into the (hi, lo) row, re-centred on its largest finite element, and leave the scratch row zero again
+      for (uint32_t tx = first + (uint32_t)l; tx - first < cnt; tx += kWave) {
+        if (__hip_atomic_load(&a.count[tx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) continue;
+        float* hi = a.acc + (uint64_t)tx * C;
+        float* lo = a.acc_lo + (uint64_t)tx * C;
+        double* drow = a.acc_d + (uint64_t)tx * C;
+        float m = -INFINITY;
+        for (uint32_t c = 0; c < C; c++) { const float h = hi[c]; if (h > m && h < INFINITY) m = h; }
+        const float centre = m > -INFINITY ? m : 0.0f;
+        for (uint32_t c = 0; c < C; c++) {
+          float h = hi[c], r = lo[c];
+          mul_fold(h, r, centre, __hip_atomic_load(&drow[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+          hi[c] = h; lo[c] = r; drow[c] = 0.0;
+        }
+      }
+      __threadfence();
+    }
     for (long long i = l; i < npx; i += kWave) {
       const uint32_t v = a.idx[(uint64_t)(x0 + (int)(i / bh)) * a.H + (y0 + (int)(i % bh))];
       if (v - first < cnt) a.count[v] = 0u;
@@ -1788,6 +1814,8 @@ struct smesh_aggregator {
   uint32_t S = 0;             // accumulator row stride in floats (C rounded up to 16)
   float* acc = nullptr;       // float32[P*S]
   float* acc_lo = nullptr;    // Mul only: float32[P*S], a row's value is acc + acc_lo (fuse_tri.inc.hpp, "Mul state")
+  double* acc_d = nullptr;    // Mul with texel renderers only (allocated on first use): float64[P*C], one view's terms of the texels of
+                              // big triangles, all zero between launches (k_fuse_texel_big)
   uint32_t* count = nullptr;  // uint32[P], all zero between add() calls
   Scratch st_idx, st_probs, st_w;        // host->device staging
   Scratch nm_idx, nm_probs, nm_w;        // normalised (contiguous) copies
@@ -2071,7 +2099,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     x.big_capacity = big_capacity;
     x.tri_blocks = (uint32_t)div_up(F, kWave);
     { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; x.dbg = fdbg; }
-    x.tex_first = nullptr; x.tex_res = nullptr; x.count = nullptr;
+    x.tex_first = nullptr; x.tex_res = nullptr; x.count = nullptr; x.acc_d = nullptr;
     x.prim_id = prim_id;
   }
   // k_fuse_tri (row in registers; the wave's 64-row block staged through LDS unless the mesh was re-ordered) takes C <= 48: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 48 for the rest
@@ -2165,6 +2193,15 @@ bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P) {
   return !off && a->P == P && a->S == a->C && a->C <= (uint32_t)kSlice;
 }
 
+// Mul: the double scratch of k_fuse_texel_big, on first use.
+static int ensure_acc_d(smesh_aggregator* a) {
+  if (a->kind != SMESH_AGG_MUL || a->acc_d) return SMESH_OK;
+  const size_t bytes = (size_t)a->P * a->C * sizeof(double);
+  SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&a->acc_d), bytes ? bytes : 16));
+  SMESH_HIP(hipMemsetAsync(a->acc_d, 0, bytes, a->ctx->stream));
+  return SMESH_OK;
+}
+
 int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
                                  const uint32_t* tex_res, const uint32_t* big_queue, const uint32_t* big_len,
                                  uint32_t big_capacity, const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t H) {
@@ -2176,9 +2213,10 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
   t.dbg = 0; t.prim_id = nullptr;
-  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count;
+  SMESH_TRY(ensure_acc_d(a));
+  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count; t.acc_d = a->acc_d;
   const dim3 tgrid((uint32_t)div_up(F, kTexelBlock)), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave), tblock(kTexelBlock);
-  SMESH_TRY(mul_recentre(a));
+  // (no pass over the whole accumulator for Mul here: every texel kernel re-centres the rows it touches)
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
     prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, 1);
@@ -2220,9 +2258,10 @@ int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const ui
   t.big_queue = views[0].big_queue; t.big_len = views[0].big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
   t.dbg = 0; t.prim_id = nullptr;
-  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count;
+  SMESH_TRY(ensure_acc_d(a));
+  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count; t.acc_d = a->acc_d;
   const dim3 tgrid((uint32_t)div_up(F, kTexelBlock)), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave), tblock(kTexelBlock);
-  SMESH_TRY(mul_recentre(a));
+  // (no pass over the whole accumulator for Mul here: every texel kernel re-centres the rows it touches)
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
     prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, (uint64_t)nviews);
@@ -2298,6 +2337,7 @@ int smesh_aggregator_destroy(smesh_aggregator_t* a) {
   (void)hipStreamSynchronize(a->ctx->stream);
   (void)hipFree(a->acc);
   if (a->acc_lo) (void)hipFree(a->acc_lo);
+  if (a->acc_d) (void)hipFree(a->acc_d);
   (void)hipFree(a->count);
   if (a->ev_staged) (void)hipEventDestroy(a->ev_staged);
   for (Scratch* s : {&a->st_idx, &a->st_probs, &a->st_w, &a->nm_idx, &a->nm_probs, &a->nm_w, &a->fb_w, &a->fb_amax, &a->pw, &a->out_tmp})

@@ -173,3 +173,45 @@ def test_random_soup_fuse_views_against_oracle(sm, oracle, seed):
         assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)
+
+
+@pytest.mark.parametrize("seed", range(14))
+def test_random_texel_soup_mul_against_the_float64_oracle(sm, oracle, seed):
+    """Mul on texel renderers, triangles of every size: small ones fold each term into the (hi, lo) row in double (k_fuse_texel /
+    k_fuse_texel_multi), the coarse texels of big triangles -- thousands of pixels each -- sum a view's terms in double scratch rows
+    before they are folded (k_fuse_texel_big).  Same bound as Sum / Summax."""
+    import types
+    from semantic_meshes_amd.device import to_device
+    rng = np.random.default_rng(7000 + seed)
+    nfaces = int(rng.choice([60, 500, 2500]))
+    spread = float(rng.choice([0.02, 0.08, 0.4]))
+    verts, faces = _soup(rng, 0, nfaces, spread)
+    W, H = int(rng.choice([64, 200, 333])), int(rng.choice([48, 150]))
+    C = int(rng.choice([2, 7, 19, 40]))
+    iew = float(rng.choice([0.0, 0.5, 1.0]))
+    cams = [_camera(sm, rng, W, H) for _ in range(int(rng.choice([1, 3, 9])))]
+    tpp = float(rng.choice([0.1, 0.5, 1.5]))
+    mesh = types.SimpleNamespace(vertices=verts, faces=faces)
+    r = sm.render.texels(mesh, cams, tpp)
+    o = oracle.OracleRenderer(verts, faces, cams, tpp)
+    P = r.getPrimitivesNum()
+    if P == 0:
+        return
+    probs = []
+    for cam in cams:
+        p = random_probs(rng, W, H, C, zero_fraction=0.1)
+        probs.append(np.where(p.sum(-1, keepdims=True) > 0, np.maximum(p, 1e-3), 0).astype(np.float32))
+    agg = sm.fusion.MeshAggregator(P, C, "mul", iew)
+    if seed % 2:
+        agg.fuse_views(r, cams, [to_device(p) for p in probs])
+    else:
+        for cam, p in zip(cams, probs):
+            agg.fuse_view(r, cam, p)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, "mul", iew)
+        for cam, p in zip(cams, probs):
+            oagg.add(o.render(cam)[0], p)
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
+    finally:
+        oracle.set_accum_double(False)
