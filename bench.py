@@ -407,9 +407,17 @@ def main():
                                                        if hist_regions or raster_regions else None)},
         }
         if world == 1 and not args.no_host_path:
-            out["host_path"] = host_path(renderer, agg, cams, W, H, C, device, views=6 if args.workload != "cfg5" else 2)
+            # side legs: reported beside the headline, never allowed to take it down
+            try:
+                out["host_path"] = host_path(renderer, agg, cams, W, H, C, device, views=6 if args.workload != "cfg5" else 2)
+            except Exception as e:
+                out["host_path"] = {"error": str(e)[:200]}
             if not texels:
-                out["foreign_images"] = foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8 if args.workload != "cfg5" else 4)
+                try:
+                    out["foreign_images"] = foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device,
+                                                           views=8 if args.workload != "cfg5" else 4)
+                except Exception as e:
+                    out["foreign_images"] = {"error": str(e)[:200]}
         if world == 1 and ((args.workload == "cfg2" and not args.no_cpu_baseline) or args.cpu_baseline):
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out), flush=True)
