@@ -419,7 +419,10 @@ def main():
                 except Exception as e:
                     out["foreign_images"] = {"error": str(e)[:200]}
         if world == 1 and ((args.workload == "cfg2" and not args.no_cpu_baseline) or args.cpu_baseline):
-            out["cpu_baseline"] = cpu_baseline(args.workload)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.workload)
+            except Exception as e:      # (the headline line is printed whatever happens to the CPU leg)
+                out["cpu_baseline"] = {"value": None, "unit": "views/s", "cores": 0, "kind": "port", "sample": "failed: " + str(e)[:200]}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
