@@ -264,6 +264,25 @@ class ModelRenderer:
         return out
 
 
+    def render_device(self, primitive_image, background=None):
+        """`render()` with the (W,H,C) image left in HBM: a `DeviceArray` (`__cuda_array_interface__` / DLPack) in a fresh allocation
+        owned by the returned object -- what the harness's `tf.gather(annotations, idx)` (eval_scannet.py:314) produces."""
+        from .device import DeviceBuffer
+        ip, imem, ishape, idt, istr, keep = describe(primitive_image, 2, "primitive image", self.device)
+        if idt not in _IDX_CODES:
+            raise ValueError("primitive image dtype must be one of uint32/int32/uint64/int64, got %s" % idt)
+        bg = np.zeros(self.classes, np.float32) if background is None else np.ascontiguousarray(background, dtype=np.float32)
+        if bg.shape != (self.classes,):
+            raise ValueError("background must have %d entries" % self.classes)
+        W, H = ishape
+        buf = DeviceBuffer(max(W * H * self.classes * 4, 4), self.device)
+        if W * H:
+            _lib.check(_lib.lib().smesh_annotation_renderer_render(
+                self._h, ctypes.c_void_p(ip), _IDX_CODES[idt], _c64(istr), imem, bg.ctypes.data_as(ctypes.c_void_p),
+                ctypes.c_void_p(buf.ptr), _lib.MEM_DEVICE, W, H))
+        return buf.view((W, H, self.classes), np.float32)
+
+
 class MeshAggregatorSum(_MeshAggregator):
     pass
 

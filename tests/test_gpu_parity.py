@@ -379,6 +379,26 @@ def test_annotation_renderer_matches_oracle(sm, oracle):
     got_i64 = agg.renderer().render(np.asarray(idx2).astype(np.int64).T.copy().T, bg)   # host, int64, strided
     np.testing.assert_array_equal(got_i64, got)
     assert (got[np.asarray(idx2) == BG] == bg).all()
+    np.testing.assert_array_equal(np.asarray(agg.renderer().render_device(idx2, bg)), got)   # the image left in HBM
+
+
+@pytest.mark.parametrize("C,shape", [(1, (37, 29)), (19, (333, 257)), (150, (64, 48)), (300, (97, 5)), (7, (1, 1))])
+def test_annotation_renderer_class_counts_and_odd_sizes(sm, C, shape):
+    """k_gather_annotations walks 256-pixel blocks with an incremental (pixel, class) counter: class counts below, at and above
+    the block size, images that are not a multiple of it.  Exact against a numpy gather of get()."""
+    W, H = shape
+    P = 50
+    rng = np.random.default_rng(C)
+    agg = sm.fusion.MeshAggregator(P, C)
+    img = rng.integers(0, P, (W, H)).astype(np.uint32)
+    img[rng.random((W, H)) < 0.2] = BG
+    probs = random_probs(rng, W, H, C, 0.0)
+    agg.add(img, probs)
+    ann = agg.get()
+    bg = rng.random(C, dtype=np.float32)
+    got = agg.renderer().render(img, bg)
+    want = np.where((img != BG)[..., None], ann[np.minimum(img, P - 1)], bg[None, None, :])
+    np.testing.assert_array_equal(got, want.astype(np.float32))
 
 
 def test_dlpack_export_feeds_add(sm, oracle):
