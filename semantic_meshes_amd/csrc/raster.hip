@@ -40,6 +40,7 @@ int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_id
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
 bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a);
 int smesh_aggregator_max_fused_views(smesh_aggregator* a);
+int smesh_aggregator_dense_probs(smesh_aggregator* a, const float* d_probs, const int64_t ps[3], uint64_t W, uint64_t H, const float** out);
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews);
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
@@ -1763,8 +1764,11 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
   if (weights && !w_strides) return fail(SMESH_ERR_INVALID, "weights without strides");
   DeviceCtx* ctx = r->ctx;
   const int64_t C = (int64_t)smesh_aggregator_classes(a);
-  bool fast = smesh_aggregator_ctx(a) == ctx && W != 0 && H != 0 &&
-              probs_strides[0] == (int64_t)H * C && probs_strides[1] == C && probs_strides[2] == 1 &&
+  const bool dense = probs_strides[0] == (int64_t)H * C && probs_strides[1] == C && probs_strides[2] == 1;
+  // class vectors in device memory with other strides (the (H,W,C) tensor of a network seen as (W,H,C): what a framework's
+  // transpose / permute returns) are gathered into the aggregator's scratch first and take the same path
+  const bool strided_dev = !dense && probs_mem == SMESH_MEM_DEVICE && probs_strides[0] >= 0 && probs_strides[1] >= 0 && probs_strides[2] >= 0;
+  bool fast = smesh_aggregator_ctx(a) == ctx && W != 0 && H != 0 && (dense || strided_dev) &&
               (!weights || (w_mem == probs_mem && w_strides[0] == (int64_t)H && w_strides[1] == 1));
   if (fast) {
     std::lock_guard<std::mutex> g(r->mu);
@@ -1781,6 +1785,7 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
       // host synchronisation per view would serialise the reference's two-call loop on launch latencies (0.10 -> 0.21 ms per
       // cfg2 view).  Callers order the buffers' next use after the library with smesh_stream_release (no host wait) or
       // smesh_synchronize; the Python layer does the former for every array that is not the library's own.
+      if (strided_dev) SMESH_TRY(smesh_aggregator_dense_probs(a, probs, probs_strides, W, H, &probs));
       return fuse_rendered(r, a, side, idx_dev, probs, weights, probs_mem, W, H);
     }
   }

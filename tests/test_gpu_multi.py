@@ -283,3 +283,34 @@ def test_bench_under_the_drivers_launcher_world_one(variant):
     # two calls of eight views; the fusion launches of every third call, the first included, are bracketed with events
     assert out["roofline"]["regions_in_timed_loop"] == 2 and out["roofline"]["regions_timed"] == 1
     assert out["roofline"]["launches_by_views"] == {"8": 1} and out["roofline"]["views_per_launch"] == 8 and 0 < out["roofline"]["frac"] < 1.5
+
+
+@pytest.mark.parametrize("C,res", [(19, (320, 240)), (19, (333, 257)), (5, (37, 29)), (40, (320, 240)), (150, (320, 240))])
+def test_permuted_device_probs_take_the_render_records_path(sm, oracle, C, res):
+    """A network's (H,W,C) output seen as (W,H,C) -- torch's `permute(1, 0, 2)`: a strided view in device memory, no copy -- handed
+    to add() with the untouched output of render(): the class vectors are gathered into the aggregator's scratch on the library's
+    stream and the view takes the triangle-order kernels on the rasteriser's records, bit-equal to the dense image."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("torch sees no GPU")
+    mesh, cams = small_scene(120, 60, res[0], res[1], views=3)   # (images that are no multiple of the gather's 32 x 8 tiles too)
+    P = len(mesh.faces)
+    rng = np.random.default_rng(C)
+    r = sm.render.triangles(mesh)
+    a, b = sm.fusion.MeshAggregator(P, C), sm.fusion.MeshAggregator(P, C)
+    oagg = oracle.OracleAggregator(P, C)
+    for k, cam in enumerate(cams):
+        W, H = cam.resolution
+        dense = random_probs(rng, W, H, C)                                   # (W,H,C)
+        hwc = torch.from_numpy(np.ascontiguousarray(dense.transpose(1, 0, 2))).cuda()   # what the network produced: (H,W,C)
+        view = hwc.permute(1, 0, 2)                                          # (W,H,C), strides (C, W*C, 1)
+        assert not view.is_contiguous()
+        idx, _ = r.render(cam)
+        a.add(idx, view)
+        assert sm._lib.lib().smesh_last_add_path().decode() == ("scatter" if os.environ.get("SMESH_FUSE") == "strip" else "render-records")
+        b.fuse_view(r, cam, dense)
+        oagg.add(np.asarray(idx), dense)
+    sm._lib.synchronize(0)
+    if os.environ.get("SMESH_FUSE") != "strip":
+        np.testing.assert_array_equal(a.get_raw().view(np.uint32), b.get_raw().view(np.uint32))
+    assert_fused_close(a.get(), oagg.get())
