@@ -1721,9 +1721,13 @@ __device__ __forceinline__ void finalize_row(float* row, int C) {
   for (int c = 0; c < C; c++) row[c] = nan_inf_to_zero(row[c] / n);
 }
 
-template <int KIND, int TP>
-__global__ __launch_bounds__(TP) void k_finalize_tile(const float* __restrict__ acc, float* __restrict__ out,
-                                                      uint64_t P, int C, int S) {
+// One workgroup of 256 threads = TP consecutive rows (TP C floats of LDS): all threads move the tile in and out with coalesced
+// 16-byte accesses, threads 0 .. TP-1 then apply the functor chain to one row each, in the reference's sequential order.  (Round 1
+// launched TP threads per workgroup -- a single wave at 150 classes, four of them per CU -- and left rows beyond 220 classes to a
+// thread-per-row kernel with uncoalesced accesses: 0.19 TB/s at C = 300.)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_finalize_tile(const float* __restrict__ acc, float* __restrict__ out,
+                                                       uint64_t P, int C, int S, int TP) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sp = reinterpret_cast<float*>(smem);
   const int t = threadIdx.x;
@@ -1732,19 +1736,31 @@ __global__ __launch_bounds__(TP) void k_finalize_tile(const float* __restrict__ 
   const int nfl = nrows * C;
   const float* __restrict__ src = acc + r0 * (uint64_t)S;
   float* __restrict__ dst = out + r0 * (uint64_t)C;
-  for (int e = t; e < nfl; e += TP) {
-    const int rr = e / C, c = e - rr * C;
-    sp[e] = src[(uint64_t)rr * S + c];
+  if (S == C) {        // dense rows (the layout in use): the tile is one contiguous run, no division per float
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+      const float4* src4 = reinterpret_cast<const float4*>(src);
+      float4* sp4w = reinterpret_cast<float4*>(sp);
+      for (int e = t; e < (nfl >> 2); e += 256) sp4w[e] = src4[e];
+      for (int e = (nfl & ~3) + t; e < nfl; e += 256) sp[e] = src[e];
+    } else {
+      for (int e = t; e < nfl; e += 256) sp[e] = src[e];
+    }
+  } else {
+    for (int e = t; e < nfl; e += 256) {
+      const int rr = e / C, c = e - rr * C;
+      sp[e] = src[(uint64_t)rr * S + c];
+    }
   }
   __syncthreads();
   if (t < nrows) finalize_row<KIND>(sp + t * C, C);
   __syncthreads();
-  if (nrows == TP && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+  if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
     const float4* sp4 = reinterpret_cast<const float4*>(sp);
     float4* dst4 = reinterpret_cast<float4*>(dst);
-    for (int e = t; e < (nfl >> 2); e += TP) dst4[e] = sp4[e];
+    for (int e = t; e < (nfl >> 2); e += 256) dst4[e] = sp4[e];
+    for (int e = (nfl & ~3) + t; e < nfl; e += 256) dst[e] = sp[e];
   } else {
-    for (int e = t; e < nfl; e += TP) dst[e] = sp[e];
+    for (int e = t; e < nfl; e += 256) dst[e] = sp[e];
   }
 }
 
@@ -1803,11 +1819,12 @@ inline size_t strip_lds_bytes(uint32_t C) {
 inline bool strip_path(uint32_t C) { return strip_lds_bytes(C) <= 64 * 1024; }
 
 // rows per finalize tile
+// Rows per workgroup of k_finalize_tile: a multiple of four (16-byte alignment of every tile), at most 256, about 32 KB of LDS
+// (64 KB for the widest rows); 0: rows too wide for LDS tiles.
 inline int tile_pixels(uint32_t C) {
-  if (C <= 48) return 256;
-  if (C <= 100) return 128;
-  if (C <= 220) return 64;
-  return 0;
+  if (C > 4000) return 0;
+  const int tp = (int)((8192u / C) & ~3u);
+  return tp >= 4 ? std::min(tp, 256) : 4;
 }
 
 void set_tiling(ScatterArgs& a) {
@@ -2512,18 +2529,11 @@ static int finalize_into(smesh_aggregator* a, float* d_out) {
   if (TP) {
     const size_t lds = (((size_t)TP * C + 3) & ~(size_t)3) * 4;
     const dim3 g((uint32_t)div_up(a->P, TP));
-#define SMESH_FIN(K)                                                                                          \
-    switch (TP) {                                                                                             \
-      case 256: hipLaunchKernelGGL((k_finalize_tile<K, 256>), g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break; \
-      case 128: hipLaunchKernelGGL((k_finalize_tile<K, 128>), g, dim3(128), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break; \
-      default:  hipLaunchKernelGGL((k_finalize_tile<K, 64>), g, dim3(64), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break;  \
-    }
     switch (a->kind) {
-      case SMESH_AGG_SUM: SMESH_FIN(SMESH_AGG_SUM); break;
-      case SMESH_AGG_SUMMAX: SMESH_FIN(SMESH_AGG_SUMMAX); break;
-      default: SMESH_FIN(SMESH_AGG_MUL); break;
+      case SMESH_AGG_SUM:    hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUM>, g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S, TP); break;
+      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUMMAX>, g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S, TP); break;
+      default:               hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_MUL>, g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S, TP); break;
     }
-#undef SMESH_FIN
   } else {
     const dim3 g((uint32_t)div_up(a->P, 256)), b(256);
     switch (a->kind) {
