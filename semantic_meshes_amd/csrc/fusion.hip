@@ -1726,7 +1726,7 @@ __device__ __forceinline__ void finalize_row(float* row, int C) {
 // launched TP threads per workgroup -- a single wave at 150 classes, four of them per CU -- and left rows beyond 220 classes to a
 // thread-per-row kernel with uncoalesced accesses: 0.19 TB/s at C = 300.)
 template <int KIND>
-__global__ __launch_bounds__(256) void k_finalize_tile(const float* __restrict__ acc, float* __restrict__ out,
+__global__ __launch_bounds__(256) void k_finalize_tile(const float* __restrict__ acc, const float* __restrict__ acc_lo, float* __restrict__ out,
                                                        uint64_t P, int C, int S, int TP) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* sp = reinterpret_cast<float*>(smem);
@@ -1749,6 +1749,27 @@ __global__ __launch_bounds__(256) void k_finalize_tile(const float* __restrict__
     for (int e = t; e < nfl; e += 256) {
       const int rr = e / C, c = e - rr * C;
       sp[e] = src[(uint64_t)rr * S + c];
+    }
+  }
+  if (KIND == SMESH_AGG_MUL && acc_lo) {
+    // Mul ("Mul state", fuse_tri.inc.hpp): a row is hi + lo.  The lo tile sits behind the hi tile in LDS; the row's thread centres
+    // the pair on its largest finite element in double and leaves the float32 values k_mul_normalise would have left in the hi
+    // plane -- without writing the state back (get() used to run that kernel over the whole accumulator first: a thread per row,
+    // 0.11-0.15 TB/s).
+    float* sl = sp + (((size_t)TP * C + 3) & ~(size_t)3);
+    const float* __restrict__ lsrc = acc_lo + r0 * (uint64_t)S;
+    for (int e = t; e < nfl; e += 256) {
+      const int rr = S == C ? 0 : e / C;
+      sl[e] = S == C ? lsrc[e] : lsrc[(uint64_t)rr * S + (e - rr * C)];
+    }
+    __syncthreads();
+    if (t < nrows) {
+      float* hi = sp + t * C;
+      const float* lo = sl + t * C;
+      double m = -INFINITY;
+      for (int c = 0; c < C; c++) { const double v = (double)hi[c] + (double)lo[c]; if (v > m && v < INFINITY) m = v; }
+      if (!(m > -INFINITY)) m = 0.0;
+      for (int c = 0; c < C; c++) hi[c] = (float)(((double)hi[c] + (double)lo[c]) - m);
     }
   }
   __syncthreads();
@@ -2522,17 +2543,21 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
 static int finalize_into(smesh_aggregator* a, float* d_out) {
   DeviceCtx* ctx = a->ctx;
   if (a->P == 0) return SMESH_OK;
-  SMESH_TRY(mul_normalise(a, false));   // Mul: centred rows, the hi plane alone now carries the elements that matter to 2^-24
   ProfScope prof(ctx, SMESH_PROF_FINALIZE);
-  const int TP = tile_pixels(a->C);
+  int TP = tile_pixels(a->C);
   const int C = (int)a->C;
+  // Mul rows of up to 512 classes are centred inside the tile kernel (hi and lo tiles in LDS); wider ones -- a handful of rows per
+  // tile, whose threads would walk them alone -- by k_mul_normalise over the whole accumulator first, as in round 1
+  const bool mul = a->kind == SMESH_AGG_MUL && C <= 512;
+  if (mul) TP = std::max(4, (TP / 2) & ~3);
+  if (a->kind == SMESH_AGG_MUL && !mul) SMESH_TRY(mul_normalise(a, false));
   if (TP) {
-    const size_t lds = (((size_t)TP * C + 3) & ~(size_t)3) * 4;
+    const size_t lds = (((size_t)TP * C + 3) & ~(size_t)3) * 4 * (mul ? 2 : 1);
     const dim3 g((uint32_t)div_up(a->P, TP));
     switch (a->kind) {
-      case SMESH_AGG_SUM:    hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUM>, g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S, TP); break;
-      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUMMAX>, g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S, TP); break;
-      default:               hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_MUL>, g, dim3(256), lds, ctx->stream, a->acc, d_out, a->P, C, (int)a->S, TP); break;
+      case SMESH_AGG_SUM:    hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUM>, g, dim3(256), lds, ctx->stream, a->acc, nullptr, d_out, a->P, C, (int)a->S, TP); break;
+      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUMMAX>, g, dim3(256), lds, ctx->stream, a->acc, nullptr, d_out, a->P, C, (int)a->S, TP); break;
+      default:               hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_MUL>, g, dim3(256), lds, ctx->stream, a->acc, mul ? a->acc_lo : nullptr, d_out, a->P, C, (int)a->S, TP); break;
     }
   } else {
     const dim3 g((uint32_t)div_up(a->P, 256)), b(256);
