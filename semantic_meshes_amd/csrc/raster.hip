@@ -889,6 +889,7 @@ struct smesh_renderer {
   bool rec_valid[kRecordSides] = {};
   bool hash_valid[kRecordSides] = {};   // d_hash[s] holds the checksum of the plane (smesh_renderer_seal_render)
   unsigned long long* d_hash = nullptr;
+  hipEvent_t hash_ev[kRecordSides] = {};   // recorded on the main stream behind the kernel that writes d_hash[s]
   Scratch match_stage;             // device copy of a host index image that is being looked up
   bool raster_pending = false;     // work queued on the raster stream since the last synchronisation
   bool main_pending = false;       // renderer state (keys, scratch) used on the main stream since then
@@ -915,10 +916,10 @@ __global__ __launch_bounds__(256) void k_plane_checksum(const uint32_t* __restri
   // one atomic per workgroup: atomics on ONE address are served one after the other (8192 of them took 99 us)
   if (threadIdx.x == 0) atomicAdd(out, ((part[0] + part[1]) + part[2]) + part[3]);
 }
-int plane_checksum(DeviceCtx* ctx, const uint32_t* d_img, uint64_t N, unsigned long long* d_out) {
-  SMESH_HIP(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), ctx->stream));
+int plane_checksum(DeviceCtx* ctx, hipStream_t st, const uint32_t* d_img, uint64_t N, unsigned long long* d_out) {
+  SMESH_HIP(hipMemsetAsync(d_out, 0, sizeof(unsigned long long), st));
   const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(div_up(N, 256 * 16), (uint64_t)ctx->num_cus));
-  hipLaunchKernelGGL(k_plane_checksum, dim3(blocks), dim3(256), 0, ctx->stream, d_img, N, d_out);
+  hipLaunchKernelGGL(k_plane_checksum, dim3(blocks), dim3(256), 0, st, d_img, N, d_out);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
@@ -1474,6 +1475,8 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   r->own_idx.release();
   r->match_stage.release();
   if (r->d_hash) (void)hipFree(r->d_hash);
+  for (int sd = 0; sd < kRecordSides; sd++)
+    if (r->hash_ev[sd]) (void)hipEventDestroy(r->hash_ev[sd]);
   for (auto& f : r->fused) f.release();
   for (int i = 0; i < 2; i++) {
     if (i == 0 && r->ev_main_fence) (void)hipEventDestroy(r->ev_main_fence);
@@ -1829,10 +1832,21 @@ int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
     SMESH_HIP(hipMemcpyAsync(r->match_stage.ptr, indices, N * 4, hipMemcpyHostToDevice, ctx->stream));
     d_img = static_cast<const uint32_t*>(r->match_stage.ptr);
   }
-  SMESH_TRY(plane_checksum(ctx, d_img, N, r->d_hash + kRecordSides));
+  // The look-up must not drain the main stream (the previous views' fusion kernels are still queued there: waiting for them made an
+  // exported-and-returned plane cost 0.34 ms per cfg2 view).  An image in DEVICE memory is checksummed on the raster stream, which
+  // the caller has ordered behind the image's producer like the main stream (smesh_stream_wait) and which only has to wait for the
+  // kernels that sealed the candidate planes (hash_ev); the host then waits for that stream alone.  HOST images are staged on the
+  // main stream (the staging buffer is read again by the fusion).
+  hipStream_t ps = ctx->stream;
+  if (idx_mem != SMESH_MEM_HOST) {
+    ps = ctx->raster_stream;
+    for (int sd = 0; sd < kRecordSides; sd++)
+      if (r->hash_valid[sd] && r->hash_ev[sd]) SMESH_HIP(hipStreamWaitEvent(ps, r->hash_ev[sd], 0));
+  }
+  SMESH_TRY(plane_checksum(ctx, ps, d_img, N, r->d_hash + kRecordSides));
   unsigned long long h[kRecordSides + 1];
-  SMESH_HIP(hipMemcpyAsync(h, r->d_hash, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
-  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  SMESH_HIP(hipMemcpyAsync(h, r->d_hash, sizeof h, hipMemcpyDeviceToHost, ps));
+  SMESH_HIP(hipStreamSynchronize(ps));
   int side = -1;
   for (int sd = 0; sd < kRecordSides; sd++)
     if (r->rec_valid[sd] && r->hash_valid[sd] && r->last_W[sd] == W && r->last_H[sd] == H && h[sd] == h[kRecordSides]) side = sd;
@@ -1858,7 +1872,9 @@ int smesh_renderer_seal_render(smesh_renderer_t* r, const uint32_t* indices_dev)
       SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&r->d_hash), (kRecordSides + 1) * sizeof(unsigned long long)));
       SMESH_HIP(hipMemsetAsync(r->d_hash, 0, (kRecordSides + 1) * sizeof(unsigned long long), ctx->stream));
     }
-    SMESH_TRY(plane_checksum(ctx, indices_dev, r->last_W[sd] * r->last_H[sd], r->d_hash + sd));
+    SMESH_TRY(plane_checksum(ctx, ctx->stream, indices_dev, r->last_W[sd] * r->last_H[sd], r->d_hash + sd));
+    if (!r->hash_ev[sd]) SMESH_HIP(hipEventCreateWithFlags(&r->hash_ev[sd], hipEventDisableTiming));
+    SMESH_HIP(hipEventRecord(r->hash_ev[sd], ctx->stream));
     r->hash_valid[sd] = true;
   }
   return SMESH_OK;
