@@ -280,11 +280,26 @@ def main():
                 dist.barrier()
                 torch.cuda.synchronize(device)
 
+    exchange = os.environ.get("SMESH_EXCHANGE", "allreduce")      # "reduce_scatter": opt-in, each rank ends up owning P / N rows
+    if exchange not in ("allreduce", "reduce_scatter"):
+        raise SystemExit("SMESH_EXCHANGE must be allreduce or reduce_scatter")
+    owned = [0, P]
+
     def allreduce():
-        if comm is not None:
+        if exchange == "reduce_scatter" and (comm is not None or dist is not None):
+            owned[:] = smdist.reduce_scatter_raw(agg, comm=comm)
+        elif comm is not None:
             comm.allreduce(agg)       # asynchronous: enqueued behind the last fusion kernel
         elif dist is not None:
             smdist.allreduce_raw(agg)
+
+    def mark(i):
+        _lib.check(_lib.lib().smesh_stream_mark(device, i))    # an event record on the library stream, no host wait
+
+    def elapsed(i, j):
+        ms = ctypes.c_double()
+        _lib.check(_lib.lib().smesh_stream_mark_elapsed(device, i, j, ctypes.byref(ms)))
+        return ms.value
 
     B = max(1, args.views_per_call)
 
@@ -326,24 +341,40 @@ def main():
     barrier()
     _lib.synchronize(device)
     t0 = time.perf_counter()
+    mark(0)
     fuse_range(args.warmup, total_views)
+    mark(1)
     allreduce()
+    mark(2)
     barrier()                      # the only host synchronisation of the timed region
     dt = time.perf_counter() - t0
     _lib.check(_lib.lib().smesh_profile_enable(device, 0))
+    # where this rank's device time went: marks 0 -> 1 = its views (render + fuse), 1 -> 2 = the exchange as this rank saw it
+    # (its own transfers AND the wait for the slowest rank to arrive).  Over all ranks: the max of each.
+    compute_ms, exchange_ms = elapsed(0, 1), elapsed(1, 2)
+    compute_ms_max, exchange_ms_max, exchange_ms_min = compute_ms, exchange_ms, exchange_ms
     if comm is not None:
-        dt = comm.reduce_scalars([dt], "max")[0]
+        dt, compute_ms_max, exchange_ms_max, neg_min = comm.reduce_scalars([dt, compute_ms, exchange_ms, -exchange_ms], "max")
+        exchange_ms_min = -neg_min
     elif dist is not None:
         import torch
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % device)
+        t = torch.tensor([dt, compute_ms, exchange_ms, -exchange_ms], dtype=torch.float64, device="cuda:%d" % device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, compute_ms_max, exchange_ms_max, neg_min = (float(v) for v in t.tolist())
+        exchange_ms_min = -neg_min
 
     t1 = time.perf_counter()
-    fused = agg.get()
+    fused = agg.get() if exchange == "allreduce" else agg.get_rows(*owned)
     get_ms = 1e3 * (time.perf_counter() - t1)
     annotated = int((fused.sum(axis=1) > 0.9).sum())
     del fused
+    nranks_reported = world
+    if comm is not None:
+        rk, nr = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().smesh_comm_rank(comm._h, ctypes.byref(rk), ctypes.byref(nr)))
+        nranks_reported = int(nr.value)        # what the RCCL communicator itself spans
+    elif dist is not None:
+        nranks_reported = dist.get_world_size()
 
     fuse_kernel = _lib.lib().smesh_last_fuse_kernel().decode()
     k_ms, k_regions, k_launches, k_views = prof_read(device, _lib.PROF_FUSE_SCATTER)
@@ -411,8 +442,14 @@ def main():
                                    % (args.workload, F, " as %d texel primitives" % P if texels else "", args.steps, W, H, C),
                        "views_per_call": B,
                        "group_pipeline": bool(int(os.environ.get("SMESH_GROUP_PIPELINE", "0") or 0)),
-                       "sharding": "views dp%d, one RCCL all-reduce of float32[P,C]" % world,
-                       "allreduce": allreduce_impl,
+                       "sharding": "views dp%d, one RCCL %s of float32[P,C]" % (world, exchange.replace("_", "-")),
+                       "allreduce": allreduce_impl, "exchange": exchange, "nranks": nranks_reported,
+                       # the exchange moves the raw accumulator once: ring all-reduce 2 (N-1)/N x, reduce-scatter (N-1)/N x per link
+                       "allreduce_bytes": int(4 * P * C) if launched else 0,
+                       "compute_ms": round(compute_ms_max, 3), "exchange_ms": round(exchange_ms_max, 3),
+                       "exchange_ms_fastest_rank": round(exchange_ms_min, 3),
+                       "rank0": {"compute_ms": round(compute_ms, 3), "exchange_ms": round(exchange_ms, 3)},
+                       "timed_region_ms": round(1e3 * dt, 3),
                        "host_syncs_in_timed_region": 1 if (comm is not None or dist is None) else 4,
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
             "roofline": {"kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),

@@ -90,6 +90,12 @@ int smesh_stream_wait(int device, void* producer_stream);
  * owner of a DEVICE buffer can overwrite or free it on that stream without a host synchronisation. */
 int smesh_stream_release(int device, void* consumer_stream);
 int smesh_stream_handle(int device, void** stream);
+/* Time stamps on the library's main stream (new; a harness's view of where a job's device time went without a profiler):
+ * smesh_stream_mark records mark `id` (0 .. 15) behind everything queued so far -- no host synchronisation;
+ * smesh_stream_mark_elapsed waits for mark `to` and returns the device milliseconds between the two marks. */
+#define SMESH_STREAM_MARKS 16
+int smesh_stream_mark(int device, int id);
+int smesh_stream_mark_elapsed(int device, int from, int to, double* ms);
 
 /* ---- triangle renderer --------------------------------------------------------------------- */
 /* Replaces TriangleRenderer::TriangleRenderer (include/semantic_meshes/render/TriangleRenderer.h:30-39):
@@ -154,6 +160,10 @@ int smesh_aggregator_add(smesh_aggregator_t* a,
  * the chosen aggregator (Fusion.cu:47-49 / 67-69 / 79-82; Fusion.h:79-104): writes float32[P,C]. */
 int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind);
 
+/* smesh_aggregator_get for the rows [row_lo, row_hi) only (row_lo a multiple of 4): writes float32[row_hi - row_lo, C].
+ * New: what a rank calls after smesh_reduce_scatter. */
+int smesh_aggregator_get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, float* out, int memkind);
+
 /* Un-normalised accumulator state float32[P,C] (Sum/Summax: weighted sums; Mul: log-domain sums).
  * New functionality: this is what is summed across GPUs before get(). */
 int smesh_aggregator_get_raw(smesh_aggregator_t* a, float* out, int memkind);
@@ -182,6 +192,12 @@ int smesh_comm_rank(const smesh_comm_t* c, int* rank, int* nranks);
  * right behind the fusion kernels already queued there; smesh_aggregator_get / smesh_synchronize order after it.  Every rank's
  * aggregator must have the same num_primitives, num_classes and kind. */
 int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs, int n);
+/* Opt-in alternative to smesh_allreduce: ONE in-place ncclReduceScatter (half the bytes per xGMI link).  Afterwards rank r holds the
+ * sum over all ranks in rows [*row_lo, *row_hi) of its accumulator: q = floor(P / nranks / 4) * 4 rows per rank (every slice starts
+ * on a 16-byte boundary), the < 5 * nranks rows beyond nranks * q are all-reduced and counted into the last rank's range.  The other
+ * rows keep the rank's own partial sums, so only smesh_aggregator_get_rows(a, *row_lo, *row_hi, ...) is meaningful afterwards: each
+ * rank normalises (Fusion.h:79-104) its own slice.  Asynchronous like smesh_allreduce. */
+int smesh_reduce_scatter(smesh_comm_t* c, smesh_aggregator_t* a, uint64_t* row_lo, uint64_t* row_hi);
 /* Blocking reduction of `n` <= 64 host doubles over the communicator (op 0 = sum, 2 = max): a harness's barrier and its
  * max-over-ranks clock without a second communication library. */
 int smesh_comm_allreduce_f64(smesh_comm_t* c, double* values, int n, int op);
@@ -261,6 +277,7 @@ const char* smesh_last_add_path(void);
 #define SMESH_PROF_FUSE_HIST    1   /* per-view histogram (Mesh.h:90-93)       */
 #define SMESH_PROF_RASTER       2   /* all rasterizer kernels of one render    */
 #define SMESH_PROF_FINALIZE     3   /* get() normalisation                     */
+#define SMESH_PROF_EXCHANGE     4   /* the RCCL all-reduce / reduce-scatter    */
 #define SMESH_PROF_SLOTS        8
 int smesh_profile_enable(int device, int slot_mask);
 /* Bracket only every n-th region of an enabled slot (default 1 = all): a HIP event pair costs ~4 us of stream

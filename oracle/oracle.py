@@ -161,6 +161,7 @@ def _strides(arr):
 class OracleAggregator:
     def __init__(self, primitives, classes, aggregator="sum", images_equal_weight=0.5):
         self.P, self.C = int(primitives), int(classes)
+        self.primitives, self.classes = self.P, self.C     # (the product aggregator's attribute names)
         self._h = ctypes.c_void_p()
         _check(lib().smesh_aggregator_create(ctypes.c_uint64(self.P), ctypes.c_uint32(self.C), AGG_KINDS[aggregator.lower()],
                                              ctypes.c_float(images_equal_weight), 0, ctypes.byref(self._h)))
@@ -201,6 +202,12 @@ class OracleAggregator:
     def get(self):
         out = np.empty((self.P, self.C), np.float32)
         _check(lib().smesh_aggregator_get(self._h, out.ctypes.data_as(ctypes.c_void_p), 0))
+        return out
+
+    def get_rows(self, row_lo, row_hi):
+        out = np.empty((int(row_hi) - int(row_lo), self.C), np.float32)
+        _check(lib().smesh_aggregator_get_rows(self._h, ctypes.c_uint64(int(row_lo)), ctypes.c_uint64(int(row_hi)),
+                                               out.ctypes.data_as(ctypes.c_void_p), 0))
         return out
 
     def get_raw(self):

@@ -45,7 +45,7 @@ bool g_fast_histogram = false;  // "optimised CPU" baseline variant: dense paral
 // ---------------------------------------------------------------------------------------------
 // Raster spec (DESIGN.md "Raster spec"); protocol from TriangleRenderer.h:30-39,46-61,63-89.
 // ---------------------------------------------------------------------------------------------
-constexpr float kNear = 1e-6f;  // triangles with a vertex at z_c <= kNear are dropped whole (B-3)
+constexpr float kNear = 1e-6f;  // near plane z_c = kNear: triangles crossing it are CLIPPED against it (round 3; B-3), see clip_triangle
 
 struct ScreenVertex {
   double u, v;  // pixel coordinates: f * (Xc.xy / Xc.z) + c  (render/Camera.h:10-11 -- double intrinsics)
@@ -176,6 +176,80 @@ inline uint32_t texel_index(uint32_t res, double b1, double b2) {
   return (uint32_t)(row * (row + 1) / 2 + tu);
 }
 
+// ---- near-plane clipping (round 3; DESIGN.md "Raster spec" #1b) ---------------------------------------------------------------
+// A vertex is FRONT when its float32 camera-space z is > kNear and everything about it is finite (project_vertex gives it screen
+// coordinates), BEHIND when its camera-space coordinates are finite and z <= kNear, UNUSABLE otherwise.  A triangle with an unusable
+// vertex, or with no front vertex, emits nothing.  A triangle with front AND behind vertices is cut along the plane z_c = kNear:
+// on every edge from a front vertex F to a behind vertex B the point I = F + t (B - F), t = (zF - n) / (zF - zB), is computed in
+// double FROM THE FRONT VERTEX (both triangles sharing the edge compute the same I bit for bit, so the cut edge F-I stays
+// watertight), projected with z = n exactly.  One front vertex F (cyclic order F, N, P): the triangle (F, I_FN, I_FP).  Two front
+// vertices (cyclic order B, N, P): the quadrilateral I_NB, N, P, I_PB as the two triangles (N, P, I_PB) and (N, I_PB, I_NB).
+// The pieces are rasterised like any triangle (same edge functions, fill rule, depth formula with the pieces' own 1/z) and write the
+// id of the triangle they came from.  Texel primitives: the pieces carry the original triangle's barycentric coordinates (b1, b2) at
+// their vertices and interpolate them perspective-correctly (the screen-space weights of an unclipped triangle are not defined for
+// a triangle with a vertex behind the camera).
+struct CamVertex { float x, y, z; int status; };   // status: 0 front, 1 behind, 2 unusable
+inline CamVertex camera_vertex(const smesh_camera_t& cam, const float* p, const ScreenVertex& s) {
+  const float* R = cam.rotation;
+  const float* t = cam.translation;
+  CamVertex c;
+  c.x = ((R[0] * p[0] + R[1] * p[1]) + R[2] * p[2]) + t[0];
+  c.y = ((R[3] * p[0] + R[4] * p[1]) + R[5] * p[2]) + t[1];
+  c.z = ((R[6] * p[0] + R[7] * p[1]) + R[8] * p[2]) + t[2];
+  if (s.iz != 0.0) c.status = 0;
+  else if (std::isfinite(c.x) && std::isfinite(c.y) && std::isfinite(c.z) && !(c.z > kNear)) c.status = 1;
+  else c.status = 2;
+  return c;
+}
+
+struct ClipVertex { ScreenVertex s; double b1, b2; };   // screen vertex + barycentric coordinates in the original triangle
+
+// The point where the edge from front vertex F to behind vertex B meets the near plane.  Returns false if it does not project.
+inline bool clip_edge(const smesh_camera_t& cam, const CamVertex& F, double fb1, double fb2, const CamVertex& B, double bb1, double bb2,
+                      ClipVertex* out) {
+  const double zn = (double)kNear;
+  const double t = ((double)F.z - zn) / ((double)F.z - (double)B.z);
+  const double x = std::fma(t, (double)B.x - (double)F.x, (double)F.x);
+  const double y = std::fma(t, (double)B.y - (double)F.y, (double)F.y);
+  const double u = cam.focal[0] * (x / zn) + cam.principal[0];
+  const double v = cam.focal[1] * (y / zn) + cam.principal[1];
+  if (!std::isfinite(u) || !std::isfinite(v)) return false;
+  out->s.u = u; out->s.v = v; out->s.iz = 1.0 / zn;
+  out->b1 = std::fma(t, bb1 - fb1, fb1);
+  out->b2 = std::fma(t, bb2 - fb2, fb2);
+  return true;
+}
+
+// Pieces of a triangle that crosses the near plane: 0, 1 or 2 triangles of ClipVertex.
+inline int clip_triangle(const smesh_camera_t& cam, const CamVertex cv[3], const ScreenVertex sv[3], ClipVertex out[2][3]) {
+  static const double B1[3] = {0.0, 1.0, 0.0}, B2[3] = {0.0, 0.0, 1.0};   // (b1, b2) of the original vertices a, b, c
+  int nfront = 0;
+  for (int k = 0; k < 3; k++) {
+    if (cv[k].status == 2) return 0;
+    nfront += cv[k].status == 0;
+  }
+  if (nfront == 0 || nfront == 3) return 0;
+  auto orig = [&](int k) { ClipVertex c; c.s = sv[k]; c.b1 = B1[k]; c.b2 = B2[k]; return c; };
+  if (nfront == 1) {
+    int f = 0;
+    while (cv[f].status != 0) f++;
+    const int n = (f + 1) % 3, p = (f + 2) % 3;
+    out[0][0] = orig(f);
+    if (!clip_edge(cam, cv[f], B1[f], B2[f], cv[n], B1[n], B2[n], &out[0][1])) return 0;
+    if (!clip_edge(cam, cv[f], B1[f], B2[f], cv[p], B1[p], B2[p], &out[0][2])) return 0;
+    return 1;
+  }
+  int b = 0;
+  while (cv[b].status != 1) b++;
+  const int n = (b + 1) % 3, p = (b + 2) % 3;
+  ClipVertex inb, ipb;
+  if (!clip_edge(cam, cv[n], B1[n], B2[n], cv[b], B1[b], B2[b], &inb)) return 0;
+  if (!clip_edge(cam, cv[p], B1[p], B2[p], cv[b], B1[b], B2[b], &ipb)) return 0;
+  out[0][0] = orig(n); out[0][1] = orig(p); out[0][2] = ipb;
+  out[1][0] = orig(n); out[1][1] = ipb;     out[1][2] = inb;
+  return 2;
+}
+
 }  // namespace
 
 struct smesh_renderer {
@@ -187,6 +261,7 @@ struct smesh_renderer {
   uint64_t num_primitives = 0;
   std::vector<uint64_t> keys;
   std::vector<ScreenVertex> sv;
+  std::vector<CamVertex> cv;
 };
 
 struct smesh_aggregator {
@@ -338,30 +413,59 @@ int smesh_renderer_render(smesh_renderer_t* r, const smesh_camera_t* cam, uint32
   const uint64_t N = W * H;
   r->keys.assign(N, kBackgroundKey);  // {z=+inf, primitive_index=-1}
   r->sv.resize(r->V);
+  r->cv.resize(r->V);
   const bool par = g_threads > 1;
 #pragma omp parallel for num_threads(g_threads) schedule(static) if (par)
-  for (int64_t v = 0; v < (int64_t)r->V; v++) r->sv[v] = project_vertex(*cam, &r->verts[3 * v]);
+  for (int64_t v = 0; v < (int64_t)r->V; v++) {
+    r->sv[v] = project_vertex(*cam, &r->verts[3 * v]);
+    r->cv[v] = camera_vertex(*cam, &r->verts[3 * v], r->sv[v]);
+  }
 #pragma omp parallel for num_threads(g_threads) schedule(dynamic, 1024) if (par)
   for (int64_t f = 0; f < (int64_t)r->F; f++) {
     const int32_t* face = &r->faces[3 * f];
     if (face[0] < 0 || face[1] < 0 || face[2] < 0) continue;
     if ((uint64_t)face[0] >= r->V || (uint64_t)face[1] >= r->V || (uint64_t)face[2] >= r->V) continue;
-    const TriSetup t = setup_triangle(r->sv[face[0]], r->sv[face[1]], r->sv[face[2]], W, H);
-    if (!t.ok) continue;
     if (r->texels && r->tex_res[f] == 0) continue;  // a triangle without texels has no primitive to write
-    for (int x = t.x0; x <= t.x1; x++) {
-      for (int y = t.y0; y <= t.y1; y++) {
-        double w[3];
-        if (!cover(t, (double)x + 0.5, (double)y + 0.5, w)) continue;
-        float z;
-        if (!depth_at(t, w, &z)) continue;
-        uint32_t prim = (uint32_t)f;  // Shader: primitive ordinal (TriangleRenderer.h:57-60)
-        if (r->texels) {
-          const double num = (w[0] + w[1]) + w[2];
-          prim = r->tex_first[f] + texel_index(r->tex_res[f], w[1] / num, w[2] / num);  // TexturedTriangleRenderer.h:193-196
+    // the triangle itself, or the one or two pieces left of it in front of the near plane
+    ClipVertex piece[2][3];
+    int npieces = 1;
+    bool clipped = false;
+    const ScreenVertex tsv[3] = {r->sv[face[0]], r->sv[face[1]], r->sv[face[2]]};
+    if (tsv[0].iz == 0.0 || tsv[1].iz == 0.0 || tsv[2].iz == 0.0) {
+      const CamVertex tcv[3] = {r->cv[face[0]], r->cv[face[1]], r->cv[face[2]]};
+      npieces = clip_triangle(*cam, tcv, tsv, piece);
+      clipped = true;
+    } else {
+      piece[0][0].s = tsv[0]; piece[0][1].s = tsv[1]; piece[0][2].s = tsv[2];
+    }
+    for (int pc = 0; pc < npieces; pc++) {
+      const ClipVertex* q = piece[pc];
+      const TriSetup t = setup_triangle(q[0].s, q[1].s, q[2].s, W, H);
+      if (!t.ok) continue;
+      for (int x = t.x0; x <= t.x1; x++) {
+        for (int y = t.y0; y <= t.y1; y++) {
+          double w[3];
+          if (!cover(t, (double)x + 0.5, (double)y + 0.5, w)) continue;
+          float z;
+          if (!depth_at(t, w, &z)) continue;
+          uint32_t prim = (uint32_t)f;  // Shader: primitive ordinal (TriangleRenderer.h:57-60)
+          if (r->texels) {
+            double b1, b2;
+            if (!clipped) {
+              const double num = (w[0] + w[1]) + w[2];
+              b1 = w[1] / num; b2 = w[2] / num;                         // TexturedTriangleRenderer.h:193-196
+            } else {
+              // perspective-correct interpolation of the original triangle's (b1, b2) over the piece
+              const double q0 = w[0] * t.iz[0], q1 = w[1] * t.iz[1], q2 = w[2] * t.iz[2];
+              const double den = std::fma(w[2], t.iz[2], std::fma(w[1], t.iz[1], w[0] * t.iz[0]));
+              b1 = std::fma(q2, q[2].b1, std::fma(q1, q[1].b1, q0 * q[0].b1)) / den;
+              b2 = std::fma(q2, q[2].b2, std::fma(q1, q[1].b2, q0 * q[0].b2)) / den;
+            }
+            prim = r->tex_first[f] + texel_index(r->tex_res[f], b1, b2);
+          }
+          const uint64_t key = ((uint64_t)float_bits(z) << 32) | prim;
+          key_min(&r->keys[(uint64_t)x * H + y], key, par);  // nearest z wins; ties -> lower id (B-4)
         }
-        const uint64_t key = ((uint64_t)float_bits(z) << 32) | prim;
-        key_min(&r->keys[(uint64_t)x * H + y], key, par);  // nearest z wins; ties -> lower id (B-4)
       }
     }
   }
@@ -543,12 +647,22 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
 static inline float nan_inf_to_zero(float v) { return (std::isnan(v) || std::isinf(v)) ? 0.0f : v; }  // Fusion.h:79-95
 
 // ModelAggregator::get (Fusion.h:72-76, Mesh.h:131-132) + functor chains (Fusion.cu:47-49,67-69,79-82)
+static int get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, float* out, int memkind);
 int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind) {
+  if (!a) return fail(SMESH_ERR_INVALID, "NULL argument");
+  return get_rows(a, 0, a->P, out, memkind);
+}
+int smesh_aggregator_get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, float* out, int memkind) {
+  if (!a || row_lo > row_hi || row_hi > a->P || (row_lo & 3)) return fail(SMESH_ERR_INVALID, "bad row range");
+  return get_rows(a, row_lo, row_hi, out, memkind);
+}
+static int get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, float* out, int memkind) {
   if (!a || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
   if (memkind != SMESH_MEM_HOST) return fail(SMESH_ERR_INVALID, "oracle only writes host memory");
   const uint32_t C = a->C;
   std::vector<float> row(C);
-  for (uint64_t p = 0; p < a->P; p++) {
+  out -= row_lo * C;
+  for (uint64_t p = row_lo; p < row_hi; p++) {
     for (uint32_t c = 0; c < C; c++) row[c] = g_accum_double ? (float)a->accd[p * C + c] : a->acc[p * C + c];
     if (a->kind == SMESH_AGG_MUL && g_accum_double) {
       // the float64 yardstick keeps its precision through the division by the largest element: casting a log-sum of magnitude
@@ -675,6 +789,8 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, cons
 int smesh_stream_wait(int, void*) { return SMESH_OK; }   // the oracle has no streams: everything is synchronous
 int smesh_stream_release(int, void*) { return SMESH_OK; }
 int smesh_stream_handle(int, void** s) { if (s) *s = nullptr; return SMESH_OK; }
+int smesh_stream_mark(int, int) { return SMESH_OK; }
+int smesh_stream_mark_elapsed(int, int, int, double* ms) { if (ms) *ms = 0.0; return SMESH_OK; }
 // multi-GPU exchange: not part of the CPU restatement (tests sum the shards' raw accumulators themselves)
 int smesh_comm_unique_id(uint8_t*) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
 int smesh_comm_create(int, int, int, const uint8_t*, smesh_comm_t**) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
@@ -682,6 +798,7 @@ int smesh_comm_create_all(const int*, int, smesh_comm_t**) { return fail(SMESH_E
 int smesh_comm_destroy(smesh_comm_t*) { return SMESH_OK; }
 int smesh_comm_rank(const smesh_comm_t*, int*, int*) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
 int smesh_allreduce(smesh_comm_t* const*, smesh_aggregator_t* const*, int) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
+int smesh_reduce_scatter(smesh_comm_t*, smesh_aggregator_t*, uint64_t*, uint64_t*) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
 int smesh_comm_allreduce_f64(smesh_comm_t*, double*, int, int) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
 int smesh_profile_enable(int, int) { return SMESH_OK; }
 int smesh_profile_sample_every(int, uint32_t) { return SMESH_OK; }

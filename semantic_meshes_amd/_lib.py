@@ -14,7 +14,7 @@ OK, ERR_INVALID, ERR_RUNTIME, ERR_NODEVICE = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
 IDX_U32, IDX_I32, IDX_U64, IDX_I64 = 0, 1, 2, 3
 AGG_KINDS = {"Sum": 0, "Summax": 1, "Mul": 2}
-PROF_FUSE_SCATTER, PROF_FUSE_HIST, PROF_RASTER, PROF_FINALIZE = 0, 1, 2, 3
+PROF_FUSE_SCATTER, PROF_FUSE_HIST, PROF_RASTER, PROF_FINALIZE, PROF_EXCHANGE = 0, 1, 2, 3, 4
 
 c_void_p, c_int, c_u64, c_u32, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_float
 P = ctypes.POINTER
@@ -41,6 +41,8 @@ SIGNATURES = {
     "smesh_stream_wait": (c_int, [c_int, c_void_p]),
     "smesh_stream_release": (c_int, [c_int, c_void_p]),
     "smesh_stream_handle": (c_int, [c_int, P(c_void_p)]),
+    "smesh_stream_mark": (c_int, [c_int, c_int]),
+    "smesh_stream_mark_elapsed": (c_int, [c_int, c_int, c_int, P(ctypes.c_double)]),
     "smesh_renderer_create_triangles": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_int, P(c_void_p)]),
     "smesh_renderer_create_texels": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_u64, c_float, c_int, P(c_void_p)]),
     "smesh_renderer_destroy": (c_int, [c_void_p]),
@@ -59,6 +61,7 @@ SIGNATURES = {
                                               c_void_p, P(ctypes.c_int64), c_int,
                                               c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64]),
     "smesh_aggregator_get": (c_int, [c_void_p, c_void_p, c_int]),
+    "smesh_aggregator_get_rows": (c_int, [c_void_p, c_u64, c_u64, c_void_p, c_int]),
     "smesh_aggregator_get_raw": (c_int, [c_void_p, c_void_p, c_int]),
     "smesh_aggregator_set_raw": (c_int, [c_void_p, c_void_p, c_int]),
     "smesh_aggregator_raw_pointer": (c_int, [c_void_p, P(c_void_p), P(c_u64)]),
@@ -69,6 +72,7 @@ SIGNATURES = {
     "smesh_comm_destroy": (c_int, [c_void_p]),
     "smesh_comm_rank": (c_int, [c_void_p, P(c_int), P(c_int)]),
     "smesh_allreduce": (c_int, [P(c_void_p), P(c_void_p), c_int]),
+    "smesh_reduce_scatter": (c_int, [c_void_p, c_void_p, P(c_u64), P(c_u64)]),
     "smesh_comm_allreduce_f64": (c_int, [c_void_p, P(ctypes.c_double), c_int, c_int]),
     "smesh_aggregator_renderer": (c_int, [c_void_p, P(c_void_p)]),
     "smesh_annotation_renderer_render": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int, c_void_p, c_void_p, c_int, c_u64, c_u64]),
@@ -99,13 +103,53 @@ _lib = None
 _lock = threading.Lock()
 
 
+def _elf_dynamic_strings(path):
+    """(SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read from its dynamic section."""
+    import struct
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:6] != b"\x7fELF\x02\x01":
+        raise ValueError("not a little-endian ELF64 file")
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+    dyn = None
+    for k in range(shnum):
+        name, typ, flags, addr, off, size, link, info, align, entsize = struct.unpack_from("<IIQQQQIIQQ", data, shoff + k * shentsize)
+        if typ == 6:      # SHT_DYNAMIC; sh_link = its string table
+            stroff, strsize = struct.unpack_from("<QQ", data, shoff + link * shentsize + 0x18)
+            dyn = (off, size, stroff)
+            break
+    if dyn is None:
+        return None, []
+    off, size, stroff = dyn
+
+    def cstr(o):
+        end = data.index(b"\0", stroff + o)
+        return data[stroff + o:end].decode()
+
+    soname, needed = None, []
+    for e in range(off, off + size, 16):
+        tag, val = struct.unpack_from("<qQ", data, e)
+        if tag == 0:
+            break
+        if tag == 1:
+            needed.append(cstr(val))
+        elif tag == 14:
+            soname = cstr(val)
+    return soname, needed
+
+
 def _preload_hip_runtime():
     """One HIP runtime per process.  PyTorch-ROCm wheels ship their own libamdhip64 / libhsa-runtime64 next to torch; a
     process that first loads this library against the system ROCm and later imports torch ends up with TWO runtimes, and
     the second one sees no usable GPU (`torch.cuda.is_available()` False, a hang at exit).  The other order is fine: the
-    dynamic linker satisfies our `libamdhip64.so.7` with the copy torch already mapped.  So, when a torch installation
-    exists in this environment (located, NOT imported), its runtime is mapped first and both then share it in any import
-    order.  SMESH_HIP_RUNTIME=system keeps the system ROCm; =<directory> takes libamdhip64.so / libhsa-runtime64.so from there."""
+    dynamic linker satisfies our DT_NEEDED `libamdhip64.so.N` with the copy torch already mapped -- IF that copy's SONAME
+    is the same `libamdhip64.so.N`.  So, when a torch installation exists in this environment (located, NOT imported) AND
+    its bundled runtime carries exactly the SONAME this library was linked against, that runtime is mapped first and both
+    then share it in any import order.  A wheel built against another ROCm major (its SONAME differs) is left alone: the
+    linker could not reuse it, and mapping it would CREATE the two-runtime state for processes that never import torch.
+    SMESH_HIP_RUNTIME=system keeps the system ROCm unconditionally; =<directory> takes libamdhip64.so / libhsa-runtime64.so
+    from there (same SONAME check)."""
     import importlib.util
     import sys
     choice = os.environ.get("SMESH_HIP_RUNTIME", "auto")
@@ -120,6 +164,16 @@ def _preload_hip_runtime():
         if spec is None or not spec.origin:
             return
         libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    hip = os.path.join(libdir, "libamdhip64.so")
+    if not os.path.exists(hip):
+        return
+    try:
+        wanted = [n for n in _elf_dynamic_strings(LIB_PATH)[1] if n.startswith("libamdhip64.so")]
+        offered = _elf_dynamic_strings(hip)[0]
+    except (OSError, ValueError, IndexError):
+        return
+    if not wanted or offered != wanted[0]:
+        return          # another ROCm major: the linker would map the system runtime beside it anyway
     for name in ("libhsa-runtime64.so", "libamdhip64.so"):
         path = os.path.join(libdir, name)
         if os.path.exists(path):

@@ -146,6 +146,14 @@ class Communicator:
         _lib.check(_lib.lib().smesh_allreduce(comms, aggs, 1))
         return aggregator
 
+    def reduce_scatter(self, aggregator):
+        """Opt-in alternative to `allreduce` (`smesh_reduce_scatter`: one in-place ncclReduceScatter, half the bytes per link).
+        Returns `(row_lo, row_hi)`: the rows of THIS rank's accumulator that now hold the sum over all ranks -- fetch them
+        with `aggregator.get_rows(row_lo, row_hi)`; the other rows keep this rank's partial sums."""
+        lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+        _lib.check(_lib.lib().smesh_reduce_scatter(self._h, aggregator._h, ctypes.byref(lo), ctypes.byref(hi)))
+        return int(lo.value), int(hi.value)
+
     def reduce_scalars(self, values, op="sum"):
         """Blocking reduction of a few host floats over all ranks (`op` sum | max)."""
         vals = [float(v) for v in values]

@@ -10,7 +10,19 @@
 #include "common.hpp"
 
 #include <dlfcn.h>
+// RCCL is loaded with dlopen at run time; its header only supplies a handful of types.  A ROCm installation without the RCCL
+// development files still builds the (single-GPU) library: the same few declarations are written out below.
+#if __has_include(<rccl/rccl.h>)
 #include <rccl/rccl.h>
+#else
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclProd = 1, ncclMax = 2, ncclMin = 3 } ncclRedOp_t;
+typedef enum { ncclFloat32 = 7, ncclFloat64 = 8 } ncclDataType_t;
+}
+#endif
 
 #include <cstring>
 #include <new>
@@ -22,7 +34,7 @@ using namespace smesh;
 struct smesh_aggregator;
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a);
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a);
-float* smesh_aggregator_acc(smesh_aggregator* a, uint64_t* num_floats);
+int smesh_aggregator_acc(smesh_aggregator* a, float** acc, uint64_t* num_floats, uint32_t* row_stride, uint64_t* rows);
 
 namespace {
 
@@ -33,6 +45,7 @@ struct Rccl {
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -59,6 +72,7 @@ Rccl* rccl() {
     x->CommInitAll = reinterpret_cast<decltype(x->CommInitAll)>(sym("ncclCommInitAll"));
     x->CommDestroy = reinterpret_cast<decltype(x->CommDestroy)>(sym("ncclCommDestroy"));
     x->AllReduce = reinterpret_cast<decltype(x->AllReduce)>(sym("ncclAllReduce"));
+    x->ReduceScatter = reinterpret_cast<decltype(x->ReduceScatter)>(sym("ncclReduceScatter"));
     x->GroupStart = reinterpret_cast<decltype(x->GroupStart)>(sym("ncclGroupStart"));
     x->GroupEnd = reinterpret_cast<decltype(x->GroupEnd)>(sym("ncclGroupEnd"));
     x->GetErrorString = reinterpret_cast<decltype(x->GetErrorString)>(sym("ncclGetErrorString"));
@@ -184,8 +198,12 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (hipSetDevice(ctx->device) != hipSuccess) { status = fail(SMESH_ERR_RUNTIME, "hipSetDevice failed"); break; }
     uint64_t count = 0;
-    float* acc = smesh_aggregator_acc(aggs[i], &count);
-    if (count == 0) continue;
+    float* acc = nullptr;
+    // a failure here must surface: a rank that skipped the collective would leave its peers blocked inside theirs.  An EMPTY
+    // accumulator (P == 0) is empty on every rank (same num_primitives is a precondition), so skipping it is collective-safe.
+    status = smesh_aggregator_acc(aggs[i], &acc, &count, nullptr, nullptr);
+    if (status != SMESH_OK || count == 0) continue;
+    ProfScope prof(ctx, SMESH_PROF_EXCHANGE);
     const ncclResult_t e = r->AllReduce(acc, acc, (size_t)count, ncclFloat32, ncclSum, comms[i]->comm, ctx->stream);
     if (e != ncclSuccess) status = fail_rccl(r, e, "ncclAllReduce");
   }
@@ -194,6 +212,35 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
     if (e != ncclSuccess && status == SMESH_OK) status = fail_rccl(r, e, "ncclGroupEnd");
   }
   return status;
+}
+
+// Opt-in alternative to smesh_allreduce (half the bytes on every xGMI link): an in-place ncclReduceScatter.  Afterwards rank r
+// holds the sum over all ranks in rows [*row_lo, *row_hi) of ITS accumulator -- q = floor(P / nranks / 4) * 4 rows per rank, so that
+// every slice starts on a 16-byte boundary whatever the class count -- and the few rows beyond nranks * q (fewer than 5 * nranks)
+// are all-reduced and belong to the last rank's range.  The other rows of a rank keep its own partial sums: only
+// smesh_aggregator_get_rows(a, *row_lo, *row_hi, ...) is meaningful afterwards, each rank normalising its own slice.
+int smesh_reduce_scatter(smesh_comm_t* c, smesh_aggregator_t* a, uint64_t* row_lo, uint64_t* row_hi) {
+  if (!c || !a || !row_lo || !row_hi) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (smesh_aggregator_ctx(a) != c->ctx) return fail(SMESH_ERR_INVALID, "aggregator and communicator live on different devices");
+  Rccl* r;
+  SMESH_TRY(need_rccl(&r));
+  std::lock_guard<std::mutex> g(smesh_aggregator_mutex(a));
+  DeviceCtx* ctx = c->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  uint64_t count = 0, P = 0;
+  uint32_t S = 0;
+  float* acc = nullptr;
+  SMESH_TRY(smesh_aggregator_acc(a, &acc, &count, &S, &P));
+  const uint64_t q = (P / (uint64_t)c->nranks) & ~(uint64_t)3;
+  *row_lo = q * (uint64_t)c->rank;
+  *row_hi = c->rank == c->nranks - 1 ? P : q * (uint64_t)(c->rank + 1);
+  if (count == 0) return SMESH_OK;
+  ProfScope prof(ctx, SMESH_PROF_EXCHANGE);
+  if (q) SMESH_RCCL(r, r->ReduceScatter(acc, acc + *row_lo * S, (size_t)(q * S), ncclFloat32, ncclSum, c->comm, ctx->stream));
+  const uint64_t tail = q * (uint64_t)c->nranks;
+  if (tail < P) SMESH_RCCL(r, r->AllReduce(acc + tail * S, acc + tail * S, (size_t)((P - tail) * S), ncclFloat32, ncclSum, c->comm, ctx->stream));
+  return SMESH_OK;
 }
 
 // Small reduction of host values over the same communicator (op: 0 = sum, 2 = max), blocking: what a benchmark harness needs

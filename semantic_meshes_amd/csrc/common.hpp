@@ -51,6 +51,7 @@ struct DeviceCtx {
   unsigned profiling = 0;   // bit s set = bracket slot s with HIP events
   unsigned profile_every = 1;   // ... every n-th region of the slot (an event pair costs ~4 us of stream time)
   ProfSlot slots[SMESH_PROF_SLOTS];
+  hipEvent_t marks[SMESH_STREAM_MARKS] = {};   // smesh_stream_mark
   std::recursive_mutex mu;
 };
 

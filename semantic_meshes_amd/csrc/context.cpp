@@ -178,6 +178,36 @@ int smesh_stream_handle(int device, void** stream) {
   return SMESH_OK;
 }
 
+int smesh_stream_mark(int device, int id) {
+  if (id < 0 || id >= SMESH_STREAM_MARKS) return fail(SMESH_ERR_INVALID, "bad mark id");
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(device));
+  if (!ctx->marks[id]) SMESH_HIP(hipEventCreate(&ctx->marks[id]));
+  SMESH_HIP(hipEventRecord(ctx->marks[id], ctx->stream));
+  return SMESH_OK;
+}
+
+int smesh_stream_mark_elapsed(int device, int from, int to, double* ms) {
+  if (from < 0 || from >= SMESH_STREAM_MARKS || to < 0 || to >= SMESH_STREAM_MARKS || !ms) return fail(SMESH_ERR_INVALID, "bad mark id");
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  hipEvent_t a, b;
+  {
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    a = ctx->marks[from];
+    b = ctx->marks[to];
+  }
+  if (!a || !b) return fail(SMESH_ERR_INVALID, "mark was never recorded");
+  SMESH_HIP(hipSetDevice(device));
+  SMESH_HIP(hipEventSynchronize(b));
+  float f = 0.f;
+  SMESH_HIP(hipEventElapsedTime(&f, a, b));
+  *ms = (double)f;
+  return SMESH_OK;
+}
+
 int smesh_profile_enable(int device, int enabled) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));

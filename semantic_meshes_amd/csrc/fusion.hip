@@ -2403,10 +2403,17 @@ int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const ui
 
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a) { return a->ctx; }
 // The accumulator as one float32 buffer on the library stream (Mul: the (hi, lo) pair folded into the hi plane first).
-float* smesh_aggregator_acc(smesh_aggregator* a, uint64_t* num_floats) {
-  if (mul_normalise(a, true) != SMESH_OK) { if (num_floats) *num_floats = 0; return nullptr; }
+// A failure (the Mul fold could not be launched) is reported as such: a rank that silently skipped the collective would leave its
+// peers blocked inside it.  `row_stride` = floats per accumulator row, `rows` = P.
+int smesh_aggregator_acc(smesh_aggregator* a, float** acc, uint64_t* num_floats, uint32_t* row_stride, uint64_t* rows) {
+  if (acc) *acc = nullptr;
+  if (num_floats) *num_floats = 0;
+  SMESH_TRY(mul_normalise(a, true));
+  if (acc) *acc = a->acc;
   if (num_floats) *num_floats = a->P * a->S;
-  return a->acc;
+  if (row_stride) *row_stride = a->S;
+  if (rows) *rows = a->P;
+  return SMESH_OK;
 }
 uint32_t smesh_aggregator_classes(smesh_aggregator* a) { return a->C; }
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a) { return a->mu; }
@@ -2540,9 +2547,14 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
   return SMESH_OK;
 }
 
-static int finalize_into(smesh_aggregator* a, float* d_out) {
+// rows [row_lo, row_hi) (row_lo a multiple of 4: the tiles move whole 16-byte pieces) normalised into d_out[(row_hi - row_lo) * C]
+static int finalize_into(smesh_aggregator* a, float* d_out, uint64_t row_lo = 0, uint64_t row_hi = ~(uint64_t)0) {
   DeviceCtx* ctx = a->ctx;
-  if (a->P == 0) return SMESH_OK;
+  row_hi = std::min<uint64_t>(row_hi, a->P);
+  if (row_lo >= row_hi) return SMESH_OK;
+  const uint64_t P = row_hi - row_lo;
+  float* const acc = a->acc + row_lo * a->S;
+  float* const acc_lo = a->acc_lo ? a->acc_lo + row_lo * a->S : nullptr;
   ProfScope prof(ctx, SMESH_PROF_FINALIZE);
   int TP = tile_pixels(a->C);
   const int C = (int)a->C;
@@ -2553,18 +2565,18 @@ static int finalize_into(smesh_aggregator* a, float* d_out) {
   if (a->kind == SMESH_AGG_MUL && !mul) SMESH_TRY(mul_normalise(a, false));
   if (TP) {
     const size_t lds = (((size_t)TP * C + 3) & ~(size_t)3) * 4 * (mul ? 2 : 1);
-    const dim3 g((uint32_t)div_up(a->P, TP));
+    const dim3 g((uint32_t)div_up(P, TP));
     switch (a->kind) {
-      case SMESH_AGG_SUM:    hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUM>, g, dim3(256), lds, ctx->stream, a->acc, nullptr, d_out, a->P, C, (int)a->S, TP); break;
-      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUMMAX>, g, dim3(256), lds, ctx->stream, a->acc, nullptr, d_out, a->P, C, (int)a->S, TP); break;
-      default:               hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_MUL>, g, dim3(256), lds, ctx->stream, a->acc, mul ? a->acc_lo : nullptr, d_out, a->P, C, (int)a->S, TP); break;
+      case SMESH_AGG_SUM:    hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUM>, g, dim3(256), lds, ctx->stream, acc, nullptr, d_out, P, C, (int)a->S, TP); break;
+      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_SUMMAX>, g, dim3(256), lds, ctx->stream, acc, nullptr, d_out, P, C, (int)a->S, TP); break;
+      default:               hipLaunchKernelGGL(k_finalize_tile<SMESH_AGG_MUL>, g, dim3(256), lds, ctx->stream, acc, mul ? acc_lo : nullptr, d_out, P, C, (int)a->S, TP); break;
     }
   } else {
-    const dim3 g((uint32_t)div_up(a->P, 256)), b(256);
+    const dim3 g((uint32_t)div_up(P, 256)), b(256);
     switch (a->kind) {
-      case SMESH_AGG_SUM: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_SUM>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break;
-      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_SUMMAX>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break;
-      default: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_MUL>, g, b, 0, ctx->stream, a->acc, d_out, a->P, C, (int)a->S); break;
+      case SMESH_AGG_SUM: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_SUM>, g, b, 0, ctx->stream, acc, d_out, P, C, (int)a->S); break;
+      case SMESH_AGG_SUMMAX: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_SUMMAX>, g, b, 0, ctx->stream, acc, d_out, P, C, (int)a->S); break;
+      default: hipLaunchKernelGGL(k_finalize_rows<SMESH_AGG_MUL>, g, b, 0, ctx->stream, acc, d_out, P, C, (int)a->S); break;
     }
   }
   SMESH_HIP(hipGetLastError());
@@ -2587,6 +2599,26 @@ int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind) {
   SMESH_TRY(a->out_tmp.reserve(bytes));
   SMESH_TRY(finalize_into(a, static_cast<float*>(a->out_tmp.ptr)));
   SMESH_HIP(hipMemcpyAsync(out, a->out_tmp.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  return SMESH_OK;
+}
+
+int smesh_aggregator_get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, float* out, int memkind) {
+  if (!a || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (row_lo > row_hi || row_hi > a->P || (row_lo & 3)) return fail(SMESH_ERR_INVALID, "bad row range (row_lo must be a multiple of 4, row_hi <= P)");
+  std::lock_guard<std::mutex> g(a->mu);
+  DeviceCtx* ctx = a->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)(row_hi - row_lo) * a->C * 4;
+  if (bytes == 0) return SMESH_OK;
+  float* d_out = out;
+  if (memkind != SMESH_MEM_DEVICE) {
+    SMESH_TRY(a->out_tmp.reserve(bytes));
+    d_out = static_cast<float*>(a->out_tmp.ptr);
+  }
+  SMESH_TRY(finalize_into(a, d_out, row_lo, row_hi));
+  if (memkind != SMESH_MEM_DEVICE) SMESH_HIP(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
   return SMESH_OK;
 }

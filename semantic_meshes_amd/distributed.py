@@ -62,9 +62,54 @@ def allreduce_raw(aggregator, group=None, comm=None):
     return aggregator
 
 
-def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None, contiguous=True, batch=8, comm=None):
-    """Fuse this rank's share of `cameras` and all-reduce.  `probs_of_view(k)` returns the (W,H,C)
-    class-probability image of view k (host or device).  `comm`: native communicator (see allreduce_raw)."""
+def owned_rows(primitives, rank, world_size):
+    """Rows [lo, hi) of the accumulator that rank `rank` owns after a reduce-scatter: q = floor(P / world / 4) * 4 rows per
+    rank (16-byte aligned slices), the remainder counted into the last rank's range (`smesh_reduce_scatter`)."""
+    q = (int(primitives) // int(world_size)) & ~3
+    return q * rank, (int(primitives) if rank == world_size - 1 else q * (rank + 1))
+
+
+def reduce_scatter_raw(aggregator, group=None, comm=None):
+    """Opt-in exchange (SMESH_EXCHANGE=reduce_scatter): afterwards this rank's rows `owned_rows(P, rank, world)` hold the sum over
+    all ranks; returns that `(row_lo, row_hi)`.  Native: one in-place ncclReduceScatter on the library's stream.  Through
+    torch.distributed: `reduce_scatter_tensor` in place under nccl; under gloo (CPU test machines, several ranks sharing one GPU)
+    the all-reduce of `allreduce_raw` stands in -- same rows, same values."""
+    if comm is not None:
+        return comm.reduce_scatter(aggregator)
+    dist = _dist()
+    P = aggregator.primitives
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, P
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi = owned_rows(P, rank, world)
+    if dist.get_backend(group) == "nccl" and hasattr(aggregator, "raw_device_array") and world > 1:
+        import ctypes
+        import torch
+        from . import _lib
+        flat = aggregator.raw_device_array(padded=True)
+        S = flat.shape[0] // max(P, 1)
+        t = torch.as_tensor(flat, device="cuda:%d" % flat.device)
+        q = (P // world) & ~3
+        if q:
+            dist.reduce_scatter_tensor(t[lo * S:(lo + q) * S], t[:q * world * S], op=dist.ReduceOp.SUM, group=group)
+        if q * world < P:
+            dist.all_reduce(t[q * world * S:], op=dist.ReduceOp.SUM, group=group)
+        _lib.check(_lib.lib().smesh_stream_wait(flat.device, ctypes.c_void_p(int(torch.cuda.current_stream(flat.device).cuda_stream))))
+        return lo, hi
+    allreduce_raw(aggregator, group)
+    return lo, hi
+
+
+def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None, contiguous=True, batch=8, comm=None,
+                       exchange=None):
+    """Fuse this rank's share of `cameras` and exchange.  `probs_of_view(k)` returns the (W,H,C)
+    class-probability image of view k (host or device).  `comm`: native communicator (see allreduce_raw).
+    `exchange` (default: SMESH_EXCHANGE, else "allreduce"): "allreduce" -- every rank ends with the whole fusion, returns the
+    aggregator; "reduce_scatter" -- returns `(row_lo, row_hi)`, the rows this rank owns (`aggregator.get_rows`)."""
+    import os
+    exchange = exchange or os.environ.get("SMESH_EXCHANGE", "allreduce")
+    if exchange not in ("allreduce", "reduce_scatter"):
+        raise ValueError("exchange must be 'allreduce' or 'reduce_scatter'")
     if comm is not None:
         rank, world = comm.rank, comm.world
     else:
@@ -83,4 +128,6 @@ def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None,
         for k in mine:
             idx, _ = renderer.render(cameras[k])
             aggregator.add(idx, probs_of_view(k))
+    if exchange == "reduce_scatter":
+        return reduce_scatter_raw(aggregator, group, comm)
     return allreduce_raw(aggregator, group, comm)

@@ -132,6 +132,14 @@ class _MeshAggregator:
             _lib.check(_lib.lib().smesh_aggregator_get(self._h, out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
         return out
 
+    def get_rows(self, row_lo, row_hi):
+        """`get()` for the rows [row_lo, row_hi) only (row_lo a multiple of 4): what a rank owns after
+        `Communicator.reduce_scatter` (new functionality)."""
+        row_lo, row_hi = int(row_lo), int(row_hi)
+        out = np.empty((max(row_hi - row_lo, 0), self.classes), np.float32)
+        _lib.check(_lib.lib().smesh_aggregator_get_rows(self._h, row_lo, row_hi, out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
+        return out
+
     def get_device(self):
         """`get()` without the trip to the host: the normalised float32[P,C] result as a device-resident `DeviceArray`
         (`__cuda_array_interface__` / DLPack) in a fresh HBM allocation owned by the returned object."""

@@ -44,6 +44,13 @@ for kind in ("sum", "summax", "mul"):
     np.testing.assert_allclose(agg.get(), whole.get(), rtol=rtol, atol=2e-7)
     np.testing.assert_allclose(agg.get_raw(), whole.get_raw(), rtol=1e-5, atol=1e-6)
     assert (whole.get().sum(axis=1) > 0.5).sum() > P // 3
+    # the opt-in exchange: every rank ends up owning a slice of rows (here through gloo, where the all-reduce stands in)
+    agg2 = oracle.OracleAggregator(P, C, kind, 0.5)
+    lo, hi = smdist.fuse_views_sharded(r, agg2, cams, probs_of_view, exchange="reduce_scatter")
+    assert (lo, hi) == smdist.owned_rows(P, rank, world) and lo % 4 == 0
+    np.testing.assert_allclose(agg2.get_rows(lo, hi), whole.get()[lo:hi], rtol=rtol, atol=2e-7)
+    spans = [smdist.owned_rows(P, k, world) for k in range(world)]
+    assert spans[0][0] == 0 and spans[-1][1] == P and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
 dist.barrier()
 dist.destroy_process_group()
 print("rank %d ok" % rank)

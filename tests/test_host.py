@@ -177,3 +177,26 @@ def test_dlpack_roundtrip_without_gpu():
     # numpy >= 1.22 arrays speak DLPack too: still taken through the array interface (no capsule needed)
     _, mem, *_ = device.describe(host, 3, "probs")
     assert mem == _lib.MEM_HOST
+
+
+def test_hip_runtime_preload_checks_the_soname(tmp_path):
+    """a bundled runtime of another ROCm major (SONAME != the DT_NEEDED of libsmesh_hip.so) must NOT be mapped --
+    the linker could not reuse it and both runtimes would load."""
+    import subprocess
+    import sys
+    soname, needed = _lib._elf_dynamic_strings(_lib.LIB_PATH)
+    want = [n for n in needed if n.startswith("libamdhip64.so")]
+    assert want, needed
+    for tag, name in (("other", "libamdhip64.so.999"), ("same", want[0])):
+        d = tmp_path / tag
+        d.mkdir()
+        src = d / "x.c"
+        src.write_text("int smesh_fake_runtime_marker(void) { return 1; }\n")
+        subprocess.check_call(["gcc", "-shared", "-fPIC", "-Wl,-soname," + name, str(src), "-o", str(d / "libamdhip64.so")])
+        assert _lib._elf_dynamic_strings(str(d / "libamdhip64.so"))[0] == name
+        code = ("import os, sys; sys.path.insert(0, %r); from semantic_meshes_amd import _lib; _lib._preload_hip_runtime(); "
+                "print('MAPPED' if %r in open('/proc/self/maps').read() else 'LEFT')" % (os.path.dirname(os.path.dirname(__file__)), str(d)))
+        out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMESH_HIP_RUNTIME=str(d)),
+                             capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        assert out.stdout.strip() == ("LEFT" if tag == "other" else "MAPPED"), (tag, out.stdout, out.stderr)

@@ -22,29 +22,106 @@ def _unrle(vals, lens, shape):
 
 # ---- rasteriser -----------------------------------------------------------------------------------
 def near_plane_scene():
-    """Raster spec B-3: a triangle with ANY vertex at z_c <= 1e-6 is dropped as a whole -- there is no
-    near-plane clipping (the rule template-tensors applies is out of tree; this one is pinned here and on the GPU).
+    """Raster spec B-3: triangles that cross the near plane z_c = 1e-6 are CLIPPED against it.
     Camera at the origin looking down +z; triangle 0 lies in front, triangle 1 (nearer, covering triangle 0) has one vertex
     behind the camera, triangle 2 has a vertex exactly on the camera plane."""
     from semantic_meshes_amd import data
     cam = data.Camera(np.eye(3, dtype=np.float32), np.zeros(3, np.float32), np.array([64, 48]), np.array([40.0, 40.0]), np.array([32.0, 24.0]))
     v = np.array([[-1, -1, 4], [1, -1, 4], [0, 1, 4],          # 0: in front
-                  [-2, -2, 2], [2, -2, 2], [0, 1, -1],         # 1: crosses the camera plane
-                  [-2, -2, 3], [2, -2, 3], [0, 2, 0]], np.float32)   # 2: touches it (z_c == 0)
+                  [-2, -2, 2], [0.5, -2, 2], [-0.5, 2, -1],    # 1: crosses the camera plane
+                  [0.6, 0.2, 3], [1.8, 1.4, 3], [1.6, 0.9, 0]], np.float32)   # 2: touches it (z_c == 0)
     f = np.array([[0, 1, 2], [3, 4, 5], [6, 7, 8]], np.int32)
     return cam, v, f
 
 
-def test_near_plane_whole_triangle_cull(oracle):
+def room_scene(W=96, H=72, eye=(0.3, -0.2, 0.1), target=(2.0, 0.5, 0.0), f=50.0, half=(2.0, 1.5, 1.2)):
+    """The camera INSIDE a closed box of twelve triangles (cfg4's namesake: a ScanNet room seen from within,
+    eval-scannet/eval_scannet.py:203-238): every wall but the one behind the camera crosses the camera plane."""
+    from semantic_meshes_amd import data, synth
+    hx, hy, hz = half
+    v = np.array([[sx * hx, sy * hy, sz * hz] for sx in (-1, 1) for sy in (-1, 1) for sz in (-1, 1)], np.float32)
+    quads = [(0, 1, 3, 2), (4, 6, 7, 5), (0, 4, 5, 1), (2, 3, 7, 6), (0, 2, 6, 4), (1, 5, 7, 3)]
+    faces = np.array([t for q in quads for t in ((q[0], q[1], q[2]), (q[0], q[2], q[3]))], np.int32)
+    R, t = synth.look_at(eye, target, up=(0, 0, 1))
+    cam = data.Camera(R, t, np.array([W, H]), np.array([f, f]), np.array([W / 2.0, H / 2.0]))
+    return cam, v, faces
+
+
+def test_near_plane_clipping_known_answers(oracle):
     cam, v, f = near_plane_scene()
     idx, depth = oracle.OracleRenderer(v, f).render(cam)
-    assert set(np.unique(idx)) == {0, BG}                     # triangles 1 and 2 vanish completely, they hide nothing
-    assert (idx == 0).sum() > 150 and np.allclose(depth[idx == 0], 4.0)
-    # moved a hair in front of the plane the crossing triangle is back (and, nearer, wins over triangle 0 where they overlap)
+    assert set(np.unique(idx)) == {0, 1, 2, BG}
+    # what is left of triangle 1 in front of the camera hides triangle 0 (z = 4) wherever it covers it; its depth is its
+    # plane's z_c along the pixel's ray, anywhere between the near plane and 2
+    assert (idx == 1).sum() > 800 and depth[idx == 1].max() <= 2.0 + 1e-6 and depth[idx == 1].min() >= 1e-6
+    assert 0 < (idx == 0).sum() < 200 and (idx == 2).sum() > 50
+    # against the independent ray caster: same primitive at every pixel that is not within a hair of an edge, same depth
+    from helpers import raycast
+    want, want_z, _, _, margin = raycast(cam, v, f)
+    sure = margin > 1e-9
+    assert sure.mean() > 0.97
+    assert np.array_equal(idx[sure], want[sure])
+    hit = sure & (want != BG)
+    np.testing.assert_allclose(depth[hit], want_z[hit], rtol=2e-6)
+    # moved in front of the plane nothing is clipped any more: same picture from the unclipped path up to the moved geometry
     v2 = v.copy()
     v2[5, 2] = 0.5
     idx2, _ = oracle.OracleRenderer(v2, f).render(cam)
-    assert (idx2 == 1).sum() > 500 and (idx2 == 0).sum() < (idx == 0).sum()
+    assert (idx2 == 1).sum() > 500
+
+
+def test_camera_inside_a_room_has_no_holes(oracle):
+    from helpers import raycast
+    for eye, target in (((0.3, -0.2, 0.1), (2.0, 0.5, 0.0)), ((-1.2, 0.9, -0.6), (0.0, -1.5, 0.4)), ((1.5, 1.2, 1.0), (-2.0, -1.5, -1.2))):
+        cam, v, f = room_scene(eye=eye, target=target)
+        idx, depth = oracle.OracleRenderer(v, f).render(cam)
+        assert (idx != BG).all() and np.isfinite(depth).all()          # a closed room: no pixel sees the background
+        want, want_z, _, _, margin = raycast(cam, v, f)
+        sure = margin > 1e-9
+        assert sure.mean() > 0.95
+        assert np.array_equal(idx[sure], want[sure])
+        np.testing.assert_allclose(depth[sure], want_z[sure], rtol=2e-6)
+        # vertex order and orientation of the crossing triangles do not matter
+        g = f[:, [1, 2, 0]].copy()
+        g[::2] = g[::2, ::-1]
+        idx_g, depth_g = oracle.OracleRenderer(v, g).render(cam)
+        assert np.array_equal(idx_g[sure], idx[sure]) and (idx_g != BG).all()
+        np.testing.assert_allclose(depth_g[sure], depth[sure], rtol=2e-6)
+
+
+def test_clipped_texel_triangles_number_their_texels_by_true_barycentrics(oracle):
+    """Texel primitives of triangles that cross the near plane: the texel under a pixel is the one its ray hits (perspective-correct
+    barycentric coordinates of the ORIGINAL triangle), the same rule texel_index applies to unclipped triangles' weights."""
+    from helpers import raycast
+    cam, v, f = room_scene(W=128, H=96)
+    ctor_cam = _camera(W=128, H=96, eye=(0.0, 0.0, 9.0), target=(0, 0, 0), f=40.0)    # a camera that sees the room from outside sizes the textures
+    r = oracle.OracleRenderer(v, f, cameras=[ctor_cam], texels_per_pixel=0.35)
+    faces_r, res, first = r.texel_layout()
+    assert res.max() >= 4
+    idx, depth = r.render(cam)
+    want_tri, want_z, b1, b2, margin = raycast(cam, v, faces_r)
+    # the triangles this is about: those with a vertex at or behind the near plane (unclipped ones keep the screen-space weights)
+    vc = (np.asarray(cam.rotation, np.float64) @ v.T.astype(np.float64)).T + np.asarray(cam.translation, np.float64)
+    crossing = (vc[faces_r][:, :, 2] <= 1e-6).any(axis=1)
+    assert crossing.sum() >= 6
+    sure = (margin > 1e-6) & (want_tri != BG) & crossing[np.minimum(want_tri, len(faces_r) - 1)]
+    tri = want_tri[sure]
+    rr = res[tri].astype(np.int64)
+    tu = np.clip(((b1[sure].astype(np.float32) - np.float32(1e-6)) * rr.astype(np.float32)).astype(np.int64), 0, None)
+    tv = np.clip(((b2[sure].astype(np.float32) - np.float32(1e-6)) * rr.astype(np.float32)).astype(np.int64), 0, None)
+    tu = np.minimum(tu, rr - 1)
+    tv = np.minimum(tv, rr - 1 - tu)
+    row = tu + tv
+    want = first[tri].astype(np.int64) + row * (row + 1) // 2 + tu
+    got = idx[sure].astype(np.int64)
+    has = rr > 0
+    # the texel changes where (b - 1e-6) * r crosses an integer: allow the pixels within rounding of such a border
+    fu = (b1[sure] - 1e-6) * rr
+    fv = (b2[sure] - 1e-6) * rr
+    border = (np.abs(fu - np.round(fu)) < 1e-4) | (np.abs(fv - np.round(fv)) < 1e-4)
+    ok = has & ~border
+    assert ok.sum() > 0.8 * sure.sum()
+    assert np.array_equal(got[ok], want[ok])
 
 
 def test_ka1_empty_scene_is_background(oracle):
