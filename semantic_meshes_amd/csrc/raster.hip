@@ -63,8 +63,9 @@ constexpr unsigned long long kBackgroundKey = (0x7F800000ull << 32) | 0xFFFFFFFF
 
 struct ScreenVertex {
   double u, v;  // pixel coordinates
-  double iz;    // 1/z_c, 0 = unusable vertex
+  double iz;    // 1/z_c > 0: in front of the near plane; kBehind: finite, at or behind it; 0 = unusable vertex
 };
+constexpr double kBehind = -1.0;
 
 struct CameraArgs {
   float R[9];
@@ -81,13 +82,16 @@ __device__ __forceinline__ ScreenVertex project_point(const CameraArgs& cam, con
   const float zc = ((cam.R[6] * X + cam.R[7] * Y) + cam.R[8] * Z) + cam.t[2];
   ScreenVertex s;
   s.u = 0.0; s.v = 0.0; s.iz = 0.0;
-  if (zc > kNear && isfinite(xc) && isfinite(yc) && isfinite(zc)) {
+  const bool fin = isfinite(xc) && isfinite(yc) && isfinite(zc);
+  if (zc > kNear && fin) {
     const double zd = (double)zc;
     const double u = cam.fx * ((double)xc / zd) + cam.cx;
     const double v = cam.fy * ((double)yc / zd) + cam.cy;
     if (isfinite(u) && isfinite(v)) {
       s.u = u; s.v = v; s.iz = 1.0 / zd;
     }
+  } else if (fin) {
+    s.iz = kBehind;   // at or behind the near plane: triangles that also have a vertex in front are clipped (clip_piece)
   }
   return s;
 }
@@ -173,7 +177,7 @@ __device__ __forceinline__ bool edge_accepts(double w, int cls) { return __built
 
 __device__ __forceinline__ bool setup_tri(const ScreenVertex& a, const ScreenVertex& b, const ScreenVertex& c,
                                           uint32_t W, uint32_t H, Tri& t) {
-  if (a.iz == 0.0 || b.iz == 0.0 || c.iz == 0.0) return false;
+  if (!(a.iz > 0.0) || !(b.iz > 0.0) || !(c.iz > 0.0)) return false;
   const double minu = fmin(a.u, fmin(b.u, c.u)), maxu = fmax(a.u, fmax(b.u, c.u));
   const double minv = fmin(a.v, fmin(b.v, c.v)), maxv = fmax(a.v, fmax(b.v, c.v));
   // first / last sample column and row, clamped to the image (the conversions saturate: coordinates are finite here)
@@ -258,6 +262,8 @@ struct FragQueues {
 
 struct RasterArgs {
   const int32_t* faces;
+  const float* verts;         // [V][3] world-space vertices: re-read by the (rare) triangles that cross the near plane
+  CameraArgs cam;             // ... together with the camera, to cut them along it (clip_piece)
   const ScreenVertex* sv;
   const uint32_t* prim_id;    // [F] primitive id of the triangle at position f (null: id == f; the renderer re-orders badly ordered meshes)
   const uint32_t* tex_res;    // null for triangle primitives
@@ -296,6 +302,165 @@ __device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t
   return setup_tri(va, vb, vc, a.W, a.H, t);
 }
 
+// ---- near-plane clipping (round 3; DESIGN.md "Raster spec" 1b; oracle: clip_edge / clip_triangle, operation for operation) --------
+// A triangle with vertices in front of AND at / behind the near plane z_c = kNear is cut along it.  On every edge from a front
+// vertex F to a behind vertex B the point I = F + t (B - F), t = (zF - n) / (zF - zB), is computed in double FROM THE FRONT VERTEX
+// (the two triangles sharing the edge compute the same I: the cut edge F-I stays watertight) and projected with z = n exactly.
+// One front vertex (cyclic order F, N, P): the piece (F, I_FN, I_FP).  Two front vertices (cyclic order B, N, P): the pieces
+// (N, P, I_PB) and (N, I_PB, I_NB).  Pieces are ordinary triangles for setup_tri / the coverage rule / the depth formula and write
+// the id of the triangle they came from; texel primitives interpolate the ORIGINAL triangle's (b1, b2), carried at the pieces'
+// vertices, perspective-correctly.  Such triangles are rare (the ring of floor / wall triangles around a camera inside a room):
+// they take the path of the largest triangles -- the fusion's big-triangle queue and the tile workgroups' queue -- whatever
+// their size, and re-read their world-space vertices instead of widening the per-vertex record of every vertex.
+struct CamPoint { float x, y, z; };
+__device__ __forceinline__ CamPoint camera_point(const CameraArgs& cam, const float* __restrict__ verts, const int32_t i) {
+  const float X = verts[3 * (uint64_t)i + 0], Y = verts[3 * (uint64_t)i + 1], Z = verts[3 * (uint64_t)i + 2];
+  CamPoint c;
+  c.x = ((cam.R[0] * X + cam.R[1] * Y) + cam.R[2] * Z) + cam.t[0];
+  c.y = ((cam.R[3] * X + cam.R[4] * Y) + cam.R[5] * Z) + cam.t[1];
+  c.z = ((cam.R[6] * X + cam.R[7] * Y) + cam.R[8] * Z) + cam.t[2];
+  return c;
+}
+struct ClipVertex { ScreenVertex s; double b1, b2; };
+// The point where the edge from front vertex F to behind vertex B meets the near plane (false: it does not project).
+__device__ __forceinline__ bool clip_edge(const CameraArgs& cam, const CamPoint& F, const double fb1, const double fb2,
+                                          const CamPoint& B, const double bb1, const double bb2, ClipVertex& out) {
+  const double zn = (double)kNear;
+  const double t = ((double)F.z - zn) / ((double)F.z - (double)B.z);
+  const double x = __builtin_fma(t, (double)B.x - (double)F.x, (double)F.x);
+  const double y = __builtin_fma(t, (double)B.y - (double)F.y, (double)F.y);
+  const double u = cam.fx * (x / zn) + cam.cx;
+  const double v = cam.fy * (y / zn) + cam.cy;
+  out.s.u = u; out.s.v = v; out.s.iz = 1.0 / zn;
+  out.b1 = __builtin_fma(t, bb1 - fb1, fb1);
+  out.b2 = __builtin_fma(t, bb2 - fb2, fb2);
+  return isfinite(u) && isfinite(v);
+}
+
+// 0: all three vertices in front (an ordinary triangle); 1 / 2: crossing with that many front vertices; -1: nothing to draw
+__device__ __forceinline__ int clip_class(const ScreenVertex& va, const ScreenVertex& vb, const ScreenVertex& vc) {
+  if (va.iz == 0.0 || vb.iz == 0.0 || vc.iz == 0.0) return -1;
+  const int nfront = (va.iz > 0.0 ? 1 : 0) + (vb.iz > 0.0 ? 1 : 0) + (vc.iz > 0.0 ? 1 : 0);
+  return nfront == 3 ? 0 : (nfront == 0 ? -1 : nfront);
+}
+
+// The three vertices (with the original triangle's barycentric coordinates) of piece `p` (0 or 1) of a crossing triangle whose
+// vertices are (i0, i1, i2) -> (va, vb, vc); nfront = clip_class() in {1, 2}.  False: there is no such piece.
+__device__ __forceinline__ bool clip_piece(const RasterArgs& a, const int32_t i0, const int32_t i1, const int32_t i2,
+                                           const ScreenVertex& va, const ScreenVertex& vb, const ScreenVertex& vc,
+                                           const int nfront, const int p, ClipVertex& q0, ClipVertex& q1, ClipVertex& q2) {
+  if (nfront == 1 && p != 0) return false;
+  // rotate so that the special vertex (the only front one / the only behind one) comes first: cyclic order S, N, P
+  const int k = nfront == 1 ? (va.iz > 0.0 ? 0 : (vb.iz > 0.0 ? 1 : 2)) : (!(va.iz > 0.0) ? 0 : (!(vb.iz > 0.0) ? 1 : 2));
+  const int32_t is = k == 0 ? i0 : (k == 1 ? i1 : i2), in = k == 0 ? i1 : (k == 1 ? i2 : i0), ip = k == 0 ? i2 : (k == 1 ? i0 : i1);
+  const CamPoint cs = camera_point(a.cam, a.verts, is), cn = camera_point(a.cam, a.verts, in), cp = camera_point(a.cam, a.verts, ip);
+  // (b1, b2) of the original vertices a, b, c: (0,0), (1,0), (0,1)
+  const double s1 = k == 1 ? 1.0 : 0.0, s2 = k == 2 ? 1.0 : 0.0;
+  const double n1 = k == 0 ? 1.0 : 0.0, n2 = k == 1 ? 1.0 : 0.0;
+  const double p1 = k == 2 ? 1.0 : 0.0, p2 = k == 0 ? 1.0 : 0.0;
+  const ScreenVertex& ss = k == 0 ? va : (k == 1 ? vb : vc);
+  const ScreenVertex& sn = k == 0 ? vb : (k == 1 ? vc : va);
+  const ScreenVertex& sp = k == 0 ? vc : (k == 1 ? va : vb);
+  if (nfront == 1) {
+    q0.s = ss; q0.b1 = s1; q0.b2 = s2;
+    const bool ok1 = clip_edge(a.cam, cs, s1, s2, cn, n1, n2, q1);
+    const bool ok2 = clip_edge(a.cam, cs, s1, s2, cp, p1, p2, q2);
+    return ok1 && ok2;
+  }
+  ClipVertex inb, ipb;
+  const bool ok1 = clip_edge(a.cam, cn, n1, n2, cs, s1, s2, inb);
+  const bool ok2 = clip_edge(a.cam, cp, p1, p2, cs, s1, s2, ipb);
+  if (!ok1 || !ok2) return false;
+  q0.s = sn; q0.b1 = n1; q0.b2 = n2;
+  if (p == 0) { q1.s = sp; q1.b1 = p1; q1.b2 = p2; q2 = ipb; }
+  else        { q1 = ipb; q2 = inb; }
+  return true;
+}
+
+// Screen bounding box of what is left of a crossing triangle in front of the near plane (the box of its pieces' vertices, clamped
+// to the image like setup_tri's): false if that is empty.
+__device__ __forceinline__ bool clip_bbox(const RasterArgs& a, const int32_t i0, const int32_t i1, const int32_t i2,
+                                          const ScreenVertex& va, const ScreenVertex& vb, const ScreenVertex& vc, const int nfront,
+                                          int& x0, int& y0, int& x1, int& y1) {
+  ClipVertex q0, q1, q2;
+  if (!clip_piece(a, i0, i1, i2, va, vb, vc, nfront, nfront == 2 ? 1 : 0, q0, q1, q2)) return false;
+  // one front vertex: the piece itself; two: piece 1 = (N, I_PB, I_NB) plus P
+  double minu = fmin(q0.s.u, fmin(q1.s.u, q2.s.u)), maxu = fmax(q0.s.u, fmax(q1.s.u, q2.s.u));
+  double minv = fmin(q0.s.v, fmin(q1.s.v, q2.s.v)), maxv = fmax(q0.s.v, fmax(q1.s.v, q2.s.v));
+  if (nfront == 2) {
+    const int k = !(va.iz > 0.0) ? 0 : (!(vb.iz > 0.0) ? 1 : 2);
+    const ScreenVertex& sp = k == 0 ? vc : (k == 1 ? va : vb);
+    minu = fmin(minu, sp.u); maxu = fmax(maxu, sp.u); minv = fmin(minv, sp.v); maxv = fmax(maxv, sp.v);
+  }
+  // (the conversions saturate; coordinates are finite here)
+  x0 = max((int)ceil(minu - 0.5), 0); x1 = min((int)floor(maxu - 0.5), (int)a.W - 1);
+  y0 = max((int)ceil(minv - 0.5), 0); y1 = min((int)floor(maxv - 0.5), (int)a.H - 1);
+  return x0 <= x1 && y0 <= y1;
+}
+
+// A triangle as the big-triangle paths shade it: piece `p` of triangle f (piece 0 of an ordinary triangle is the triangle).
+struct Piece {
+  Tri t;
+  double b1[3], b2[3];   // clipped pieces: the original triangle's barycentric coordinates at the piece's vertices
+  bool clipped;
+};
+__device__ __forceinline__ bool load_piece(const RasterArgs& a, const uint64_t f, const int p, Piece& pc) {
+  const int32_t i0 = a.faces[3 * f + 0], i1 = a.faces[3 * f + 1], i2 = a.faces[3 * f + 2];
+  if ((uint64_t)max((uint32_t)i0, max((uint32_t)i1, (uint32_t)i2)) >= a.V) return false;
+  if (a.tex_res && a.tex_res[f] == 0) return false;
+  const ScreenVertex va = a.sv[i0], vb = a.sv[i1], vc = a.sv[i2];
+  const int cls = clip_class(va, vb, vc);
+  pc.clipped = cls > 0;
+  if (cls < 0) return false;
+  if (cls == 0) return p == 0 && setup_tri(va, vb, vc, a.W, a.H, pc.t);
+  ClipVertex q0, q1, q2;
+  if (!clip_piece(a, i0, i1, i2, va, vb, vc, cls, p, q0, q1, q2)) return false;
+  pc.b1[0] = q0.b1; pc.b1[1] = q1.b1; pc.b1[2] = q2.b1;
+  pc.b2[0] = q0.b2; pc.b2[1] = q1.b2; pc.b2[2] = q2.b2;
+  return setup_tri(q0.s, q1.s, q2.s, a.W, a.H, pc.t);
+}
+
+// Depth-test key of piece `pc` of triangle f at sample (x, y), or kNullKey if the sample is not covered (shade() / shade_key() with
+// the texel of a clipped piece taken from the perspective-correct barycentric coordinates).
+__device__ __forceinline__ unsigned long long shade_piece_key(const RasterArgs& a, const uint64_t f, const Piece& pc, const int x, const int y) {
+  const Tri& t = pc.t;
+  const double px = (double)x + 0.5, py = (double)y + 0.5;
+  const double w0 = eval_edge(t.e0, px, py);
+  if (!edge_accepts(w0, t.cls0)) return kNullKey;
+  const double w1 = eval_edge(t.e1, px, py);
+  if (!edge_accepts(w1, t.cls1)) return kNullKey;
+  const double w2 = eval_edge(t.e2, px, py);
+  if (!edge_accepts(w2, t.cls2)) return kNullKey;
+  const double num = (w0 + w1) + w2;
+  const double den = __builtin_fma(w2, t.iz2, __builtin_fma(w1, t.iz1, w0 * t.iz0));
+  const float zf = (float)(num / den);
+  if (!(zf > 0.0f) || !isfinite(zf)) return kNullKey;
+  uint32_t prim = a.prim_id ? a.prim_id[f] : (uint32_t)f;
+  if (a.tex_res) {
+    double b1, b2;
+    if (!pc.clipped) { b1 = w1 / num; b2 = w2 / num; }
+    else {
+      const double q0 = w0 * t.iz0, q1 = w1 * t.iz1, q2 = w2 * t.iz2;
+      b1 = __builtin_fma(q2, pc.b1[2], __builtin_fma(q1, pc.b1[1], q0 * pc.b1[0])) / den;
+      b2 = __builtin_fma(q2, pc.b2[2], __builtin_fma(q1, pc.b2[1], q0 * pc.b2[0])) / den;
+    }
+    prim = a.tex_first[f] + texel_of(a.tex_res[f], b1, b2);
+  }
+  return ((unsigned long long)__float_as_uint(zf) << 32) | prim;
+}
+
+// load_tri for the one-lane-per-triangle kernels: 1 = an ordinary triangle, set up in `t`; 2 = a triangle that crosses the near
+// plane, t.x0 .. t.y1 = the screen box of what is left of it (to be shaded piece by piece, load_piece); 0 = nothing to draw.
+__device__ __forceinline__ int load_tri_ex(const RasterArgs& a, uint64_t f, Tri& t, const int32_t i0, const int32_t i1, const int32_t i2) {
+  if ((uint64_t)max((uint32_t)i0, max((uint32_t)i1, (uint32_t)i2)) >= a.V) return 0;
+  if (a.tex_res && a.tex_res[f] == 0) return 0;
+  const ScreenVertex va = a.sv[i0], vb = a.sv[i1], vc = a.sv[i2];
+  const int cls = clip_class(va, vb, vc);
+  if (cls == 0) return setup_tri(va, vb, vc, a.W, a.H, t) ? 1 : 0;
+  if (cls < 0) return 0;
+  return clip_bbox(a, i0, i1, i2, va, vb, vc, cls, t.x0, t.y0, t.x1, t.y1) ? 2 : 0;
+}
+
 // Depth-test key of triangle f at sample (x, y), or kNullKey if the sample is not covered.
 __device__ __forceinline__ unsigned long long shade_key(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y) {
   const Shaded sh = shade(t, x, y, a.tex_res != nullptr);
@@ -320,10 +485,11 @@ __global__ void k_raster_small(RasterArgs a) {
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   Tri t;
-  if (load_tri(a, f, t)) {
+  const int have = load_tri_ex(a, f, t, a.faces[3 * f + 0], a.faces[3 * f + 1], a.faces[3 * f + 2]);
+  if (have) {
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
     rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
-    if (bw > 8 || bh > 8) {
+    if (bw > 8 || bh > 8 || have == 2) {
       const uint32_t slot = atomicAdd(a.big_count, 1u);
       if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
       rec.kind = 2;
@@ -351,16 +517,21 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a, uint32_t chunk
   // blocks walk the queue; each triangle is split into 64x64 chunks processed by successive blocks
   for (uint32_t q = blockIdx.x; q < nbig; q += gridDim.x) {
     const uint64_t f = a.big_queue[q];
-    Tri t;
-    if (!load_tri(a, f, t)) continue;
-    const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
-    const int ty = threadIdx.x & 63, tx = threadIdx.x >> 6;  // 64 rows x 4 columns per pass
-    for (int cx = 0; cx < bw; cx += 4) {
-      const int x = t.x0 + cx + tx;
-      if (x > t.x1) continue;
-      for (int cy = 0; cy < bh; cy += 64) {
-        const int y = t.y0 + cy + ty;
-        if (y <= t.y1) emit(a, f, t, x, y);
+    for (int p = 0; p < 2; p++) {   // the triangle, or the one or two pieces of a triangle that crosses the near plane
+      Piece pc;
+      if (!load_piece(a, f, p, pc)) continue;
+      const Tri& t = pc.t;
+      const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
+      const int ty = threadIdx.x & 63, tx = threadIdx.x >> 6;  // 64 rows x 4 columns per pass
+      for (int cx = 0; cx < bw; cx += 4) {
+        const int x = t.x0 + cx + tx;
+        if (x > t.x1) continue;
+        for (int cy = 0; cy < bh; cy += 64) {
+          const int y = t.y0 + cy + ty;
+          if (y > t.y1) continue;
+          const unsigned long long key = shade_piece_key(a, f, pc, x, y);
+          if (key != kNullKey && !(a.dbg & 1)) atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
+        }
       }
     }
   }
@@ -432,15 +603,16 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   unsigned long long cover = 0ull;
   bool medium = false;
   const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // value written to the index image
-  if (f < a.F && load_tri(a, f, t, i0, i1, i2)) {
+  const int have = f < a.F ? load_tri_ex(a, f, t, i0, i1, i2) : 0;   // 2: crosses the near plane (t holds only its screen box)
+  if (have) {
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
     rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
-    if (bw > 8 || bh > 8) {
+    if (bw > 8 || bh > 8 || have == 2) {
       const uint32_t slot = atomicAdd(a.big_count, 1u);          // every such triangle: the fusion walks this queue
       if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
       rec.kind = 2;
       rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
-      if (bw <= kMedium && bh <= kMedium) medium = true;         // rasterised below by the whole wave
+      if (bw <= kMedium && bh <= kMedium && have == 1) medium = true;   // rasterised below by the whole wave
       else {                                                     // rasterised by the tile workgroups it overlaps
         const uint32_t hs = atomicAdd(a.big_count + 2, 1u);
         if (hs < a.big_capacity) a.huge_queue[hs] = (uint32_t)f;
@@ -522,7 +694,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
       a.q.pix[e] = pin;
     } else if (key != kNullKey) {
       atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
-      a.q.flag[(tx0 + (hx ? 1u : 0u)) * a.q.tiles_y + ty0 + (hy ? 1u : 0u)] = 1u;
+      atomicOr(&a.q.flag[(tx0 + (hx ? 1u : 0u)) * a.q.tiles_y + ty0 + (hy ? 1u : 0u)], 1u);
     }
   }
   if (mask) rec.kind = 1;
@@ -599,7 +771,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
         a.q.pix[e] = (uint16_t)((x - jx * kQW) * kQH + (y - jy * kQH));
       } else if (key != kNullKey) {
         atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
-        a.q.flag[tile] = 1u;
+        atomicOr(&a.q.flag[tile], 1u);
       }
     }
   }
@@ -644,14 +816,68 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   raster_frag_wave<true>(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
 }
 
+// The largest triangles (box over kMedium x kMedium) and the triangles that cross the near plane (clip_piece), between k_raster_frag
+// and k_tile_resolve: one workgroup per screen tile scans their queue, keeps those whose box overlaps the tile and shades the
+// overlap, 256 samples at a time, piece by piece.  The fragments go through the global key image (64-bit atomicMin; the lanes of
+// an instruction run down a column, consecutive keys) and the tile is flagged (bit 1) so that its resolve merges them.  With an
+// empty queue -- every BASELINE config -- a workgroup reads one counter and leaves.  (Round 2 did this inside k_tile_resolve,
+// against the LDS keys; with the clipping code in it the resolve went from 76 to 110 VGPRs and from 57 to 159 us per eight cfg2
+// views, so it moved out.)
+__device__ __forceinline__ void raster_huge_block(const RasterArgs& a, const uint32_t tile) {
+  __shared__ uint32_t s_hits[256];
+  __shared__ uint32_t s_nhits;
+  const uint32_t nbig = min(a.big_count[2], a.big_capacity);
+  if (nbig == 0u) return;
+  const FragQueues& q = a.q;
+  const int t = threadIdx.x;
+  const uint32_t tx = tile / q.tiles_y, ty = tile - tx * q.tiles_y;
+  const uint32_t x0 = tx * kQW, y0 = ty * kQH;
+  const int tx1 = (int)min(x0 + kQW, a.W) - 1, ty1 = (int)min(y0 + kQH, a.H) - 1;   // last pixel of the tile inside the image
+  bool any = false;
+  if (t == 0) s_nhits = 0u;
+  __syncthreads();
+  for (uint32_t qb = 0; qb < nbig; qb += 256u) {
+    const uint32_t qi = qb + (uint32_t)t;
+    if (qi < nbig) {
+      const uint32_t f = a.huge_queue[qi];
+      const TriFrag rec = a.frags[f];
+      const int bx1 = (int)(rec.mask & 0xFFFFu), by1 = (int)((rec.mask >> 16) & 0xFFFFu);
+      if (rec.kind == 2 && (int)rec.x0 <= tx1 && bx1 >= (int)x0 && (int)rec.y0 <= ty1 && by1 >= (int)y0)
+        s_hits[atomicAdd(&s_nhits, 1u)] = f;
+    }
+    __syncthreads();
+    const uint32_t nh = s_nhits;
+    for (uint32_t h = 0; h < nh; h++) {
+      const uint64_t f = s_hits[h];
+      for (int p = 0; p < 2; p++) {   // the triangle, or the one or two pieces of a triangle that crosses the near plane
+        Piece pc;
+        if (!load_piece(a, f, p, pc)) continue;
+        const Tri& tr = pc.t;
+        const int xa = max(tr.x0, (int)x0), xb = min(tr.x1, tx1), ya = max(tr.y0, (int)y0), yb = min(tr.y1, ty1);
+        const int hh = yb - ya + 1, area = (xb - xa + 1) * hh;
+        if (hh <= 0) continue;
+        for (int i = t; i < area; i += 256) {
+          const int x = xa + i / hh, y = ya + i % hh;
+          const unsigned long long key = shade_piece_key(a, f, pc, x, y);
+          if (key != kNullKey) { atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key); any = true; }
+        }
+      }
+    }
+    __syncthreads();
+    if (t == 0) s_nhits = 0u;
+    __syncthreads();
+  }
+  if (any) atomicOr(&q.flag[tile], 2u);
+}
+
+__global__ __launch_bounds__(256) void k_raster_huge(RasterArgs a) { raster_huge_block(a, blockIdx.x); }
+
 // One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
 // > 8 x 8: the workgroup scans their queue, keeps those whose box overlaps the tile and shades the overlap, 256
 // samples at a time), then the output planes are written once.  "Big" here means larger than kMedium x kMedium.
 __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out,
                                                    const uint32_t tile) {
   __shared__ unsigned long long skeys[kQPixels];
-  __shared__ uint32_t s_hits[256];
-  __shared__ uint32_t s_nhits;
   const FragQueues& q = a.q;
   const int t = threadIdx.x;
   const uint32_t W = a.W, H = a.H;
@@ -672,8 +898,10 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
     spec_pix[k] = q.pix[qbase + i];
   }
   const uint32_t n = min(q.count[tile * kQSub + sq], q.cap);
-  const bool merge = q.flag[tile] != 0u;
-  const uint32_t nbig = min(a.big_count[2], a.big_capacity);   // triangles larger than kMedium x kMedium
+  // bit 0: fragments of small triangles that did not fit the queue went through the global key image; bit 1: k_raster_huge left the
+  // fragments of triangles larger than kMedium x kMedium (and of triangles clipped at the near plane) there
+  const uint32_t tile_flag = q.flag[tile];
+  const bool merge = tile_flag != 0u;
   for (int p = t; p < kQPixels; p += 256) {
     const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
     unsigned long long k = kBackgroundKey;
@@ -684,40 +912,11 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
     }
     skeys[p] = k;
   }
-  if (t == 0) s_nhits = 0u;
   __syncthreads();
 #pragma unroll
   for (uint32_t k = 0; k < kSpec; k++)
     if (sq_lane + k * kGroup < n) atomicMin(&skeys[spec_pix[k]], spec_key[k]);
   for (uint32_t i = sq_lane + kSpec * kGroup; i < n; i += kGroup) atomicMin(&skeys[q.pix[qbase + i]], q.key[qbase + i]);
-  const int tx1 = (int)min(x0 + kQW, W) - 1, ty1 = (int)min(y0 + kQH, H) - 1;   // last pixel of the tile inside the image
-  for (uint32_t qb = 0; qb < nbig; qb += 256u) {
-    const uint32_t qi = qb + (uint32_t)t;
-    if (qi < nbig) {
-      const uint32_t f = a.huge_queue[qi];
-      const TriFrag rec = a.frags[f];
-      const int bx1 = (int)(rec.mask & 0xFFFFu), by1 = (int)((rec.mask >> 16) & 0xFFFFu);
-      if (rec.kind == 2 && (int)rec.x0 <= tx1 && bx1 >= (int)x0 && (int)rec.y0 <= ty1 && by1 >= (int)y0)
-        s_hits[atomicAdd(&s_nhits, 1u)] = f;
-    }
-    __syncthreads();
-    const uint32_t nh = s_nhits;
-    for (uint32_t h = 0; h < nh; h++) {
-      const uint64_t f = s_hits[h];
-      Tri tr;
-      if (!load_tri(a, f, tr)) continue;
-      const int xa = max(tr.x0, (int)x0), xb = min(tr.x1, tx1), ya = max(tr.y0, (int)y0), yb = min(tr.y1, ty1);
-      const int hh = yb - ya + 1, area = (xb - xa + 1) * hh;
-      for (int i = t; i < area; i += 256) {
-        const int x = xa + i / hh, y = ya + i % hh;
-        const unsigned long long key = shade_key(a, f, tr, x, y);
-        if (key != kNullKey) atomicMin(&skeys[(x - (int)x0) * kQH + (y - (int)y0)], key);
-      }
-    }
-    __syncthreads();
-    if (t == 0) s_nhits = 0u;
-    __syncthreads();
-  }
   __syncthreads();
   // The depth test is decided: tell the triangle-order fusion which fragments of the small triangles LOST it, by clearing their
   // bit in the triangle's record (about one fragment in twenty at cfg2; the winners need no memory traffic at all).  The record
@@ -726,7 +925,7 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
   // id) nor re-ordered meshes (it holds the caller's face id, the records are indexed by position); a tile that merged
   // overflowed fragments from the key image cannot name their losers and raises the "check them" flag for the whole view.
   if (a.frags && !a.prim_id && !a.tex_res) {
-    if (merge) {
+    if (tile_flag & 1u) {
       if (t == 0) a.big_count[1] = 1u;
     } else {
       auto lost = [&](const unsigned long long key, const uint32_t pin) {
@@ -758,6 +957,12 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
 
 __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out) {
   tile_resolve_block(a, idx_out, depth_out, blockIdx.x);
+}
+
+__global__ __launch_bounds__(256) void k_raster_huge_group(RasterGroup g) {
+  uint32_t v = 0;
+  while (v + 1 < g.n && blockIdx.x >= g.tile_end[v]) v++;   // block-uniform, n <= kMaxGroup
+  raster_huge_block(g.view[v], blockIdx.x - (v ? g.tile_end[v - 1] : 0u));
 }
 
 // Several views in one launch (index planes only).
@@ -999,7 +1204,7 @@ CameraArgs camera_args(const smesh_camera_t* cam) {
 // Kernel arguments of a render of a W x H view with scratch set `vs`, leaving its records in side `side` (queues: a.q).
 RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int side, uint64_t W, uint64_t H) {
   RasterArgs a;
-  a.faces = r->faces; a.sv = vs.sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
+  a.faces = r->faces; a.verts = r->verts; a.sv = vs.sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
   a.prim_id = r->prim_id;
   a.keys = vs.keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
   a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
@@ -1050,11 +1255,14 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   }
   if (r->F) {
     RasterArgs a = raster_args(r, vs, side, W, H);
+    a.cam = ca;
     const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
     int qs = SMESH_OK;
     if (raster_path() == RasterPath::Frag && ensure_queues(r, vs, W, H, st, &qs)) {
       a.q = vs.fq;
       hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(div_up(r->F, a.tpw), 4)), dim3(256), 0, st, a);
+      SMESH_HIP(hipGetLastError());
+      hipLaunchKernelGGL(k_raster_huge, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a);
       SMESH_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_tile_resolve, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a, d_idx, d_depth);
       SMESH_HIP(hipGetLastError());
@@ -1143,6 +1351,7 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     pg.sv[v] = vs.sv;
     pg.big_count[v] = r->side[base + v].big_count;
     rg.view[v] = raster_args(r, vs, base + v, W, H);
+    rg.view[v].cam = pg.cam[v];
     rg.view[v].q = vs.fq;
     rg.idx[v] = static_cast<uint32_t*>(r->fused[base + v].ptr);
     tiles += (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
@@ -1157,6 +1366,8 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   hipLaunchKernelGGL(k_project_vertices_group, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, pg);
   SMESH_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_raster_frag_group, dim3((uint32_t)n * rg.blocks_per_view), dim3(256), 0, st, rg);
+  SMESH_HIP(hipGetLastError());
+  hipLaunchKernelGGL(k_raster_huge_group, dim3(tiles), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_tile_resolve_group, dim3(tiles), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
