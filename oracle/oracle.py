@@ -105,6 +105,18 @@ def set_fast_histogram(on):
     lib().smesh_oracle_set_fast_histogram(1 if on else 0)
 
 
+def set_mul_literal(on):
+    """Independent yardstick: the Mul term as the literal reading of Fusion.cu:83-87, logf(powf(p, w)) with p^w rounded to
+    float32 first, instead of the spec'd w * log_spec(p) (DESIGN.md 3.3 #6)."""
+    lib().smesh_oracle_set_mul_literal(1 if on else 0)
+
+
+def set_edge_five_op(on):
+    """Independent yardstick: the round-1 edge function sign * (dx (py - ly) - dy (px - lx)) instead of the spec'd
+    fma(A, px, fma(B, py, C)) (DESIGN.md 3.3 #3)."""
+    lib().smesh_oracle_set_edge_five_op(1 if on else 0)
+
+
 class OracleRenderer:
     def __init__(self, vertices, faces, cameras=None, texels_per_pixel=0.1):
         self.vertices = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)

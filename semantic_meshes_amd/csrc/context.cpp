@@ -143,10 +143,12 @@ int smesh_stream_wait(int device, void* producer_stream) {
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(device));
   hipStream_t ps = static_cast<hipStream_t>(producer_stream);
-  if (ps == ctx->stream || ps == ctx->raster_stream) return SMESH_OK;
+  if (ps == ctx->raster_stream) return SMESH_OK;
   if (!ctx->ev_order) SMESH_HIP(hipEventCreateWithFlags(&ctx->ev_order, hipEventDisableTiming));
   SMESH_HIP(hipEventRecord(ctx->ev_order, ps));
-  SMESH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
+  // the library's MAIN stream as producer: a DLPack producer was handed that stream (`__dlpack__(stream=...)`) and ordered its
+  // writes on it -- the raster stream (content checksums of foreign images run there) still has to be put behind them
+  if (ps != ctx->stream) SMESH_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_order, 0));
   SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, ctx->ev_order, 0));
   return SMESH_OK;
 }

@@ -202,7 +202,8 @@ __global__ __launch_bounds__(kBlock) void k_rec_clear(const uint32_t* __restrict
 namespace smesh {
 
 // One allocation: [frags 16 P][cand 4 P][big_count 16] -- what a call dirties and one memset clears -- then [big4 16 P][queue 4 P]
-static size_t block_bytes(uint64_t P) { return (size_t)P * (sizeof(TriFrag) + 4) + 16; }
+// (rounded up to 16 bytes: big4 behind it is read and written with 128-bit accesses)
+static size_t block_bytes(uint64_t P) { return (((size_t)P * (sizeof(TriFrag) + 4) + 16) + 15) & ~(size_t)15; }
 
 void ImageRecords::release() {
   if (frags) (void)hipFree(frags);

@@ -278,6 +278,8 @@ def describe(obj, want_ndim, what, device=None, streams=None):
             if not ordered:
                 st = _order_after_producer(obj, None, device)
             else:   # the producer ordered the hand-over itself; its later use of the buffer: assume its current / default stream
+                # (it ordered the library's MAIN stream: the raster stream, where foreign index images are checksummed, follows)
+                _lib.check(_lib.lib().smesh_stream_wait(int(device), ctypes.c_void_p(library_stream(device))))
                 st = 0
                 if (type(obj).__module__ or "").split(".")[0] == "torch":
                     try:

@@ -314,3 +314,35 @@ def test_permuted_device_probs_take_the_render_records_path(sm, oracle, C, res):
     if os.environ.get("SMESH_FUSE") != "strip":
         np.testing.assert_array_equal(a.get_raw().view(np.uint32), b.get_raw().view(np.uint32))
     assert_fused_close(a.get(), oagg.get())
+
+
+def test_reference_package_name_returns_capsules_by_default(sm):
+    """`import semantic_meshes` (the reference's name): render() returns the reference's "dltensor" capsules without
+    any switch, and the reference's loop (colorize_cityscapes_mesh.py:65-67: capsule straight back into add()) takes the
+    triangle-order kernels."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import semantic_meshes
+from semantic_meshes_amd import _lib, synth
+from helpers import small_scene
+mesh, cams = small_scene(40, 20, 160, 120, views=2)
+r = semantic_meshes.render.triangles(mesh)
+agg = semantic_meshes.fusion.MeshAggregator(primitives=r.getPrimitivesNum(), classes=5)
+ref = semantic_meshes.fusion.MeshAggregator(primitives=r.getPrimitivesNum(), classes=5)
+for k, cam in enumerate(cams):
+    idx, depth = r.render(cam)
+    assert type(idx).__name__ == "PyCapsule" and type(depth).__name__ == "PyCapsule"
+    probs = np.asarray(synth.device_probs(160, 120, 5, 11 + k))
+    agg.add(idx, probs)
+    assert _lib.lib().smesh_last_fuse_kernel().decode().startswith("k_fuse_tri")
+    ref.fuse_view(r, cam, probs)
+assert np.array_equal(agg.get(), ref.get())
+print("capsules ok")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "SMESH_RENDER_CAPSULES"}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "capsules ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

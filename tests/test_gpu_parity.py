@@ -1097,6 +1097,31 @@ def test_mul_aggregator_edge_values(sm, oracle):
         oracle.set_accum_double(False)
 
 
+def test_mul_against_the_literal_pow_then_log_oracle(sm, oracle):
+    """the HIP Mul aggregator against the oracle's INDEPENDENT literal mode (logf(powf(p, w)) with libm, float64 sums):
+    1e-5 on get() for ordinary class vectors -- a yardstick that did not move with the kernels."""
+    mesh, cams = small_scene(60, 30, 200, 150, views=3)
+    P, C = len(mesh.faces), 19
+    rng = np.random.default_rng(78)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    agg = sm.fusion.MeshAggregator(P, C, "mul")
+    oracle.set_accum_double(True)
+    oracle.set_mul_literal(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, "mul")
+        for cam in cams:
+            W, H = cam.resolution
+            probs = random_probs(rng, W, H, C)
+            weights = (rng.random((W, H), dtype=np.float32) + 0.5).astype(np.float32)
+            agg.fuse_view(r, cam, probs, weights)
+            oagg.add(o.render(cam)[0], probs, weights)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5, atol=1e-6)
+    finally:
+        oracle.set_mul_literal(False)
+        oracle.set_accum_double(False)
+
+
 # ---- smesh_fuse_views: a batch of views, consecutive views fused two per launch ----------------------------------
 @pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
 @pytest.mark.parametrize("C", [5, 19, 7, 40, 48])

@@ -311,6 +311,61 @@ def test_ka12_mul_aggregator(oracle):
     np.testing.assert_allclose(out[0], 1 / 3, rtol=1e-6)           # untouched Mul rows: exp(0) normalised (A.4)
 
 
+def test_mul_spec_against_the_literal_pow_then_log_reading(oracle):
+    """the spec'd Mul term w * log_spec(p) against an INDEPENDENT restatement of the literal reading of
+    Fusion.cu:83-87 -- logf(powf(p, w)), p^w rounded to float32 before the log, libm on both calls.  (i) For probabilities a
+    network emits the two agree to 1e-5 on get(); (ii) where p^w underflows float32 (w * ln p < ~-103) the literal form yields
+    -inf and eliminates the class for good, the spec'd form keeps a finite term: the one known behavioural difference."""
+    rng = np.random.default_rng(5)
+    W, H, C, P = 48, 40, 6, 30
+    idx = rng.integers(0, P, (W, H)).astype(np.uint32)
+    oracle.set_accum_double(True)
+    try:
+        res = {}
+        for literal in (False, True):
+            oracle.set_mul_literal(literal)
+            agg = oracle.OracleAggregator(P, C, "mul", 0.5)
+            r2 = np.random.default_rng(6)
+            for view in range(4):
+                p = r2.random((W, H, C), dtype=np.float32) ** 2 + 1e-3
+                p /= p.sum(axis=-1, keepdims=True)
+                agg.add(idx, p, r2.random((W, H), dtype=np.float32) + 0.25)
+            res[literal] = agg.get()
+        np.testing.assert_allclose(res[False], res[True], rtol=1e-5, atol=1e-7)
+        # (ii) the divergence, pinned: one pixel, p = (1e-30, 1 - 1e-30), weight 4: p^w = 1e-120 underflows float32
+        out = {}
+        for literal in (False, True):
+            oracle.set_mul_literal(literal)
+            agg = oracle.OracleAggregator(1, 2, "mul", 0.0)
+            agg.add(np.zeros((1, 1), np.uint32), np.array([[[1e-30, 1.0]]], np.float32), np.full((1, 1), 4.0, np.float32))
+            out[literal] = agg.get_raw()[0]
+        assert np.isneginf(out[True][0]) and np.isfinite(out[False][0]) and abs(out[False][0] - 4 * np.log(1e-30)) < 1e-3
+    finally:
+        oracle.set_mul_literal(False)
+        oracle.set_accum_double(False)
+
+
+def test_edge_function_spec_against_the_five_operation_form(oracle):
+    """the spec'd edge function fma(A, px, fma(B, py, C)) (two roundings) against the round-1 form
+    sign * (dx (py - ly) - dy (px - lx)) (five), kept as an independent yardstick: they can only disagree on samples within a
+    rounding error of an edge.  cfg1 views: identical index images up to a handful of pixels, depth where they agree to 1e-6."""
+    from semantic_meshes_amd import synth
+    mesh, cams, _ = synth.scene("cfg1")
+    r = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    for cam in cams[:2]:
+        idx, depth = r.render(cam)
+        oracle.set_edge_five_op(True)
+        try:
+            idx5, depth5 = r.render(cam)
+        finally:
+            oracle.set_edge_five_op(False)
+        differ = idx != idx5
+        assert differ.mean() < 1e-4, differ.sum()
+        same = ~differ & (idx != BG)
+        np.testing.assert_allclose(depth[same], depth5[same], rtol=1e-6)
+        assert ((idx == BG) == (idx5 == BG)).mean() > 0.9999          # watertight either way: no cracks appear or vanish
+
+
 def test_ka9_shape_errors(oracle):
     agg = _simple(oracle)
     with pytest.raises(ValueError):
