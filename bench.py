@@ -245,7 +245,7 @@ def main():
         # render.texels(mesh, cameras): the texel resolution of a triangle comes from its largest projection over the workspace's
         # cameras (TexturedTriangleRenderer.h:87-127) -- here the config's whole ring, the same on every rank
         ctor_cams = [synth.ring_camera(k, cfg["views"], W, H) for k in range(cfg["views"])]
-        renderer = render.texels(mesh, ctor_cams, 0.1, device=device)
+        renderer = render.texels(mesh, ctor_cams, cfg.get("texels_per_pixel", 0.1), device=device)
     else:
         renderer = render.triangles(mesh, device=device)
     P = renderer.getPrimitivesNum()

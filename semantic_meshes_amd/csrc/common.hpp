@@ -119,6 +119,7 @@ struct TriFuseArgs {
   const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
   uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
   double* acc_d;              // Mul + texel primitives: [P][C] sums of ONE view's terms, all zero between launches (big triangles only)
+  uint32_t ps0, ps1;          // k_fuse_tri / fuse_box only: element strides of x and y of the class-vector image (dense: H * C and C); the class stride is 1
 };
 
 // What k_fuse_tri needs to know about ONE of the views it fuses in a launch (the per-view part of TriFuseArgs), and NV of them.
@@ -130,6 +131,7 @@ struct TriView {
   const uint32_t* big_queue;
   const uint32_t* big_len;    // [0] queue length, [1] "check the masks against the index plane" flag of the render
   uint32_t W, H;
+  uint32_t ps0, ps1;          // k_fuse_tri only: element strides of x and y of `probs` (dense: H * C and C; a (H,W,C) tensor seen as (W,H,C): C and W * C)
 };
 template <int NV>
 struct TriViews {
@@ -145,6 +147,7 @@ struct RenderedView {
   const float* probs;           // [W][H][C], device
   const float* weights;         // [W][H] or null, device
   uint64_t W, H;
+  int64_t ps0 = 0, ps1 = 0;     // element strides of x and y of `probs` when it is not the dense (W,H,C) image (class stride 1); 0, 0: dense
 };
 
 // Per-primitive records built from an arbitrary index image (image_records.hip): what lets MeshAggregator::add() run the

@@ -201,6 +201,14 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
   // U pixels per lane and step: their index loads, then their class vectors, are in flight together
   constexpr int U = CT <= 24 ? 4 : 2;
   auto pix_of = [&](long long i) -> uint64_t { return (uint64_t)(x0 + (int)(i / bh)) * a.H + (uint64_t)(y0 + (int)(i % bh)); };
+  // where pixel `pix` (= x * H + y) has its class vector: dense images at pix * C, strided ones (a network's (H,W,C) output seen
+  // as (W,H,C)) at x * ps0 + y * ps1
+  const bool dense_probs = a.ps1 == (uint32_t)C && a.ps0 == a.H * (uint32_t)C;
+  auto probs_at = [&](uint64_t pix) -> const float* {
+    if (dense_probs) return a.probs + pix * C;
+    const uint32_t x = (uint32_t)pix / a.H, y = (uint32_t)pix - x * a.H;
+    return a.probs + ((uint64_t)x * a.ps0 + (uint64_t)y * a.ps1);
+  };
   // this wave owns the row: its current value is requested now and written back at the end (plain read-modify-write)
   float row_value = (l < C) ? a.acc[(uint64_t)f * C + l] : 0.0f;
   const bool one_step = npx <= (long long)kWave * U;   // the whole box in one round of index loads
@@ -269,7 +277,7 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
     const uint64_t pix = lds_list[hit ? l : 0];
     wave_sync();   // the list is rewritten by this wave's next triangle
     float p[CT];
-    load_row<CT, EXACT>(a.probs + pix * C, C, p);
+    load_row<CT, EXACT>(probs_at(pix), C, p);
     const float wt = (a.weights && hit) ? a.weights[pix] : 1.0f;
     accumulate(p, hit, wt);
     // part[] is now ONE pixel's contribution per lane: instead of a butterfly per class (6 DPP steps each), the n vectors go
@@ -300,7 +308,7 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
       float wt[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const float* __restrict__ pr = a.probs + (hit[u] ? pix[u] : pix_of(0)) * C;   // unconditional: the loads overlap
+        const float* __restrict__ pr = probs_at(hit[u] ? pix[u] : pix_of(0));   // unconditional: the loads overlap
         load_row<CT, EXACT>(pr, C, p[u]);
         wt[u] = (a.weights && hit[u]) ? a.weights[pix[u]] : 1.0f;
       }
@@ -326,7 +334,7 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
 __device__ __forceinline__ TriFuseArgs with_view(const TriFuseArgs& a, const TriView& w) {
   TriFuseArgs x = a;
   x.frags = w.frags; x.idx = w.idx; x.probs = w.probs; x.weights = w.weights; x.big_queue = w.big_queue; x.big_len = w.big_len;
-  x.W = w.W; x.H = w.H;
+  x.W = w.W; x.H = w.H; x.ps0 = w.ps0; x.ps1 = w.ps1;
   return x;
 }
 
@@ -489,7 +497,9 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> 
         int k = 0;
         if (mm) { k = __ffsll((long long)mm) - 1; mm &= mm - 1ull; }
         const uint64_t pix = have[j] ? pixel(v, k) : 0;
-        const float* __restrict__ pr = probs + pix * C;
+        // (dense images: ps0 = H * C, ps1 = C; the strided (H,W,C) output of a network is read in place, colorize_cityscapes_mesh.py:65-67)
+        const float* __restrict__ pr = probs + (have[j] ? (uint64_t)((org[v] & 0xFFFFu) + (uint32_t)(k >> 3)) * vw.v[v].ps0 +
+                                                          (uint64_t)((org[v] >> 16) + (uint32_t)(k & 7)) * vw.v[v].ps1 : 0);
         load_row<CT, EXACT>(pr, C, p[j]);
         wt[j] = weights ? weights[pix] : 1.0f;
       }

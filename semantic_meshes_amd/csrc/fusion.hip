@@ -1591,9 +1591,19 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a,
     for (int v = 0; v < 8; v++) s_view[v] = vw.v[v];
   }
   __syncthreads();
+  // (round 3) Every step that can be issued for all views at once IS: the kernel is a chain of dependent memory round trips per
+  // lane (record -> index -> row / class vector, view after view), and its TCPs sat waiting on pending requests 63 % of the time.
+  // The eight records of a triangle are requested together (the short-circuit `seen = seen || ...` made them eight dependent
+  // loads for the seven triangles out of eight that no view sees), again after the compaction, and so is each view's first
+  // candidate pixel.
   bool seen = false;
-  if (f < a.F)
-    for (int v = 0; v < nv; v++) seen = seen || s_view[v].frags[f].kind == 1;
+  {
+    uint16_t kind[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) kind[v] = (v < nv && f < a.F) ? s_view[v].frags[f].kind : (uint16_t)0;
+#pragma unroll
+    for (int v = 0; v < 8; v++) seen = seen || kind[v] == 1;
+  }
   const unsigned long long ballot = __ballot(seen);
   if (l == 0) s_wave_count[wv] = (uint32_t)__popcll(ballot);
   __syncthreads();
@@ -1608,31 +1618,60 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a,
   __syncthreads();
   if ((uint32_t)t >= total) return;
   const uint32_t g = s_tri[t];
+  // this triangle in all views: box origin, mask of emitted fragments, and the index under the first of them -- all in flight together
+  uint32_t org[8], t0[8];
+  unsigned long long msk[8];
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    org[v] = 0u; msk[v] = 0ull;
+    if (v < nv) {
+      const TriFrag rec = s_view[v].frags[g];
+      org[v] = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
+      msk[v] = rec.kind == 1 ? rec.mask : 0ull;
+    }
+  }
   const uint32_t first = a.tex_first[g], res = a.tex_res[g], cnt = res * (res + 1u) / 2u;
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    t0[v] = 0xFFFFFFFFu;
+    if (v < nv && msk[v]) {
+      const int k = __ffsll((long long)msk[v]) - 1;
+      t0[v] = s_view[v].idx[(uint64_t)((org[v] & 0xFFFFu) + (uint32_t)(k >> 3)) * s_view[v].H + (org[v] >> 16) + (uint32_t)(k & 7)];
+    }
+  }
   float accr[kSlice];
   constexpr int NL = KIND == SMESH_AGG_MUL ? kSlice : 1;
   float lo[NL];                 // Mul: the row's second plane
   uint32_t cur = 0xFFFFFFFFu;   // texel whose row is in accr
   bool dirty = false;
-  for (int v = 0; v < nv; v++) {
-    const TriFrag rec = s_view[v].frags[g];
-    if (rec.kind != 1) continue;
+#pragma unroll
+  for (int v = 0; v < 8; v++) {
+    if (v >= nv || msk[v] == 0ull) continue;
     const uint32_t* __restrict__ idx = s_view[v].idx;
     const float* __restrict__ probs = s_view[v].probs;
     const float* __restrict__ weights = s_view[v].weights;
     const uint32_t Hv = s_view[v].H;
-    auto pixel = [&](int k) -> uint64_t { return (uint64_t)(rec.x0 + (k >> 3)) * Hv + rec.y0 + (k & 7); };
+    const uint32_t ox = org[v] & 0xFFFFu, oy = org[v] >> 16;
+    auto pixel = [&](int k) -> uint64_t { return (uint64_t)(ox + (uint32_t)(k >> 3)) * Hv + oy + (uint32_t)(k & 7); };
     // which emitted fragments won the depth test (the pixel then holds one of this triangle's texels)
-    unsigned long long win = 0ull;
-    for (unsigned long long m = rec.mask; m; m &= m - 1ull) {
+    const int kfirst = __ffsll((long long)msk[v]) - 1;
+    unsigned long long win = (t0[v] - first < cnt) ? 1ull << kfirst : 0ull;
+    for (unsigned long long m = msk[v] & (msk[v] - 1ull); m; m &= m - 1ull) {
       const int k = __ffsll((long long)m) - 1;
       if (idx[pixel(k)] - first < cnt) win |= 1ull << k;
     }
+    const bool single = win == (1ull << kfirst);   // the first candidate is the only visible pixel: its texel is t0, its count 1 -- no further index loads
     for (unsigned long long m = win; m; m &= m - 1ull) {
       const uint64_t pix = pixel(__ffsll((long long)m) - 1);
-      const uint32_t tex = idx[pix];
-      uint32_t n = 0;                                   // Mesh.h:90-93 restricted to this triangle's pixels
-      for (unsigned long long m2 = win; m2; m2 &= m2 - 1ull) n += idx[pixel(__ffsll((long long)m2) - 1)] == tex ? 1u : 0u;
+      uint32_t tex = t0[v], n = 1u;
+      if (!single) {
+        tex = idx[pix];
+        n = 0u;                                           // Mesh.h:90-93 restricted to this triangle's pixels
+        for (unsigned long long m2 = win; m2; m2 &= m2 - 1ull) n += idx[pixel(__ffsll((long long)m2) - 1)] == tex ? 1u : 0u;
+      }
+      // the class vector and (if it is not the one in registers) the texel's row: requested together
+      float p[kSlice];
+      load_slice(probs + pix * C, (int)C, p);
       if (tex != cur) {
         if (dirty) {
           store_slice(a.acc + (uint64_t)cur * C, (int)C, accr);
@@ -1643,8 +1682,6 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a,
         cur = tex;
         dirty = false;
       }
-      float p[kSlice];
-      load_slice(probs + pix * C, (int)C, p);
       const float wt = weights ? weights[pix] : 1.0f;
       float sum = 0.0f, best = p[0];
       int am = 0;
@@ -2177,6 +2214,7 @@ const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordere
 }
 
 int smesh_aggregator_max_fused_views(smesh_aggregator* a);
+bool smesh_aggregator_takes_strided_probs(smesh_aggregator* a, int64_t ps0, int64_t ps1, int nviews);
 bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a) { return smesh_aggregator_max_fused_views(a) >= 2; }
 
 // How many views one k_fuse_tri launch takes for this aggregator: 8 for class counts up to 40 (the per-view state is 3 registers:
@@ -2192,6 +2230,15 @@ int smesh_aggregator_max_fused_views(smesh_aggregator* a) {
   return std::min(m, cap);
 }
 
+// Can the triangle-order fusion of this aggregator read class vectors in place at element strides (ps0, ps1, 1) -- the (H,W,C)
+// output of a network seen as (W,H,C), colorize_cityscapes_mesh.py:65-67 -- instead of a gathered copy?  k_fuse_tri (C <= 48)
+// addresses every pixel's vector on its own; the wide-row kernels keep their dense layout.
+bool smesh_aggregator_takes_strided_probs(smesh_aggregator* a, int64_t ps0, int64_t ps1, int nviews) {
+  static const bool off = getenv("SMESH_STRIDED_PROBS") && atoi(getenv("SMESH_STRIDED_PROBS")) == 0;
+  if (off || ps0 <= 0 || ps1 <= 0 || ps0 > 0xFFFFFFFFll || ps1 > 0xFFFFFFFFll) return false;
+  return a->C <= kFuseTriMaxC && !(a->C > 40u && nviews > 2);
+}
+
 // `nviews` = 1, or 2 (smesh_aggregator_can_fuse_pair): views[0] then views[1] of the same renderer in one launch.
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews) {
@@ -2205,13 +2252,18 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   TriViews<8> tv;
   for (int v = 0; v < 8; v++) {
     const RenderedView& rv = views[v < nviews ? v : 0];
-    tv.v[v] = TriView{rv.frags, rv.idx, rv.probs, rv.weights, rv.big_queue, rv.big_len, (uint32_t)rv.W, (uint32_t)rv.H};
+    tv.v[v] = TriView{rv.frags, rv.idx, rv.probs, rv.weights, rv.big_queue, rv.big_len, (uint32_t)rv.W, (uint32_t)rv.H,
+                      rv.ps0 ? (uint32_t)rv.ps0 : (uint32_t)(rv.H * a->C), rv.ps1 ? (uint32_t)rv.ps1 : a->C};
   }
+  for (int v = 0; v < nviews; v++)
+    if ((views[v].ps0 || views[v].ps1) && !smesh_aggregator_takes_strided_probs(a, views[v].ps0, views[v].ps1, nviews))
+      return fail(SMESH_ERR_INVALID, "fuse_triangles: strided class vectors need the narrow-row kernel");
   for (int v = 0; v < 1; v++) {
     const RenderedView& rv = views[0];
     TriFuseArgs& x = t;
     x.frags = rv.frags; x.idx = rv.idx; x.probs = rv.probs; x.weights = rv.weights; x.acc = a->acc; x.acc_lo = a->acc_lo; x.F = F; x.C = a->C;
     x.W = (uint32_t)rv.W; x.H = (uint32_t)rv.H; x.iew = a->iew; x.big_queue = rv.big_queue; x.big_len = rv.big_len;
+    x.ps0 = tv.v[0].ps0; x.ps1 = tv.v[0].ps1;
     x.big_capacity = big_capacity;
     x.tri_blocks = (uint32_t)div_up(F, kWave);
     { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; x.dbg = fdbg; }

@@ -40,6 +40,7 @@ int smesh_aggregator_add_device_contig(smesh_aggregator* a, const uint32_t* d_id
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
 bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a);
 int smesh_aggregator_max_fused_views(smesh_aggregator* a);
+bool smesh_aggregator_takes_strided_probs(smesh_aggregator* a, int64_t ps0, int64_t ps1, int nviews);
 int smesh_aggregator_dense_probs(smesh_aggregator* a, const float* d_probs, const int64_t ps[3], uint64_t W, uint64_t H, const float** out);
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews);
@@ -870,7 +871,12 @@ __device__ __forceinline__ void raster_huge_block(const RasterArgs& a, const uin
   if (any) atomicOr(&q.flag[tile], 2u);
 }
 
-__global__ __launch_bounds__(256) void k_raster_huge(RasterArgs a) { raster_huge_block(a, blockIdx.x); }
+// (a grid of a few hundred workgroups walking the tiles: with the queue empty -- the usual case -- the launch is over in the time
+// it takes that many waves to read one counter)
+__global__ __launch_bounds__(256) void k_raster_huge(RasterArgs a, uint32_t ntiles) {
+  if (min(a.big_count[2], a.big_capacity) == 0u) return;
+  for (uint32_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) { raster_huge_block(a, tile); __syncthreads(); }
+}
 
 // One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
 // > 8 x 8: the workgroup scans their queue, keeps those whose box overlaps the tile and shades the overlap, 256
@@ -960,9 +966,15 @@ __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __
 }
 
 __global__ __launch_bounds__(256) void k_raster_huge_group(RasterGroup g) {
-  uint32_t v = 0;
-  while (v + 1 < g.n && blockIdx.x >= g.tile_end[v]) v++;   // block-uniform, n <= kMaxGroup
-  raster_huge_block(g.view[v], blockIdx.x - (v ? g.tile_end[v - 1] : 0u));
+  bool any = false;
+  for (uint32_t v = 0; v < g.n; v++) any = any || min(g.view[v].big_count[2], g.view[v].big_capacity) != 0u;
+  if (!any) return;
+  for (uint32_t tile = blockIdx.x; tile < g.tile_end[g.n - 1]; tile += gridDim.x) {
+    uint32_t v = 0;
+    while (v + 1 < g.n && tile >= g.tile_end[v]) v++;   // block-uniform, n <= kMaxGroup
+    raster_huge_block(g.view[v], tile - (v ? g.tile_end[v - 1] : 0u));
+    __syncthreads();
+  }
 }
 
 // Several views in one launch (index planes only).
@@ -1262,7 +1274,8 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
       a.q = vs.fq;
       hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(div_up(r->F, a.tpw), 4)), dim3(256), 0, st, a);
       SMESH_HIP(hipGetLastError());
-      hipLaunchKernelGGL(k_raster_huge, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a);
+      const uint32_t ntiles = (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
+      hipLaunchKernelGGL(k_raster_huge, dim3(std::min<uint32_t>(ntiles, 2u * (uint32_t)ctx->num_cus)), dim3(256), 0, st, a, ntiles);
       SMESH_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_tile_resolve, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a, d_idx, d_depth);
       SMESH_HIP(hipGetLastError());
@@ -1367,7 +1380,7 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   SMESH_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_raster_frag_group, dim3((uint32_t)n * rg.blocks_per_view), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_raster_huge_group, dim3(tiles), dim3(256), 0, st, rg);
+  hipLaunchKernelGGL(k_raster_huge_group, dim3(std::min<uint32_t>(tiles, 4u * (uint32_t)ctx->num_cus)), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_tile_resolve_group, dim3(tiles), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
@@ -1517,7 +1530,7 @@ void smesh_note_fuse(const char* kernel, const char* path) { g_last_fuse_kernel 
 // The fusion half of smesh_fuse_view / smesh_aggregator_add_rendered: `d_idx` is the index plane of the render
 // whose per-triangle records sit in r->side[slot].
 static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const uint32_t* d_idx, const float* probs,
-                         const float* weights, int memkind, uint64_t W, uint64_t H) {
+                         const float* weights, int memkind, uint64_t W, uint64_t H, int64_t ps0 = 0, int64_t ps1 = 0) {
   DeviceCtx* ctx = r->ctx;
   const uint64_t N = W * H;
   const float* d_probs = probs;
@@ -1538,7 +1551,8 @@ static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const
   }
   if (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) {
     // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
-    const RenderedView rv{r->side[slot].frags, r->side[slot].big_queue, r->side[slot].big_count, d_idx, d_probs, d_w, W, H};
+    // (ps0, ps1: DEVICE class vectors with element strides (ps0, ps1, 1), read in place by k_fuse_tri; 0, 0: the dense image)
+    const RenderedView rv{r->side[slot].frags, r->side[slot].big_queue, r->side[slot].big_count, d_idx, d_probs, d_w, W, H, ps0, ps1};
     SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, &rv, 1));
     smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr), "render-records");
   } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
@@ -1999,6 +2013,11 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
       // host synchronisation per view would serialise the reference's two-call loop on launch latencies (0.10 -> 0.21 ms per
       // cfg2 view).  Callers order the buffers' next use after the library with smesh_stream_release (no host wait) or
       // smesh_synchronize; the Python layer does the former for every array that is not the library's own.
+      // strided class vectors (the (H,W,C) output of a network seen as (W,H,C), colorize_cityscapes_mesh.py:65-67): k_fuse_tri
+      // reads them where they are; the wide-row and texel kernels get a gathered copy (315 MB more traffic per cfg2-sized view)
+      if (strided_dev && !r->texels && probs_strides[2] == 1 && !(reinterpret_cast<uintptr_t>(probs) & 3) &&
+          smesh_aggregator_takes_strided_probs(a, probs_strides[0], probs_strides[1], 1))
+        return fuse_rendered(r, a, side, idx_dev, probs, weights, probs_mem, W, H, probs_strides[0], probs_strides[1]);
       if (strided_dev) SMESH_TRY(smesh_aggregator_dense_probs(a, probs, probs_strides, W, H, &probs));
       return fuse_rendered(r, a, side, idx_dev, probs, weights, probs_mem, W, H);
     }
@@ -2024,9 +2043,13 @@ int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
   DeviceCtx* ctx = r->ctx;
   const int64_t C = (int64_t)smesh_aggregator_classes(a);
   if ((idx_dtype != SMESH_IDX_U32 && idx_dtype != SMESH_IDX_I32) || idx_strides[0] != (int64_t)H || idx_strides[1] != 1 || W == 0 || H == 0 ||
-      smesh_aggregator_ctx(a) != ctx || probs_strides[0] != (int64_t)H * C || probs_strides[1] != C || probs_strides[2] != 1 ||
-      (weights && (w_mem != probs_mem || w_strides[0] != (int64_t)H || w_strides[1] != 1)))
-    return SMESH_OK;   // only dense images can take the triangle-order kernels
+      smesh_aggregator_ctx(a) != ctx || (weights && (w_mem != probs_mem || w_strides[0] != (int64_t)H || w_strides[1] != 1)))
+    return SMESH_OK;   // only dense index / weight images can take the triangle-order kernels
+  const bool dense_probs = probs_strides[0] == (int64_t)H * C && probs_strides[1] == C && probs_strides[2] == 1;
+  // ... and dense class vectors, or DEVICE ones that k_fuse_tri can read in place at their strides
+  const bool strided_ok = !dense_probs && probs_mem == SMESH_MEM_DEVICE && !r->texels && probs_strides[2] == 1 &&
+                          !(reinterpret_cast<uintptr_t>(probs) & 3) && smesh_aggregator_takes_strided_probs(a, probs_strides[0], probs_strides[1], 1);
+  if (!dense_probs && !strided_ok) return SMESH_OK;
   std::lock_guard<std::mutex> g(r->mu);
   std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
@@ -2062,7 +2085,8 @@ int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
   for (int sd = 0; sd < kRecordSides; sd++)
     if (r->rec_valid[sd] && r->hash_valid[sd] && r->last_W[sd] == W && r->last_H[sd] == H && h[sd] == h[kRecordSides]) side = sd;
   if (side < 0) return SMESH_OK;
-  SMESH_TRY(fuse_rendered(r, a, side, d_img, probs, weights, probs_mem, W, H));   // asynchronous for DEVICE images, see smesh_aggregator_add_rendered
+  SMESH_TRY(fuse_rendered(r, a, side, d_img, probs, weights, probs_mem, W, H, dense_probs ? 0 : probs_strides[0],
+                          dense_probs ? 0 : probs_strides[1]));   // asynchronous for DEVICE images, see smesh_aggregator_add_rendered
   *matched = 1;
   return SMESH_OK;
 }

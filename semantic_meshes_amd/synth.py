@@ -18,6 +18,9 @@ CONFIGS = {
     "cfg1": dict(a=100, b=50, width=640, height=480, classes=5, views=4),
     "cfg2": dict(a=1000, b=500, width=1920, height=1080, classes=19, views=200),
     "cfg4": dict(a=2500, b=1000, width=1296, height=968, classes=40, views=1000, texels=True),   # render.texels path
+    # cfg4's mesh and cameras with texels_per_pixel 5: the sub-pixel triangles get r = 3 (six texels each, 30 M primitives, a 4.8 GB
+    # accumulator) -- the texel shader (TexturedTriangleRenderer.h:31-41) is exercised with r > 1, which cfg4's default 0.1 never does
+    "cfg4t": dict(a=2500, b=1000, width=1296, height=968, classes=40, views=1000, texels=True, texels_per_pixel=5.0),
     "cfg5": dict(a=5000, b=2000, width=4096, height=2160, classes=150, views=500),
 }
 

@@ -188,6 +188,52 @@ def test_cfg4_full_size_properties(sm):
     np.testing.assert_allclose(plain.get_raw().astype(np.float64).sum(), hp[keep].astype(np.float64).sum(), rtol=1e-5)
 
 
+def test_cfg4t_multi_texel_full_size_properties(sm):
+    """cfg4's mesh with texels_per_pixel 5 (`bench.py --workload cfg4t`): the sub-pixel triangles get three texel rows
+    (six texels each), so the texel shader runs with r > 1 at full size.  Size-independent properties."""
+    from semantic_meshes_amd import synth
+    cfg = synth.CONFIGS["cfg4t"]
+    W, H, C = cfg["width"], cfg["height"], cfg["classes"]
+    mesh = synth.grid_mesh(cfg["a"], cfg["b"])
+    ctor_cams = [synth.ring_camera(k, cfg["views"], W, H) for k in range(0, cfg["views"], 50)]
+    r = sm.render.texels(mesh, ctor_cams, cfg["texels_per_pixel"])
+    P = r.getPrimitivesNum()
+    _, res, first = r.texel_layout()
+    assert np.median(res) >= 3 and P == int((res.astype(np.int64) * (res + 1) // 2).sum()) > 25_000_000          # KA10
+    views = [3, 400, 777]
+    cams = [synth.ring_camera(k, cfg["views"], W, H) for k in views]
+    probs = [synth.device_probs(W, H, C, synth.probs_seed(4, k), 0.02) for k in views]
+    idx_a = np.asarray(r.render(cams[0])[0])
+    assert np.array_equal(idx_a, np.asarray(r.render(cams[0])[0]))                               # idempotent
+    valid = idx_a[idx_a != BG]
+    assert valid.max() < P and (idx_a != BG).mean() > 0.4
+    # every visible texel belongs to a triangle with texels, and all of a triangle's texel slots are hit somewhere in the image
+    tri = np.searchsorted(first.astype(np.int64), valid.astype(np.int64), side="right") - 1
+    local = valid.astype(np.int64) - first[tri].astype(np.int64)
+    assert (local < res[tri].astype(np.int64) * (res[tri] + 1) // 2).all()
+    assert len(np.unique(local)) >= 6                                                           # r >= 3: texels 0 .. 5 all occur
+    whole = sm.fusion.MeshAggregator(P, C)
+    parts = [sm.fusion.MeshAggregator(P, C) for _ in views]
+    whole.fuse_views(r, cams, probs)
+    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_texel"
+    for cam, p, part in zip(cams, probs, parts):
+        part.fuse_view(r, cam, p)
+    # shard-sum identity on every fifth block of a million rows (the whole 4.8 GB accumulator in float64 is 10 GB of host memory)
+    raw = whole.get_raw()
+    part_raw = [part.get_raw() for part in parts]
+    del parts
+    for lo in range(0, P, 5_000_000):
+        sl = slice(lo, min(lo + 1_000_000, P))
+        np.testing.assert_allclose(raw[sl], sum(p[sl].astype(np.float64) for p in part_raw), rtol=1e-5, atol=1e-6)
+    assert (raw.sum(axis=1) > 0).sum() > 1_000_000
+    del raw, part_raw
+    plain = sm.fusion.MeshAggregator(P, C, "sum", 0.0)       # mass conservation with iew = 0
+    plain.fuse_view(r, cams[0], probs[0])
+    hp = np.asarray(probs[0]).reshape(-1, C)
+    keep = (idx_a.reshape(-1) != BG) & (hp.sum(axis=1) > 0.5)
+    np.testing.assert_allclose(plain.get_raw().astype(np.float64).sum(), hp[keep].astype(np.float64).sum(), rtol=1e-5)
+
+
 def test_cfg5_class_count_and_resolution_parity_on_the_1m_triangle_mesh(sm, oracle):
     """BASELINE cfg5's fusion kernel (k_fuse_tri_wide, C = 150) at cfg5's resolution (4096x2160, 5.3 GB of class vectors per
     view) on the 1 M-triangle mesh, which the oracle affords: indices and depth bit-exact, Sum's raw accumulator to 2e-6."""
