@@ -119,6 +119,7 @@ struct TriFuseArgs {
   const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
   uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
   double* acc_d;              // Mul + texel primitives: [P][C] sums of ONE view's terms, all zero between launches (big triangles only)
+  int mid;                    // k_fuse_tri: nonzero = k_fuse_mid takes the queued triangles with at most kMidBox pixels per view (the tail waves skip them)
   uint32_t ps0, ps1;          // k_fuse_tri / fuse_box only: element strides of x and y of the class-vector image (dense: H * C and C); the class stride is 1
 };
 

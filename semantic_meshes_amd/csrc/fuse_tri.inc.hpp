@@ -338,44 +338,77 @@ __device__ __forceinline__ TriFuseArgs with_view(const TriFuseArgs& a, const Tri
   return x;
 }
 
+// Medium triangles -- a box of at most kMidBox pixels in every view of the launch -- are fused by k_fuse_mid (fusion_mid.hip: sixteen
+// lanes per triangle, four triangles per wave) when TriFuseArgs::mid is set; the tail waves below then leave them alone.
+constexpr int kMidBox = 1024;
+__device__ __forceinline__ bool mid_box(const TriFrag& rec, uint32_t W, uint32_t H) {
+  (void)W; (void)H;
+  if (rec.kind != 2) return true;                        // nothing emitted here, or a box of at most 8 x 8
+  const int w = (int)(rec.mask & 0xFFFFu) - (int)rec.x0 + 1, h = (int)((rec.mask >> 16) & 0xFFFFu) - (int)rec.y0 + 1;
+  return w * h <= kMidBox;
+}
+
 template <int CT, int KIND, bool EXACT, int NV>
 __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const TriViews<NV>& vw, uint32_t worker, uint32_t nworkers,
                                                    uint32_t* __restrict__ lds_list) {
   uint32_t len[NV], total = 0u;
 #pragma unroll
   for (int v = 0; v < NV; v++) { len[v] = min(*vw.v[v].big_len, a.big_capacity); total += len[v]; }
-  for (uint32_t q = worker; q < total; q += nworkers) {
+  const int l = threadIdx.x;
+  // `chunk` queue entries per step, one per lane: which of them are this wave's to fuse is decided for all of them at once (the
+  // entry, its record, the records of the earlier views: loads in flight together), then the wave takes the chosen ones one after
+  // the other.  (Round 2 walked the entries one per step: two dependent round trips per entry, seven out of eight of them
+  // rejected -- a triangle sits in the queue of every view in which it is big and is taken from the first.)  The chunk grows
+  // with the queues -- one entry per step while there are fewer entries than tail waves, so that a few expensive triangles
+  // still spread over all of them, 64 when there are many.
+  // With a.mid the MEDIUM views are k_fuse_mid's: an entry counts only if its triangle is LARGE (over kMidBox pixels) in the
+  // entry's view, and is taken from the first view in which it is large.
+  const uint32_t chunk = max(1u, min((uint32_t)kWave, total / max(nworkers, 1u)));
+  for (uint32_t q0 = worker * chunk; q0 < total; q0 += nworkers * chunk) {
+    const uint32_t q = (uint32_t)l < chunk ? q0 + (uint32_t)l : total;
     uint32_t fi = 0u;
     bool take = false;
     {
       uint32_t qq = q;
-      bool earlier_done = false;   // the queue entry has been located
+      bool located = q >= total;
+      int jsel = -1;
 #pragma unroll
-      for (int j = 0; j < NV; j++) {   // wave-uniform: q is
-        if (!earlier_done) {
-          if (qq < len[j]) {
-            fi = vw.v[j].big_queue[qq];
-            take = vw.v[j].frags[fi].kind == 2;
-#pragma unroll
-            for (int i = 0; i < NV; i++) if (i < j && vw.v[i].frags[fi].kind == 2) take = false;   // an earlier view's queue has it
-            earlier_done = true;
-          } else {
-            qq -= len[j];
-          }
+      for (int j = 0; j < NV; j++) {
+        if (!located) {
+          if (qq < len[j]) { fi = vw.v[j].big_queue[qq]; jsel = j; located = true; }
+          else qq -= len[j];
         }
       }
-    }
-    if (!take) continue;
-    const uint32_t f = a.prim_id ? a.prim_id[fi] : fi;        // primitive id = value in the index image = accumulator row
+      if (jsel >= 0) {
+        bool mine = false, earlier = false;
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-      const TriFrag rec = vw.v[j].frags[fi];
-      if (rec.kind == 0) continue;
-      const TriFuseArgs x = with_view(a, vw.v[j]);
-      int x1, y1;
-      if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
-      else { x1 = min((int)rec.x0 + 7, (int)x.W - 1); y1 = min((int)rec.y0 + 7, (int)x.H - 1); }
-      fuse_box<CT, KIND, EXACT>(x, f, rec.x0, rec.y0, x1, y1, lds_list);
+        for (int i = 0; i < NV; i++) {
+          if (i <= jsel) {
+            const TriFrag rec = vw.v[i].frags[fi];
+            const bool counts = rec.kind == 2 && !(a.mid && mid_box(rec, vw.v[i].W, vw.v[i].H));
+            if (i < jsel) earlier = earlier || counts;
+            else mine = counts;
+          }
+        }
+        take = mine && !earlier;
+      }
+    }
+    unsigned long long todo = __ballot(take);
+    while (todo) {
+      const int src = __ffsll((long long)todo) - 1;
+      todo &= todo - 1ull;
+      const uint32_t fq = (uint32_t)__builtin_amdgcn_readlane((int)fi, src);   // wave-uniform
+      const uint32_t f = a.prim_id ? a.prim_id[fq] : fq;        // primitive id = value in the index image = accumulator row
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        const TriFrag rec = vw.v[j].frags[fq];
+        if (rec.kind == 0 || (a.mid && rec.kind == 2 && mid_box(rec, 0u, 0u))) continue;   // (a medium view: k_fuse_mid's)
+        const TriFuseArgs x = with_view(a, vw.v[j]);
+        int x1, y1;
+        if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
+        else { x1 = min((int)rec.x0 + 7, (int)x.W - 1); y1 = min((int)rec.y0 + 7, (int)x.H - 1); }
+        fuse_box<CT, KIND, EXACT>(x, f, rec.x0, rec.y0, x1, y1, lds_list);
+      }
     }
   }
 }
@@ -409,7 +442,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> 
       const TriFrag rec = vw.v[v].frags[f];
       org[v] = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
       msk[v] = rec.kind == 1 ? rec.mask : 0ull;
-      big = big || rec.kind == 2;
+      big = big || (rec.kind == 2 && !(a.mid && mid_box(rec, 0u, 0u)));   // (a.mid: medium views are k_fuse_mid's, the row stays this lane's)
     }
   }
   if (big) {

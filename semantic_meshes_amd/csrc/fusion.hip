@@ -37,6 +37,8 @@
 
 using namespace smesh;
 
+// fusion_mid.hip: k_fuse_mid, the queued triangles of at most kMidBox pixels per view, sixteen lanes each
+void smesh_launch_fuse_mid(int kind, int slots, int nviews, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv);
 // fusion_pair.hip: k_fuse_tri<CT, KIND, EXACT, 2> for the class-count slot `tri_ct` chosen below
 void smesh_launch_fuse_tri_multi(int kind, int tri_ct, int nviews, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv);
 
@@ -2269,6 +2271,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; x.dbg = fdbg; }
     x.tex_first = nullptr; x.tex_res = nullptr; x.count = nullptr; x.acc_d = nullptr;
     x.prim_id = prim_id;
+    x.mid = 0;
   }
   // k_fuse_tri (row in registers; the wave's 64-row block staged through LDS unless the mesh was re-ordered) takes C <= 48: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 48 for the rest
   // (tri_ct 41 = the run-time instance with 40 slots).
@@ -2340,6 +2343,16 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     }
     TriViews<1> tv1;
     tv1.v[0] = tv.v[0];
+    if (specialised) {
+      // medium triangles first (their rows are nobody else's: the main waves leave the rows of queued triangles alone, the tail waves
+      // skip what t.mid hands to k_fuse_mid); a few waves per SIMD walking the queues, gone at once when the queues are empty
+      static const int mid_mode = getenv("SMESH_FUSE_MID") ? atoi(getenv("SMESH_FUSE_MID")) : 1;   // (2 / 3: development, half of the hand-over each)
+      if (mid_mode && a->kind != SMESH_AGG_MUL) {      // (Mul's (hi, lo) rows cannot take k_fuse_mid's atomics)
+        t.mid = mid_mode == 2 ? 0 : 1;
+        const int slots = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : a->C <= 40 ? 40 : 48;
+        if (mid_mode != 3) smesh_launch_fuse_mid(a->kind, slots, nviews, dim3(6u * (uint32_t)std::max(1, ctx->num_cus)), st, t, tv);
+      }
+    }
     if (nviews >= 2 && specialised) {   // the several-view instances of k_fuse_tri live in fusion_pair.hip / fusion_multi*.hip
       smesh_launch_fuse_tri_multi(a->kind, tri_ct, nviews, grid, st, t, tv);
     } else

@@ -1224,8 +1224,9 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   a.frags = r->side[side].frags;
   { static const int rdbg = getenv("SMESH_RDBG") ? atoi(getenv("SMESH_RDBG")) : 0; a.dbg = rdbg; }
   a.q = FragQueues();
-  a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~2048 waves
-  while (a.tpw > 1 && r->F / a.tpw < 2048) a.tpw >>= 1;
+  a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~kMinWaves waves
+  static const uint64_t min_waves = getenv("SMESH_RASTER_MIN_WAVES") ? (uint64_t)std::max(1, atoi(getenv("SMESH_RASTER_MIN_WAVES"))) : 2048u;
+  while (a.tpw > 1 && r->F / a.tpw < min_waves) a.tpw >>= 1;
   a.groups = 1;  // (frag_groups() decides per launch)
   return a;
 }
