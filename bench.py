@@ -49,6 +49,58 @@ def prof_read(device, slot):
     return ms.value, int(r.value), int(n.value), int(v.value)
 
 
+def pmc_traffic(workload, kernel_prefix, views_per_launch, group_pipeline=False):
+    """HBM bytes per launch of the dominant kernel, measured NOW (`--pmc`): two short runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes (the TCC
+    block cannot count both at once) -- and traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950: FETCH_SIZE counts 64 B per
+    128-byte request), averaged over the launches of the kernel instance that fuses `views_per_launch` views."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not found"
+    per = {}
+    tmp = tempfile.mkdtemp(prefix="smesh_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--no-host-path"]
+            if group_pipeline:
+                cmd.append("--group-pipeline")
+            env = dict(os.environ, TMPDIR="/tmp")
+            env.pop("RANK", None)
+            try:
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s timed out" % counter
+            path = None
+            for dirpath, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("counter_collection.csv"):
+                        path = os.path.join(dirpath, f)
+            if path is None:
+                return None, "rocprofv3 --pmc %s wrote no counter file" % counter
+            acc, cnt = {}, {}
+            for row in csv.DictReader(open(path)):
+                name = row["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+                acc[name] = acc.get(name, 0.0) + float(row["Counter_Value"])
+                cnt[name] = cnt.get(name, 0) + 1
+            per[counter] = {n: acc[n] / cnt[n] for n in acc}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    # the instance that takes `views_per_launch` views: k_fuse_tri<C, kind, exact, NV>; the run-time-view kernels have one instance
+    cands = [n for n in per["FETCH_SIZE"] if kernel_prefix in n and n in per["WRITE_SIZE"]]
+    exact = [n for n in cands if n.rstrip(">").endswith(", %d" % views_per_launch)]
+    name = (exact or sorted(cands, key=lambda n: -per["FETCH_SIZE"][n]) or [None])[0]
+    if name is None:
+        return None, "no launch of %s in the counter files" % kernel_prefix
+    traffic = int((2.0 * per["FETCH_SIZE"][name] + per["WRITE_SIZE"][name]) * 1024)
+    return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --workload %s --steps 16 "
+                     "--warmup 8`, kernel %s: (2 x %.0f + %.0f) KiB" % (workload, name, per["FETCH_SIZE"][name], per["WRITE_SIZE"][name]))
+
+
 def cpu_baseline(workload, budget_s=20.0):
     """The CPU oracle (a port of the reference's CPU fusion, include/semantic_meshes/fusion/Mesh.h:90-106,
     plus a CPU rasteriser -- the reference renders on CUDA only) timed on this box's host cores on a bounded
@@ -196,6 +248,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true", help="also for workloads other than cfg2 (slow: the oracle at that size)")
     ap.add_argument("--no-host-path", action="store_true")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic in this run: two extra short passes of this script under rocprofv3 --pmc (about a minute)")
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("SMESH_BENCH_VIEWS_PER_CALL", "8")),
                     help="views handed to the library per call (fuse_views; 1 = one fuse_view call per view)")
     ap.add_argument("--group-pipeline", action="store_true",
@@ -415,14 +469,28 @@ def main():
         achieved = bytes_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         achieved_needed = needed_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "fusion_traffic.json")
-        if os.path.exists(tpath) and args.workload == "cfg2":
+        vpl_int = int(round(views_per_launch)) if views_per_launch else 1
+        if args.pmc and world == 1:
             try:
-                tkey = fuse_kernel + ("_x8" if views_per_launch > 6 else "_pair" if views_per_launch > 1.5 else "")
-                traffic = json.load(open(tpath)).get(tkey, {}).get("hbm_bytes_per_launch")
-                traffic_source = "profiles/fusion_traffic.json (PMC passes of an earlier run of this command; not measured in this run)"
-            except Exception:
-                traffic = None
+                traffic, traffic_source = pmc_traffic(args.workload, fuse_kernel, vpl_int, args.group_pipeline)
+            except Exception as e:
+                traffic, traffic_source = None, "pmc passes failed: %s" % str(e)[:160]
+        if traffic is None:
+            # not measured in this run (the default: two more passes of the whole script under rocprofv3 take a minute): the
+            # committed PMC summary of this round, for the kernel instance that ran
+            note = traffic_source
+            tpath = os.path.join(ROOT, "profiles", "fusion_traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    tkey = "%s:%s" % (args.workload, fuse_kernel) + ("_x8" if views_per_launch > 6 else "_pair" if views_per_launch > 1.5 else "")
+                    entry = json.load(open(tpath)).get(tkey)
+                    if entry:
+                        traffic = entry.get("hbm_bytes_per_launch")
+                        traffic_source = "profiles/fusion_traffic.json [%s] (committed PMC passes of this round; `--pmc` measures it in the run)" % tkey
+                except Exception:
+                    traffic = None
+            if traffic is None and note:
+                traffic_source = note
         out = {
             "metric": ("views/sec fused (1080p, 19 classes, 1M-tri mesh)" if args.workload == "cfg2" else
                        "views/sec fused (%s: %dx%d, %d classes, %d triangles%s)" % (args.workload, W, H, C, F,
@@ -452,14 +520,18 @@ def main():
                        "timed_region_ms": round(1e3 * dt, 3),
                        "host_syncs_in_timed_region": 1 if (comm is not None or dist is None) else 4,
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
-            "roofline": {"kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),
+            # frac_needed first: the fraction by the bytes the kernel HAS to move (visible pixels' class vectors, records, touched
+            # rows once per launch); `frac` is SURVEY.md 8(d)'s formula, which also charges the class vectors of background
+            # pixels and a row round trip per view that the kernel does not perform -- it flatters
+            "roofline": {"frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4),
+                         "kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),
                          "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_traffic": (round(traffic / max(t_launch, 1e-12) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
                          "algorithmic_bytes_per_view": int(bytes_per_view),
                          "algorithmic_bytes_per_launch": int(bytes_per_view * views_per_launch),
                          "needed_bytes_per_view": int(needed_per_view),
-                         "frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4),
                          "views_per_launch": (int(views_per_launch) if views_per_launch == int(views_per_launch)
                                               else round(views_per_launch, 3)),
                          "launches_by_views": {str(k): v for k, v in sorted(mix.items(), reverse=True)} or None,

@@ -149,7 +149,12 @@ struct RenderedView {
   const float* weights;         // [W][H] or null, device
   uint64_t W, H;
   int64_t ps0 = 0, ps1 = 0;     // element strides of x and y of `probs` when it is not the dense (W,H,C) image (class stride 1); 0, 0: dense
+  bool mid_queue = false;       // big_queue[big_capacity ...] lists the medium triangles of this view, big_len[3] of them (the rasteriser's renders)
 };
+
+// Medium triangles: a bounding box over 8 x 8 pixels of at most kMidBox pixels (16 x 16: beyond that a whole wave per triangle --
+// fuse_box -- is faster than sixteen lanes, tools/mesh_density_sweep.py).  The rasteriser lists them (push_mid), k_fuse_mid fuses them.
+constexpr int kMidBox = 256;
 
 // Per-primitive records built from an arbitrary index image (image_records.hip): what lets MeshAggregator::add() run the
 // triangle-order fusion on images the library did not render.  Scratch of one aggregator, all zero between calls.

@@ -340,7 +340,6 @@ __device__ __forceinline__ TriFuseArgs with_view(const TriFuseArgs& a, const Tri
 
 // Medium triangles -- a box of at most kMidBox pixels in every view of the launch -- are fused by k_fuse_mid (fusion_mid.hip: sixteen
 // lanes per triangle, four triangles per wave) when TriFuseArgs::mid is set; the tail waves below then leave them alone.
-constexpr int kMidBox = 1024;
 __device__ __forceinline__ bool mid_box(const TriFrag& rec, uint32_t W, uint32_t H) {
   (void)W; (void)H;
   if (rec.kind != 2) return true;                        // nothing emitted here, or a box of at most 8 x 8
@@ -363,9 +362,13 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const T
   // still spread over all of them, 64 when there are many.
   // With a.mid the MEDIUM views are k_fuse_mid's: an entry counts only if its triangle is LARGE (over kMidBox pixels) in the
   // entry's view, and is taken from the first view in which it is large.
+  // A step's `chunk` entries are spread over the whole concatenation of the queues (lane l takes entry l * steps + step): the entries of
+  // the first view's queue are all taken, the later views' mostly are duplicates, so consecutive entries would hand a few waves all
+  // the work.
   const uint32_t chunk = max(1u, min((uint32_t)kWave, total / max(nworkers, 1u)));
-  for (uint32_t q0 = worker * chunk; q0 < total; q0 += nworkers * chunk) {
-    const uint32_t q = (uint32_t)l < chunk ? q0 + (uint32_t)l : total;
+  const uint32_t steps = (total + chunk - 1u) / chunk;
+  for (uint32_t step = worker; step < steps; step += nworkers) {
+    const uint32_t q = (uint32_t)l < chunk ? (uint32_t)l * steps + step : total;
     uint32_t fi = 0u;
     bool take = false;
     {

@@ -2347,7 +2347,9 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
       // medium triangles first (their rows are nobody else's: the main waves leave the rows of queued triangles alone, the tail waves
       // skip what t.mid hands to k_fuse_mid); a few waves per SIMD walking the queues, gone at once when the queues are empty
       static const int mid_mode = getenv("SMESH_FUSE_MID") ? atoi(getenv("SMESH_FUSE_MID")) : 1;   // (2 / 3: development, half of the hand-over each)
-      if (mid_mode && a->kind != SMESH_AGG_MUL) {      // (Mul's (hi, lo) rows cannot take k_fuse_mid's atomics)
+      bool listed = true;                              // (records rebuilt from a foreign image carry no list of medium primitives)
+      for (int v = 0; v < nviews; v++) listed = listed && views[v].mid_queue;
+      if (mid_mode && listed && a->kind != SMESH_AGG_MUL) {      // (Mul's (hi, lo) rows cannot take k_fuse_mid's atomics)
         t.mid = mid_mode == 2 ? 0 : 1;
         const int slots = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : a->C <= 40 ? 40 : 48;
         if (mid_mode != 3) smesh_launch_fuse_mid(a->kind, slots, nviews, dim3(6u * (uint32_t)std::max(1, ctx->num_cus)), st, t, tv);

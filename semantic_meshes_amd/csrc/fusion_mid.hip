@@ -31,7 +31,7 @@ namespace {
 
 #include "fuse_tri.inc.hpp"
 
-constexpr int kMidHits = 384;     // compacted hits per 16-lane row (LDS: 16 rows x 384 x 2 bytes per workgroup)
+constexpr int kMidHits = 256;     // compacted hits per 16-lane row = kMidBox: every box fits (LDS: 16 rows x 256 x 2 bytes per workgroup)
 constexpr int kRowRor1 = 0x121, kRowRor2 = 0x122, kRowRor4 = 0x124, kRowRor8 = 0x128;
 
 __device__ __forceinline__ float row16_sum(float v) {     // every lane of the 16-lane row ends with the row's total
@@ -76,8 +76,8 @@ __global__ __launch_bounds__(256) void k_fuse_mid(TriFuseArgs a, TriViews<8> vw,
   const uint32_t slot = (blockIdx.x * 256u + threadIdx.x) >> 4, nslots = gridDim.x * 16u;
   uint32_t len[8], total = 0u;
 #pragma unroll
-  for (int v = 0; v < 8; v++) { len[v] = v < nv ? min(vw.v[v].big_len[0], a.big_capacity) : 0u; total += len[v]; }
-  if (total == 0u) return;             // no triangle with a box over 8 x 8 in any view: every BASELINE config
+  for (int v = 0; v < 8; v++) { len[v] = v < nv ? min(vw.v[v].big_len[3], a.big_capacity) : 0u; total += len[v]; }   // the rasteriser's lists of medium triangles (push_mid)
+  if (total == 0u) return;             // no medium triangle in any view: every BASELINE config
   __shared__ uint16_t s_hit[16][kMidHits];   // per 16-lane row: the box pixels that hold the triangle, compacted (pass 2 takes one per lane and round)
   uint16_t* __restrict__ my_hits = s_hit[(threadIdx.x >> 4) & 15u];
   // what a queue entry is: the view it belongs to, the triangle, the triangle's record in that view
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256) void k_fuse_mid(TriFuseArgs a, TriViews<8> vw,
 #pragma unroll
     for (int j = 0; j < 8; j++) {
       if (!located) {
-        if (qq < len[j]) { e.fi = vw.v[j].big_queue[qq]; e.rec = vw.v[j].frags[e.fi]; e.view = j; located = true; }
+        if (qq < len[j]) { e.fi = vw.v[j].big_queue[(uint64_t)a.big_capacity + qq]; e.rec = vw.v[j].frags[e.fi]; e.view = j; located = true; }
         else qq -= len[j];
       }
     }
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_fuse_mid(TriFuseArgs a, TriViews<8> vw,
     const int bh = on ? y1 - y0 + 1 : 1;
     const int npx = on ? (x1 - x0 + 1) * bh : 0;
     // pass 1: this lane's pixels l, l + 16, l + 32 ... of the box (x-major, y fastest) against the index plane -- all the loads
-    // of a lane in flight together -- leave a 64-bit mask of its hits (a box holds at most kMidBox = 64 x 16 pixels)
+    // of a lane in flight together -- leave a 64-bit mask of its hits (a box holds at most kMidBox = 16 x 16 pixels: 16 per lane)
     unsigned long long hits = 0ull;
     {
       int cx = l16 / bh, cy = l16 - cx * bh;     // walks the lane's pixels without a division per pixel
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_fuse_mid(TriFuseArgs a, TriViews<8> vw,
     const float w0 = ntot ? a.iew * (1.0f / (float)ntot) + (1 - a.iew) * 1.0f : 0.0f;    // Mesh.h:100-102
     // The hits of the sixteen lanes, compacted through LDS (a DPP row scan gives every lane its offset): pass 2 then runs
     // ceil(ntot / 16) rounds with full rows instead of as many rounds as the unluckiest lane of the WAVE has hits.  Rows with more
-    // than kMidHits hits (a box of 1024 pixels more than half full) keep their own hits per lane.
+    // than kMidHits hits (none while kMidHits >= kMidBox) would keep their own hits per lane.
     uint32_t incl = mine_n;
     incl += dpp_u<kDppRowShr1>(0u, incl);
     incl += dpp_u<kDppRowShr2>(0u, incl);

@@ -99,7 +99,7 @@ __device__ __forceinline__ ScreenVertex project_point(const CameraArgs& cam, con
 
 __device__ __forceinline__ void project_vertex(const float* __restrict__ verts, uint64_t V, const CameraArgs& cam,
                                                ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count, const uint64_t i) {
-  if (i == 0) { big_count[0] = 0u; big_count[1] = 0u; big_count[2] = 0u; }   // [1]: "the per-triangle masks are not final" flag
+  if (i == 0) { big_count[0] = 0u; big_count[1] = 0u; big_count[2] = 0u; big_count[3] = 0u; }   // [1]: "the per-triangle masks are not final" flag
   if (i >= V) return;
   sv[i] = project_point(cam, verts[3 * i + 0], verts[3 * i + 1], verts[3 * i + 2]);
 }
@@ -123,7 +123,7 @@ struct ProjectGroup {
 __global__ void k_project_vertices_group(ProjectGroup g) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0)
-    for (uint32_t v = 0; v < g.n; v++) { g.big_count[v][0] = 0u; g.big_count[v][1] = 0u; g.big_count[v][2] = 0u; }
+    for (uint32_t v = 0; v < g.n; v++) { g.big_count[v][0] = 0u; g.big_count[v][1] = 0u; g.big_count[v][2] = 0u; g.big_count[v][3] = 0u; }
   if (i >= g.V) return;
   const float X = g.verts[3 * i + 0], Y = g.verts[3 * i + 1], Z = g.verts[3 * i + 2];
   for (uint32_t v = 0; v < g.n; v++) g.sv[v][i] = project_point(g.cam[v], X, Y, Z);
@@ -478,6 +478,14 @@ __device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri&
   atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
 }
 
+// Medium triangles (a box over 8 x 8 of at most kMidBox pixels) are listed a second time, in the upper half of the big-triangle queue
+// (entries big_capacity ..., count in big_count[3]): k_fuse_mid (fusion_mid.hip) walks that list and nothing else.
+__device__ __forceinline__ void push_mid(const RasterArgs& a, const uint64_t f, const int box_pixels) {
+  if (box_pixels > kMidBox) return;
+  const uint32_t slot = atomicAdd(a.big_count + 3, 1u);
+  if (slot < a.big_capacity) a.big_queue[(uint64_t)a.big_capacity + slot] = (uint32_t)f;
+}
+
 // Direct path.  One lane per triangle; triangles whose bounding box exceeds 8 x 8 pixels are queued for k_raster_big.
 // Besides the depth-tested keys, each triangle leaves a TriFrag record (which pixels it emitted).
 __global__ void k_raster_small(RasterArgs a) {
@@ -493,6 +501,7 @@ __global__ void k_raster_small(RasterArgs a) {
     if (bw > 8 || bh > 8 || have == 2) {
       const uint32_t slot = atomicAdd(a.big_count, 1u);
       if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
+      push_mid(a, f, bw * bh);
       rec.kind = 2;
       rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
     } else if (!(a.dbg & 2)) {
@@ -611,6 +620,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
     if (bw > 8 || bh > 8 || have == 2) {
       const uint32_t slot = atomicAdd(a.big_count, 1u);          // every such triangle: the fusion walks this queue
       if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
+      push_mid(a, f, bw * bh);
       rec.kind = 2;
       rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
       if (bw <= kMedium && bh <= kMedium && have == 1) medium = true;   // rasterised below by the whole wave
@@ -1424,7 +1434,7 @@ int check_camera(const smesh_camera_t* cam) {
 hipError_t alloc_side(smesh_renderer* r, int i) {
   smesh_renderer::Side& sd = r->side[i];
   if (sd.frags) return hipSuccess;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&sd.big_queue), (size_t)r->big_capacity * 4);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&sd.big_queue), (size_t)r->big_capacity * 8);   // (upper half: the medium triangles again, push_mid)
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sd.big_count), 16);
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sd.frags), std::max<uint64_t>(r->F * sizeof(TriFrag), 16));
   if (e == hipSuccess) e = hipMemsetAsync(sd.big_count, 0, 16, r->ctx->stream);
@@ -1553,7 +1563,7 @@ static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const
   if (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) {
     // triangle primitives: every accumulator row is owned by its triangle's lane -- no atomics, no histogram
     // (ps0, ps1: DEVICE class vectors with element strides (ps0, ps1, 1), read in place by k_fuse_tri; 0, 0: the dense image)
-    const RenderedView rv{r->side[slot].frags, r->side[slot].big_queue, r->side[slot].big_count, d_idx, d_probs, d_w, W, H, ps0, ps1};
+    const RenderedView rv{r->side[slot].frags, r->side[slot].big_queue, r->side[slot].big_count, d_idx, d_probs, d_w, W, H, ps0, ps1, true};
     SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, &rv, 1));
     smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr), "render-records");
   } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
@@ -1969,7 +1979,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
           const smesh_renderer::Side& sd = r->side[base + j + v];
           const uint64_t k = i + (uint64_t)(j + v);
           rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[base + j + v].ptr), probs[k],
-                               weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
+                               weights ? weights[k] : nullptr, cams[k].width, cams[k].height, 0, 0, true};
         }
         SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
         j += nv;

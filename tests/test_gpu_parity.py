@@ -558,6 +558,46 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
         oracle.set_accum_double(False)
 
 
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C,iew", [(5, 0.5), (19, 0.0), (19, 1.0), (33, 0.5), (48, 0.5)])
+def test_fuse_views_medium_triangles(sm, oracle, kind, C, iew):
+    """Meshes of MEDIUM triangles (boxes over 8 x 8, up to ~30 x 30 pixels: k_fuse_mid, sixteen lanes per (triangle, view), float
+    atomics; Mul: the tail waves of k_fuse_tri) through fuse_views with per-pixel weights, plus one triangle too large for sixteen
+    lanes (tail wave) whose other views are medium, against the float64 oracle; the views of a group in one call and one by one."""
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(14, 9, 420, 310, views=5)          # ~20 x 20-pixel triangles
+    extra_v = np.array([[-1.2, -0.9, 0.8], [1.2, -0.9, 0.8], [0, 1.0, 0.8]], np.float32)     # ~ 100 x 80 pixels: large in every view
+    verts = np.concatenate([mesh.vertices, extra_v])
+    faces = np.concatenate([mesh.faces, [[len(mesh.vertices), len(mesh.vertices) + 1, len(mesh.vertices) + 2]]]).astype(np.int32)
+    P = len(faces)
+    rng = np.random.default_rng(C * 7 + len(kind))
+    r = sm.render.triangles(sm.data.Mesh(verts, faces))
+    o = oracle.OracleRenderer(verts, faces)
+    group, single = sm.fusion.MeshAggregator(P, C, kind, iew), sm.fusion.MeshAggregator(P, C, kind, iew)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, iew)
+        probs, weights = [], []
+        for cam in cams:
+            p = random_probs(rng, *cam.resolution, C)
+            if kind == "mul":
+                p = np.maximum(p, 1e-3).astype(np.float32)
+            w = (rng.random(cam.resolution, dtype=np.float32) + 0.25).astype(np.float32)
+            probs.append(p)
+            weights.append(w)
+            oagg.add(o.render(cam)[0], p, w)
+        dp, dw = [to_device(p) for p in probs], [to_device(w) for w in weights]
+        group.fuse_views(r, cams, dp, dw)
+        for cam, p, w in zip(cams, dp, dw):
+            single.fuse_view(r, cam, p, w)
+        want = oagg.get()
+        assert (want.sum(axis=1) > 0.5).sum() > P // 2
+        assert_fused_close(group.get(), want, rtol=1e-5)
+        assert_fused_close(single.get(), want, rtol=1e-5)
+    finally:
+        oracle.set_accum_double(False)
+
+
 def test_fuse_view_user_index_images_take_generic_path(sm, oracle):
     mesh, cams = small_scene()
     P, C = len(mesh.faces) + 5, 7                               # aggregator larger than the mesh: not triangle-order
