@@ -215,3 +215,76 @@ def test_random_texel_soup_mul_against_the_float64_oracle(sm, oracle, seed):
         assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)
+
+
+def _room(rng, n):
+    """A closed box whose six walls are n x n jittered quads (2 n^2 triangles each): seen from inside, the walls beside and behind
+    the camera cross the camera plane (near-plane clipping, raster spec 1b), and with small n the triangles are medium-sized."""
+    half = rng.uniform(1.0, 3.0, 3)
+    verts, faces = [], []
+    for axis in range(3):
+        for side in (-1.0, 1.0):
+            u, v = [a for a in range(3) if a != axis]
+            base = len(verts)
+            g = np.linspace(-1.0, 1.0, n + 1)
+            for i in range(n + 1):
+                for j in range(n + 1):
+                    p = np.zeros(3)
+                    p[axis] = side * half[axis]
+                    p[u], p[v] = g[i] * half[u], g[j] * half[v]
+                    verts.append(p)
+            for i in range(n):
+                for j in range(n):
+                    a, b, c, d = base + i * (n + 1) + j, base + (i + 1) * (n + 1) + j, base + (i + 1) * (n + 1) + j + 1, base + i * (n + 1) + j + 1
+                    faces += [(a, b, c), (a, c, d)] if (i + j) % 2 else [(a, b, d), (b, c, d)]
+    verts = np.asarray(verts)
+    # interior vertices of a wall move a little inside their wall's plane (the room stays closed: borders are shared and fixed)
+    return verts.astype(np.float32), np.asarray(faces, np.int32), half
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_room_against_oracle(sm, oracle, seed):
+    """Cameras INSIDE closed rooms (eval-scannet/eval_scannet.py:203-238's regime): clipped walls, medium and large triangles, every
+    aggregator; indices and depth bit-equal, no background pixel, fused distributions against the float64 oracle -- single views and
+    fuse_views groups."""
+    import types
+    from semantic_meshes_amd import synth
+    from semantic_meshes_amd.device import to_device
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice([1, 3, 8, 20]))
+    verts, faces, half = _room(rng, n)
+    W, H = int(rng.choice([96, 320, 640])), int(rng.choice([72, 240, 480]))
+    C = int(rng.choice([3, 19, 40, 64]))
+    kind = str(rng.choice(["sum", "summax", "mul"]))
+    r = sm.render.triangles(types.SimpleNamespace(vertices=verts, faces=faces))
+    o = oracle.OracleRenderer(verts, faces)
+    P = len(faces)
+    agg, grouped = sm.fusion.MeshAggregator(P, C, kind), sm.fusion.MeshAggregator(P, C, kind)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind)
+        cams, images = [], []
+        for view in range(3):
+            eye = rng.uniform(-0.85, 0.85, 3) * half
+            target = rng.uniform(-1.0, 1.0, 3) * half
+            R, t = synth.look_at(tuple(eye), tuple(target), up=(0, 0, 1))
+            f = float(rng.uniform(0.35, 1.2)) * W
+            cam = sm.data.Camera(R, t, np.array([W, H]), np.array([f, f]), np.array([W / 2.0, H / 2.0]))
+            idx, depth = r.render(cam)
+            oidx, odepth = o.render(cam)
+            np.testing.assert_array_equal(np.asarray(idx), oidx)
+            np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), odepth.view(np.uint32))
+            assert (oidx != 0xFFFFFFFF).all()                          # a closed room: no pixel sees the background
+            probs = random_probs(rng, W, H, C, zero_fraction=0.1)
+            if kind == "mul":
+                probs = np.where(probs.sum(-1, keepdims=True) > 0, np.maximum(probs, 1e-3), 0).astype(np.float32)
+            agg.fuse_view(r, cam, probs)
+            oagg.add(oidx, probs)
+            cams.append(cam)
+            images.append(to_device(probs))
+        grouped.fuse_views(r, cams, images)
+        want = oagg.get()
+        assert_fused_close(agg.get(), want, rtol=2e-5, atol=1e-6)
+        assert_fused_close(grouped.get(), want, rtol=2e-5, atol=1e-6)
+    finally:
+        oracle.set_accum_double(False)
