@@ -266,11 +266,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    device = local_rank
+    # SMESH_BENCH_BACKEND=gloo (tests): the N > 1 code path of this script on a box with fewer GPUs than ranks -- the ranks share
+    # GPUs (local_rank modulo the device count) and exchange through torch.distributed's gloo backend (RCCL refuses two ranks on one
+    # device).  The driver's runs never set it.
+    backend = os.environ.get("SMESH_BENCH_BACKEND", "nccl")
+    device = local_rank % max(_lib.device_count(), 1) if backend == "gloo" else local_rank
     launched = world > 1 or "RANK" in os.environ   # through torch.distributed.run (or any launcher that sets RANK)
     comm, dist, allreduce_impl = None, None, "none"
     if launched:
-        if os.environ.get("SMESH_ALLREDUCE", "native") != "torch":
+        if os.environ.get("SMESH_ALLREDUCE", "native") != "torch" and backend != "gloo":
             try:
                 comm = smcomm.Communicator.from_env(device)
                 allreduce_impl = "native smesh_allreduce (RCCL on the library stream)"
@@ -280,10 +284,14 @@ def main():
         if comm is None:
             import torch
             import torch.distributed as dist
-            torch.cuda.set_device(local_rank)
-            # device_id: the communicator is bound to this GPU and created now, not inside the timed region
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-            allreduce_impl = "torch.distributed nccl (RCCL), in place on the accumulator"
+            torch.cuda.set_device(device)
+            if backend == "gloo":
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+                allreduce_impl = "torch.distributed gloo (host copies; test mode, ranks sharing GPUs)"
+            else:
+                # device_id: the communicator is bound to this GPU and created now, not inside the timed region
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+                allreduce_impl = "torch.distributed nccl (RCCL), in place on the accumulator"
 
     cfg = synth.CONFIGS[args.workload]
     W, H, C = cfg["width"], cfg["height"], cfg["classes"]
@@ -412,7 +420,8 @@ def main():
         exchange_ms_min = -neg_min
     elif dist is not None:
         import torch
-        t = torch.tensor([dt, compute_ms, exchange_ms, -exchange_ms], dtype=torch.float64, device="cuda:%d" % device)
+        t = torch.tensor([dt, compute_ms, exchange_ms, -exchange_ms], dtype=torch.float64,
+                         device="cpu" if backend == "gloo" else "cuda:%d" % device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt, compute_ms_max, exchange_ms_max, neg_min = (float(v) for v in t.tolist())
         exchange_ms_min = -neg_min

@@ -127,3 +127,29 @@ def test_native_reduce_scatter_world_one_owns_every_row(sm):
     lo, hi = c.reduce_scatter(agg)
     assert (lo, hi) == (0, P)
     assert np.array_equal(agg.get_rows(lo, hi), want)
+
+
+@pytest.mark.parametrize("exchange", ["allreduce", "reduce_scatter"])
+def test_bench_line_of_a_two_rank_run(tmp_path, sm, exchange):
+    """bench.py exactly as the driver launches it for N = 2 (`python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2`),
+    on the one GPU of the test box: SMESH_BENCH_BACKEND=gloo lets the two ranks share it.  The N > 1 branch of the script -- view
+    sharding, the exchange inside the timed region, barrier, max over ranks, the diagnosable fields -- runs and prints ONE JSON line."""
+    import json
+    port = _free_port()
+    env = dict(os.environ, SMESH_BENCH_BACKEND="gloo", SMESH_EXCHANGE=exchange, OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--workload", "cfg1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    cfg = d["config"]
+    assert d["n_gpus"] == 2 and d["steps"] == 12 and d["warmup"] == 4 and d["scaling"] == "weak" and d["value"] > 0
+    assert abs(d["value"] - 2 * 12 / (d["ms_per_step"] * 12 * 1e-3)) < 0.02 * d["value"]          # whole-job views / max-over-ranks time
+    assert cfg["nranks"] == 2 and cfg["exchange"] == exchange and cfg["allreduce_bytes"] == 4 * 10000 * 5
+    assert cfg["compute_ms"] > 0 and cfg["exchange_ms"] > 0 and cfg["exchange_ms"] >= cfg["exchange_ms_fastest_rank"]
+    assert cfg["compute_ms"] + cfg["exchange_ms_fastest_rank"] <= cfg["timed_region_ms"] * 1.05
+    assert "cpu_baseline" not in d and d["roofline"]["frac"] > 0
