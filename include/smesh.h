@@ -156,6 +156,16 @@ int smesh_aggregator_add(smesh_aggregator_t* a,
                          const float* weights, const int64_t weights_strides[2], int weights_memkind,
                          uint64_t width, uint64_t height);
 
+/* smesh_aggregator_add that does not wait for the kernels reading DEVICE images (HOST images are still consumed before it
+ * returns, Fusion.h:45-47): keep device images valid until smesh_stream_release / smesh_synchronize, like
+ * smesh_aggregator_add_rendered.  New: lets consecutive add() calls on images the library did not render overlap -- the
+ * per-primitive records of call k+1 (image_records.hip) are built on the main stream while call k is fused on a second one. */
+int smesh_aggregator_add_async(smesh_aggregator_t* a,
+                               const void* indices, int idx_dtype, const int64_t idx_strides[2], int idx_memkind,
+                               const float* probs, const int64_t probs_strides[3], int probs_memkind,
+                               const float* weights, const int64_t weights_strides[2], int weights_memkind,
+                               uint64_t width, uint64_t height);
+
 /* Replaces ModelAggregator::get (Fusion.h:72-76; Mesh.h:131-132) with the output functor chain of
  * the chosen aggregator (Fusion.cu:47-49 / 67-69 / 79-82; Fusion.h:79-104): writes float32[P,C]. */
 int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind);

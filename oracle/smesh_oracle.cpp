@@ -807,6 +807,11 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, cons
   const int64_t is[2] = {(int64_t)H, 1};   // the oracle has one add(): the reference's
   return smesh_aggregator_add(a, idx, SMESH_IDX_U32, is, SMESH_MEM_HOST, probs, ps, pmem, weights, ws, wmem, W, H);
 }
+int smesh_aggregator_add_async(smesh_aggregator_t* a, const void* indices, int idx_dtype, const int64_t is[2], int imem,
+                               const float* probs, const int64_t ps[3], int pmem,
+                               const float* weights, const int64_t ws[2], int wmem, uint64_t W, uint64_t H) {
+  return smesh_aggregator_add(a, indices, idx_dtype, is, imem, probs, ps, pmem, weights, ws, wmem, W, H);   // (synchronous like everything here)
+}
 int smesh_stream_wait(int, void*) { return SMESH_OK; }   // the oracle has no streams: everything is synchronous
 int smesh_stream_release(int, void*) { return SMESH_OK; }
 int smesh_stream_handle(int, void** s) { if (s) *s = nullptr; return SMESH_OK; }

@@ -57,6 +57,9 @@ SIGNATURES = {
     "smesh_aggregator_add": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int,
                                      c_void_p, P(ctypes.c_int64), c_int,
                                      c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64]),
+    "smesh_aggregator_add_async": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int,
+                                           c_void_p, P(ctypes.c_int64), c_int,
+                                           c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64]),
     "smesh_aggregator_add_rendered": (c_int, [c_void_p, c_void_p, c_void_p,
                                               c_void_p, P(ctypes.c_int64), c_int,
                                               c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64]),

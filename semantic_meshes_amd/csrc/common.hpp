@@ -165,13 +165,18 @@ struct ImageRecords {
                                    //     runs, 65536 - smallest y; zero otherwise
   uint32_t* big_queue = nullptr;   // [P] those primitives
   uint32_t* big_count = nullptr;   // [4] [0] queue length, [1] stays 0: the masks are exact, [2] nonzero: there are sparse primitives
+  unsigned long long* mom = nullptr;   // [P] moments of the current image (count | sum x << 24 | sum y << 44), zero between calls
   uint64_t P = 0;
-  bool clean = false;
+  bool clean = false;              // frags / cand / counters are all zero (what passes A and B start from)
+  bool moments = false;            // the last build took passes M / R (image_records.hip)
+  uint32_t tag = 2;                // passes M / R: what marks a record written by THIS call's pass M (alternates 2, 4)
   void release();
 };
 int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, uint64_t P);
+int image_records_pending(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
+                          uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st);
 int image_records_scatter_sparse(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
-                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc);
-int image_records_clear(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H);
+                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st);
+int image_records_clear(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, hipStream_t st);
 
 }  // namespace smesh

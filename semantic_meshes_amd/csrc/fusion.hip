@@ -187,9 +187,7 @@ __device__ __forceinline__ float pixel_weight(const ScatterArgs& a, uint32_t v, 
 // strip ids walk down an image column (their probs segments abut in memory); ids are dealt to the 8 XCDs
 // in contiguous ranges so that neighbouring strips share an L2.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSX = 4;
-constexpr int kTY = 16;
-constexpr int kNone = 255;
+#include "strip.inc.hpp"
 
 struct StripGeom {
   uint32_t x0, y0;
@@ -209,80 +207,6 @@ __device__ __forceinline__ StripGeom strip_geom(const ScatterArgs& a) {
   g.nx = g.valid ? min((int)(a.W - g.x0), kSX) : 0;
   g.ny = g.valid ? min((int)(a.H - g.y0), kTY) : 0;
   return g;
-}
-
-// Wave-private LDS bookkeeping (no workgroup barrier is ever needed: the workgroup IS one wave).
-struct StripLists {
-  uint32_t sv[kWave];      // primitive of pixel l (0xFFFFFFFF outside the image)
-  uint8_t shead[kWave];    // head lane of the run pixel l belongs to
-  uint8_t lmatch[kWave];   // head lane of the first same-primitive run in the column to the left (or kNone)
-  uint8_t rmatch[kWave];   // ... to the right
-  uint8_t child[kWave];    // head lane -> next run of the chain (mutual match), or kNone
-  uint8_t slen[kWave];     // head lane -> pixels in the run
-  uint8_t groot[kWave];    // group g -> head lane of the chain's first (leftmost) run
-  uint8_t amax[kWave];     // arg-max class of pixel l (Summax only)
-  float sw[kWave];         // weight of pixel l (0 = contributes nothing)
-};
-
-struct StripRuns {
-  bool head;       // this lane starts a run
-  int hl;          // head lane of my run
-  int len;         // pixels in my run (valid on head lanes)
-  bool root;       // head lane of the first run of a chain with a valid primitive
-  int gidx;        // root lanes: dense index of my group in [0, G)
-  int G;           // groups in the strip
-};
-
-// Builds runs, links and groups from each lane's primitive id `v` (0xFFFFFFFF outside the image).
-__device__ __forceinline__ StripRuns build_strip(StripLists& L, uint32_t v, uint32_t P, int l) {
-  StripRuns r;
-  const int ty = l & (kTY - 1), cx = l / kTY;
-  // ---- runs: a pixel starts a run when it is the top of a column segment or differs from the pixel above
-  L.sv[l] = v;
-  const uint32_t prev = __shfl_up(v, 1);
-  r.head = (ty == 0) || (v != prev);
-  const unsigned long long heads = __ballot(r.head);
-  const unsigned long long upto = (2ull << l) - 1ull;   // bits 0..l (l = 63: wraps to all ones)
-  r.hl = 63 - __clzll((long long)(heads & upto));      // lane 0 is always a head
-  const unsigned long long later = heads & ~upto;
-  const int next = later ? (__ffsll((long long)later) - 1) : kWave;
-  r.len = next - l;
-  L.shead[l] = (uint8_t)r.hl;
-  L.slen[l] = (uint8_t)r.len;
-  wave_sync();
-  // ---- first same-primitive run in the neighbouring columns (8-connectivity)
-  const bool valid = v < P;
-  int lp = kNone, rc = kNone;
-  if (r.head && valid) {
-    const int lo = max(ty - 1, 0), hi = min(ty + r.len, kTY - 1);
-    if (cx < kSX - 1) {
-      const int q0 = (cx + 1) * kTY;
-      for (int y = lo; y <= hi; y++)
-        if (L.sv[q0 + y] == v) { rc = L.shead[q0 + y]; break; }
-    }
-    if (cx > 0) {
-      const int q0 = (cx - 1) * kTY;
-      for (int y = lo; y <= hi; y++)
-        if (L.sv[q0 + y] == v) { lp = L.shead[q0 + y]; break; }
-    }
-  }
-  L.lmatch[l] = (uint8_t)lp;
-  L.rmatch[l] = (uint8_t)rc;
-  wave_sync();
-  // ---- a link exists only when both runs chose each other, so chains never fork
-  int child = kNone;
-  r.root = false;
-  if (r.head && valid) {
-    if (rc != kNone && L.lmatch[rc] == l) child = rc;
-    r.root = !(lp != kNone && L.rmatch[lp] == l);
-  }
-  L.child[l] = (uint8_t)child;
-  const unsigned long long roots = __ballot(r.root);
-  r.G = __popcll(roots);
-  r.gidx = __popcll(roots & ((1ull << l) - 1ull));
-  if (r.root) L.groot[r.gidx] = (uint8_t)l;
-  wave_sync();
-  return r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1994,8 +1918,8 @@ namespace {
 
 int mul_normalise(smesh_aggregator* a, bool fold) {
   if (a->kind != SMESH_AGG_MUL || a->P == 0) return SMESH_OK;
-  hipLaunchKernelGGL(k_mul_normalise, dim3((uint32_t)div_up(a->P, 256)), dim3(256), 0, a->ctx->stream, a->acc, a->acc_lo, a->P, a->C, a->S,
-                     fold ? 1 : 0);
+  hipLaunchKernelGGL(k_mul_normalise, dim3((uint32_t)div_up(a->P, 256)), dim3(256), 0, a->ctx->stream, a->acc, a->acc_lo,
+                     a->P, a->C, a->S, fold ? 1 : 0);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
@@ -2070,14 +1994,16 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
   const char* min_c_env = getenv("SMESH_ADD_RECORDS_MIN_C");      // (read per call: tests and tools move the threshold at run time)
   const uint32_t records_min_c = min_c_env ? (uint32_t)atoi(min_c_env) : kAddRecordsMinC;
   if (!records_off && C >= records_min_c && a->P > 0 && W <= 65535 && H <= 65535 && smesh_aggregator_can_fuse_triangles(a, a->P)) {
+    ImageRecords& rec = a->rec;
     {
       ProfScope prof(ctx, SMESH_PROF_FUSE_HIST);
-      SMESH_TRY(image_records_build(ctx, a->rec, idx, W, H, a->P));
+      SMESH_TRY(image_records_build(ctx, rec, idx, W, H, a->P));
     }
-    const RenderedView rv{a->rec.frags, a->rec.big_queue, a->rec.big_count, idx, probs, weights, W, H};
+    SMESH_TRY(image_records_pending(ctx, rec, a->kind, idx, probs, weights, W, H, C, a->iew, a->acc, st));
+    const RenderedView rv{rec.frags, rec.big_queue, rec.big_count, idx, probs, weights, W, H};
     SMESH_TRY(smesh_aggregator_fuse_triangles(a, a->P, nullptr, (uint32_t)a->P, &rv, 1));
-    SMESH_TRY(image_records_scatter_sparse(ctx, a->rec, a->kind, idx, probs, weights, W, H, C, a->iew, a->acc));
-    SMESH_TRY(image_records_clear(ctx, a->rec, idx, W, H));
+    SMESH_TRY(image_records_scatter_sparse(ctx, rec, a->kind, idx, probs, weights, W, H, C, a->iew, a->acc, st));
+    SMESH_TRY(image_records_clear(ctx, rec, idx, W, H, st));
     smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, false), "image-records");
     return SMESH_OK;
   }
@@ -2563,9 +2489,9 @@ int smesh_aggregator_reset(smesh_aggregator_t* a) {
   return SMESH_OK;
 }
 
-int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dtype, const int64_t is[2], int imem,
-                         const float* probs, const int64_t ps[3], int pmem,
-                         const float* weights, const int64_t ws[2], int wmem, uint64_t W, uint64_t H) {
+static int aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dtype, const int64_t is[2], int imem,
+                          const float* probs, const int64_t ps[3], int pmem,
+                          const float* weights, const int64_t ws[2], int wmem, uint64_t W, uint64_t H, bool wait_for_device_inputs) {
   if (!a || !indices || !probs) return fail(SMESH_ERR_INVALID, "NULL argument");
   if (idx_dtype < 0 || idx_dtype > 3) return fail(SMESH_ERR_INVALID, "bad index dtype");
   SMESH_TRY(check_strides(is, 2, "indices"));
@@ -2607,12 +2533,25 @@ int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dty
   SMESH_TRY(add_device(a, d_idx, idx_dtype, is, d_probs, ps, d_w, ws, W, H));
   if (any_host) SMESH_HIP(hipEventSynchronize(a->ev_staged));
   // device inputs must stay valid until the kernels that read them have run
-  if (imem == SMESH_MEM_DEVICE || pmem == SMESH_MEM_DEVICE || (weights && wmem == SMESH_MEM_DEVICE)) {
+  if (wait_for_device_inputs && (imem == SMESH_MEM_DEVICE || pmem == SMESH_MEM_DEVICE || (weights && wmem == SMESH_MEM_DEVICE))) {
     // inputs are never retained after return (Fusion.h:45-47): wait for the kernels that read them
     SMESH_HIP(hipStreamSynchronize(ctx->stream));
   }
   return SMESH_OK;
 }
+
+int smesh_aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dtype, const int64_t is[2], int imem,
+                         const float* probs, const int64_t ps[3], int pmem,
+                         const float* weights, const int64_t ws[2], int wmem, uint64_t W, uint64_t H) {
+  return aggregator_add(a, indices, idx_dtype, is, imem, probs, ps, pmem, weights, ws, wmem, W, H, true);
+}
+
+int smesh_aggregator_add_async(smesh_aggregator_t* a, const void* indices, int idx_dtype, const int64_t is[2], int imem,
+                               const float* probs, const int64_t ps[3], int pmem,
+                               const float* weights, const int64_t ws[2], int wmem, uint64_t W, uint64_t H) {
+  return aggregator_add(a, indices, idx_dtype, is, imem, probs, ps, pmem, weights, ws, wmem, W, H, false);
+}
+
 
 // rows [row_lo, row_hi) (row_lo a multiple of 4: the tiles move whole 16-byte pieces) normalised into d_out[(row_hi - row_lo) * C]
 static int finalize_into(smesh_aggregator* a, float* d_out, uint64_t row_lo = 0, uint64_t row_hi = ~(uint64_t)0) {

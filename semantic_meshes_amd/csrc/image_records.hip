@@ -25,7 +25,9 @@
 // same-address atomics.
 #include "common.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <type_traits>
 
 using namespace smesh;
@@ -33,6 +35,7 @@ using namespace smesh;
 namespace {
 
 #include "fuse_tri.inc.hpp"   // contribution<KIND>() (the Mul logarithm is part of the spec)
+#include "strip.inc.hpp"      // runs / chains / groups of a 4 x 16-pixel strip (shared with the histogram kernel)
 
 constexpr int kBlock = 256;
 constexpr unsigned long long kDenseFactor = 16ull, kDenseSlack = 256ull;   // a box scan may cost 16 x the pixel count + 256 reads
@@ -151,16 +154,171 @@ __global__ __launch_bounds__(kBlock) void k_rec_big(const uint32_t* __restrict__
   }
 }
 
+// ================================================================================================================================
+// Round 3: records from MOMENTS.  Passes A and B above cost two atomics per run of pixels (1.5 M runs in a cfg2 image: ~90 us),
+// and atomics are all they cost.  This variant issues ONE atomic per (primitive, 4 x 16 strip) group -- 0.8 M for the same image:
+//   pass M  k_rec_moments  one wave per strip (strip.inc.hpp: runs linked into chains across the strip's four columns); the root
+//                          lane of each group adds the group's pixel count, sum of x and sum of y to the primitive's 64-bit moment
+//                          word (count: 24 bits, sums: 20 bits each -- exact for up to 64 pixels below 16384 x 16384; beyond, only
+//                          the count is used) and STORES the group's own 8 x 8 record (plainly, tagged kPadSpec).
+//   pass R  k_rec_resolve  one lane per primitive: a stored record whose population count equals the primitive's total count IS the
+//                          primitive (a group that holds every pixel has no rival writer) -- 85 % of cfg2's primitives.  Otherwise
+//                          the lane scans the index image around the centroid (8 x 8, then 16 x 16 pixels): all `count` pixels found
+//                          -> the exact record (mask at the true origin, or a kind 2 box); else (more than 64 pixels, or pixels
+//                          further than 7 from the centroid) the primitive is queued as "pending", and
+//   pass E  k_rec_extent   (leaves at once when nothing is pending) per run of a pending primitive: its extent by atomics,
+//   pass C' k_rec_pending  per pending primitive: kind 2 record, or "sparse" exactly as k_rec_big decides it.
+// No clear pass: R rewrites every record that differs and zeroes the moment words it consumed, C' its extent words, M the counters.
+// ================================================================================================================================
+constexpr uint32_t kPadPending = 3u;    // (1: sparse, k_rec_big; 2 and 4: the alternating tags of pass M's own records)
+constexpr int kMomCountBits = 24, kMomSumBits = 20;
+
+typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (a window row of the index image)
+
+__global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t strips_y,
+                                                       uint32_t nstrips, uint32_t strips_per_xcd, uint32_t tag, int dbg,
+                                                       unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
+                                                       uint32_t* __restrict__ big_count) {
+  __shared__ StripLists L;
+  const uint32_t b = blockIdx.x;
+  const int l = threadIdx.x;
+  if (b == 0u && l == 0) { big_count[0] = 0u; big_count[2] = 0u; big_count[3] = 0u; }   // (R, later on the stream, is the first to touch them)
+  // block b runs on XCD b % 8 (observed, MI355X_MICROARCH.md): neighbouring strips share an L2; only speed depends on it
+  const uint32_t s = (b & 7u) * strips_per_xcd + (b >> 3);
+  if (s >= nstrips) return;
+  const uint32_t bx = s / strips_y, by = s - bx * strips_y;
+  const uint32_t x0 = bx * kSX, y0 = by * kTY;
+  const int cx = l / kTY, ty = l - cx * kTY;
+  const bool in = x0 + (uint32_t)cx < W && y0 + (uint32_t)ty < H;
+  const uint32_t v = in ? idx[(uint64_t)(x0 + cx) * H + y0 + ty] : 0xFFFFFFFFu;
+  const StripRuns r = build_strip(L, v, P, l);
+  if (!r.root) return;
+  // the chain: at most four runs, one per column, left to right
+  uint32_t n = 0, sx = 0, sy = 0;
+  int ymin = kTY, ymax = -1;
+  {
+    int q = l;
+    for (int hop = 0; hop < kSX && q != kNone; hop++) {
+      const uint32_t len = L.slen[q];
+      const int qx = q / kTY, qy = q - qx * kTY;
+      n += len;
+      sx += len * (x0 + (uint32_t)qx);
+      sy += len * (y0 + (uint32_t)qy) + ((len * (len - 1u)) >> 1);
+      ymin = min(ymin, qy);
+      ymax = max(ymax, qy + (int)len - 1);
+      q = L.child[q];
+    }
+  }
+  if (!(dbg & 4))
+    atomicAdd(&mom[v], (unsigned long long)n | ((unsigned long long)sx << kMomCountBits) | ((unsigned long long)sy << (kMomCountBits + kMomSumBits)));
+  if (ymax - ymin < 8 && !(dbg & 2)) {
+    unsigned long long mask = 0ull;
+    int q = l;
+    for (int hop = 0; hop < kSX && q != kNone; hop++) {
+      const uint32_t len = L.slen[q];
+      const int qx = q / kTY, qy = q - qx * kTY;
+      mask |= ((1ull << len) - 1ull) << ((qx - cx) * 8 + (qy - ymin));     // bit dx * 8 + dy (common.hpp, TriFrag)
+      q = L.child[q];
+    }
+    *reinterpret_cast<uint4*>(&frags[v]) = make_uint4((x0 + (uint32_t)cx) | ((y0 + (uint32_t)ymin) << 16), 1u | (tag << 16),
+                                                      (uint32_t)mask, (uint32_t)(mask >> 32));
+  }
+}
+
+// Bits of the pixels equal to v in an 8-column x 8-row window at (xs, ys), bit dx * 8 + dy.  The window lies inside the image.
+__device__ __forceinline__ unsigned long long scan8(const uint32_t* __restrict__ idx, uint32_t H, uint32_t xs, uint32_t ys, uint32_t v) {
+  unsigned long long mask = 0ull;
+#pragma unroll
+  for (int dx = 0; dx < 8; dx++) {
+    const uint32_t* col = idx + (uint64_t)(xs + dx) * H + ys;
+    const u32x4u a = *reinterpret_cast<const u32x4u*>(col), c = *reinterpret_cast<const u32x4u*>(col + 4);
+    const uint32_t bits = (a.x == v ? 1u : 0u) | (a.y == v ? 2u : 0u) | (a.z == v ? 4u : 0u) | (a.w == v ? 8u : 0u) |
+                          (c.x == v ? 16u : 0u) | (c.y == v ? 32u : 0u) | (c.z == v ? 64u : 0u) | (c.w == v ? 128u : 0u);
+    mask |= (unsigned long long)bits << (dx * 8);
+  }
+  return mask;
+}
+
+// A kind 1 record from the bits of an 8 x 8 window at (xs, ys): origin moved to the first occupied column and row.
+__device__ __forceinline__ uint4 record_from_window(unsigned long long mask, uint32_t xs, uint32_t ys) {
+  const uint32_t jx = (uint32_t)__builtin_ctzll(mask) >> 3;
+  uint32_t rows = (uint32_t)(mask | (mask >> 32));
+  rows |= rows >> 16;
+  rows |= rows >> 8;
+  const uint32_t jy = (uint32_t)__builtin_ctz(rows & 0xFFu);
+  mask >>= jx * 8u + jy;                 // every set bit has dy >= jy: nothing crosses a column
+  return make_uint4((xs + jx) | ((ys + jy) << 16), 1u, (uint32_t)mask, (uint32_t)(mask >> 32));
+}
+
+__global__ __launch_bounds__(kBlock) void k_rec_resolve(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t tag,
+                                                        int dbg, unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
+                                                        uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+  const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
+  if (v >= P) return;
+  const unsigned long long m = mom[v];
+  uint4 raw = *reinterpret_cast<const uint4*>(&frags[v]);
+  if (m == 0ull) {                       // not in this image: no record (whatever the last image left is cleared)
+    if (raw.x | raw.y | raw.z | raw.w) *reinterpret_cast<uint4*>(&frags[v]) = make_uint4(0u, 0u, 0u, 0u);
+    return;
+  }
+  mom[v] = 0ull;
+  const uint32_t n = (uint32_t)(m & ((1ull << kMomCountBits) - 1ull));       // Mesh.h:90-93 for this primitive
+  const unsigned long long smask = (unsigned long long)raw.z | ((unsigned long long)raw.w << 32);
+  // One group holds every pixel: its record stands as it is.  (`tag` alternates between calls, and every record this pass meets was
+  // left by the previous call or written by this call's pass M: a stale record never carries this call's tag.)
+  if (((raw.y >> 16) == tag && (uint32_t)__popcll(smask) == n) || (dbg & 1)) return;
+  uint4 rec = make_uint4(0u, kPadPending << 16, n, 0u);                      // pending: kind 0, the pixel count parked in the mask
+  bool queue = true;
+  if (n <= 64u) {
+    const uint32_t fx = (uint32_t)((m >> kMomCountBits) & ((1ull << kMomSumBits) - 1ull)) / n;
+    const uint32_t fy = (uint32_t)(m >> (kMomCountBits + kMomSumBits)) / n;
+    // a primitive of at most 8 x 8 pixels lies within 7 pixels of (the floor of) its centroid; most lie within [-3, +4]
+    const uint32_t xs = min(fx > 3u ? fx - 3u : 0u, W - 8u), ys = min(fy > 3u ? fy - 3u : 0u, H - 8u);
+    const unsigned long long m8 = scan8(idx, H, xs, ys, v);
+    if ((uint32_t)__popcll(m8) == n) {
+      rec = record_from_window(m8, xs, ys);
+      queue = false;
+    } else {
+      const uint32_t xw = min(fx > 7u ? fx - 7u : 0u, W - 16u), yw = min(fy > 7u ? fy - 7u : 0u, H - 16u);
+      uint32_t found = 0, xlo = 16u, xhi = 0u, ylo = 16u, yhi = 0u;
+      for (uint32_t dx = 0; dx < 16u; dx++) {
+        const uint32_t* col = idx + (uint64_t)(xw + dx) * H + yw;
+        uint32_t bits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const u32x4u a = *reinterpret_cast<const u32x4u*>(col + 4 * k);
+          bits |= ((a.x == v ? 1u : 0u) | (a.y == v ? 2u : 0u) | (a.z == v ? 4u : 0u) | (a.w == v ? 8u : 0u)) << (4 * k);
+        }
+        if (bits) {
+          found += (uint32_t)__popc(bits);
+          xlo = min(xlo, dx); xhi = dx;
+          ylo = min(ylo, (uint32_t)__builtin_ctz(bits));
+          yhi = max(yhi, 31u - (uint32_t)__builtin_clz(bits));
+        }
+      }
+      if (found == n) {
+        if (xhi - xlo < 8u && yhi - ylo < 8u) {
+          // (the window at the box's own origin may reach past the image: clamp it, the record's origin moves back to the pixels)
+          const uint32_t bxs = min(xw + xlo, W - 8u), bys = min(yw + ylo, H - 8u);
+          rec = record_from_window(scan8(idx, H, bxs, bys, v), bxs, bys);
+          queue = false;
+        } else {     // a box of at most 16 x 16 pixels: dense by k_rec_big's rule (area <= 16 n + 256)
+          rec = make_uint4((xw + xlo) | ((yw + ylo) << 16), 2u, (xw + xhi) | ((yw + yhi) << 16), 0u);
+        }
+      }
+    }
+  }
+  *reinterpret_cast<uint4*>(&frags[v]) = rec;
+  if (queue) big_queue[atomicAdd(big_count, 1u)] = v;                        // capacity P: a primitive is queued at most once
+}
+
 // Pixels of the sparse primitives (k_rec_big), in pixel order: Mesh.h:94-106 with one float atomic per class.  One thread per pixel;
 // an image without sparse primitives -- every rendering -- leaves at the first test.  Mul adds on the hi plane (hi + lo is the value).
+// One pixel of pass D: Mesh.h:94-106 for a pixel of a sparse primitive, one float atomic per class.
 template <int KIND>
-__global__ __launch_bounds__(kBlock) void k_scatter_sparse(const uint32_t* __restrict__ idx, const float* __restrict__ probs,
-                                                           const float* __restrict__ weights, uint64_t N, uint32_t P, uint32_t C, float iew,
-                                                           const TriFrag* __restrict__ frags, const uint32_t* __restrict__ big_count,
-                                                           float* __restrict__ acc) {
-  if (big_count[2] == 0u) return;
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
+__device__ __forceinline__ void scatter_sparse_pixel(uint64_t i, const uint32_t* __restrict__ idx, const float* __restrict__ probs,
+                                                     const float* __restrict__ weights, uint32_t P, uint32_t C, float iew,
+                                                     const TriFrag* __restrict__ frags, float* __restrict__ acc) {
   const uint32_t v = idx[i];
   if (v >= P) return;
   const TriFrag rec = frags[v];
@@ -181,6 +339,102 @@ __global__ __launch_bounds__(kBlock) void k_scatter_sparse(const uint32_t* __res
   } else {
     for (uint32_t c = 0; c < C; c++) atomicAdd(&row[c], contribution<KIND>(pr[c], w));
   }
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_scatter_sparse(const uint32_t* __restrict__ idx, const float* __restrict__ probs,
+                                                           const float* __restrict__ weights, uint64_t N, uint32_t P, uint32_t C, float iew,
+                                                           const TriFrag* __restrict__ frags, const uint32_t* __restrict__ big_count,
+                                                           float* __restrict__ acc) {
+  if (big_count[2] == 0u) return;
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= N) return;
+  scatter_sparse_pixel<KIND>(i, idx, probs, weights, P, C, iew, frags, acc);
+}
+
+// Pending primitives (more than 64 pixels, or pixels far from the centroid): passes E, C' and D in ONE launch of co-resident workgroups
+// with grid barriers between them (big_count[3]); every workgroup leaves at once when nothing is pending -- every rendering of a
+// finely tessellated mesh, for which three launches that find nothing to do would cost a sixth of the whole call.  E: extent by
+// atomics, one set per run of a column.  C': the kind 2 record, or "sparse" as k_rec_big decides.  D: the pixels of sparse primitives,
+// float atomics in pixel order -- ahead of the fusion launch, whose waves write whole blocks of rows back.
+__device__ __forceinline__ void grid_barrier(uint32_t* counter, uint32_t target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(counter, 1u);
+    // (bounded: a launch whose workgroups never all become resident ends in a reported kernel fault after a few seconds, not in a hang)
+    for (uint32_t spins = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) {
+      __builtin_amdgcn_s_sleep(8);
+      if (spins > (1u << 24)) __builtin_trap();
+    }
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_rec_tail(const uint32_t* __restrict__ idx, const float* __restrict__ probs,
+                                                     const float* __restrict__ weights, uint64_t N, uint32_t H, uint32_t P, uint32_t C, float iew,
+                                                     TriFrag* __restrict__ frags, uint4* __restrict__ big4,
+                                                     const uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count,
+                                                     float* __restrict__ acc) {
+  const uint32_t nbig = big_count[0];       // final: pass R ran before this launch
+  if (nbig == 0u) return;
+  for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < N; base += (uint64_t)gridDim.x * kBlock) {
+    const uint64_t i = base + threadIdx.x;
+    const int l = threadIdx.x & 63;
+    uint32_t v = i < N ? idx[i] : 0xFFFFFFFFu;
+    if (v >= P) v = 0xFFFFFFFFu;
+    const uint32_t x = (uint32_t)(i / H), y = (uint32_t)(i - (uint64_t)x * H);
+    const uint32_t prev = (uint32_t)__shfl_up((int)v, 1);
+    const bool leader = l == 0 || prev != v || y == 0u;
+    const unsigned long long Lm = __ballot(leader);
+    const unsigned long long after = l == 63 ? 0ull : (Lm >> (l + 1));
+    const uint32_t next = after ? (uint32_t)l + 1u + (uint32_t)__builtin_ctzll(after) : 64u;
+    if (!leader || v == 0xFFFFFFFFu) continue;
+    const uint32_t len = next - (uint32_t)l;
+    if (frags[v].pad != kPadPending) continue;
+    uint32_t* b = reinterpret_cast<uint32_t*>(&big4[v]);
+    atomicMax(&b[0], x + 1u);            // largest x + 1
+    atomicMax(&b[1], y + len);           // largest y + 1
+    atomicMax(&b[2], 65536u - x);        // 65536 - smallest x
+    atomicMax(&b[3], 65536u - y);        // 65536 - smallest y
+  }
+  // (the launch has at most two workgroups per CU: all resident, or waiting only for other kernels to end)
+  grid_barrier(&big_count[3], gridDim.x);
+  for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < nbig; q += gridDim.x * kBlock) {
+    const uint32_t v = big_queue[q];
+    TriFrag rec = frags[v];
+    if (rec.pad != kPadPending) continue;          // a kind 2 record k_rec_resolve finished itself
+    uint32_t* bw = reinterpret_cast<uint32_t*>(&big4[v]);
+    uint32_t b[4];
+    for (int k = 0; k < 4; k++) b[k] = __hip_atomic_load(&bw[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (written by atomics: read where they landed)
+    const uint32_t x0 = 65536u - b[2], x1 = b[0] - 1u, ytop = 65536u - b[3], y1 = b[1] - 1u;
+    const unsigned long long n = rec.mask;
+    const unsigned long long area = (unsigned long long)(x1 - x0 + 1u) * (unsigned long long)(y1 - ytop + 1u);
+    rec.x0 = (uint16_t)x0; rec.y0 = (uint16_t)ytop; rec.pad = 0;
+    if (x1 - x0 < 8u && y1 - ytop < 8u) {          // (cannot happen for a pending primitive; kept so that the record is right if it does)
+      unsigned long long m = 0ull;
+      for (uint32_t dx = 0; dx <= x1 - x0; dx++)
+        for (uint32_t dy = 0; dy <= y1 - ytop; dy++)
+          if (idx[(uint64_t)(x0 + dx) * H + ytop + dy] == v) m |= 1ull << (dx * 8u + dy);
+      rec.kind = 1;
+      rec.mask = m;
+    } else if (area <= kDenseFactor * n + kDenseSlack) {
+      rec.kind = 2;
+      rec.mask = (unsigned long long)x1 | ((unsigned long long)y1 << 16);
+    } else {            // sparse, as in k_rec_big
+      rec.kind = 0; rec.pad = 1;
+      rec.mask = n;
+      big_count[2] = 1u;
+    }
+    frags[v] = rec;
+    big4[v] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  grid_barrier(&big_count[3], 2u * gridDim.x);
+  if (__hip_atomic_load(&big_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (uint64_t)gridDim.x * kBlock)
+    scatter_sparse_pixel<KIND>(i, idx, probs, weights, P, C, iew, frags, acc);
 }
 
 // After the fusion, when the image is much smaller than the primitive count: only the records the image touched.
@@ -207,8 +461,14 @@ static size_t block_bytes(uint64_t P) { return (((size_t)P * (sizeof(TriFrag) + 
 
 void ImageRecords::release() {
   if (frags) (void)hipFree(frags);
-  frags = nullptr; cand = nullptr; big4 = nullptr; big_queue = nullptr; big_count = nullptr;
+  frags = nullptr; cand = nullptr; big4 = nullptr; big_queue = nullptr; big_count = nullptr; mom = nullptr;
   P = 0; clean = false;
+}
+
+// Moments (passes M, R, E, C') when the packed sums are exact: fewer than 2^24 pixels, sides of 16 .. 16383 pixels.
+static bool use_moments(uint64_t W, uint64_t H) {
+  static const bool off = getenv("SMESH_REC_MOMENTS") && atoi(getenv("SMESH_REC_MOMENTS")) == 0;
+  return !off && W >= 16 && H >= 16 && W < 16384 && H < 16384 && W * H < (1ull << kMomCountBits);
 }
 
 int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, uint64_t P) {
@@ -218,19 +478,37 @@ int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, 
     r.release();
     const size_t n = (size_t)(P ? P : 1);
     char* base = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), block_bytes(n) + n * (sizeof(uint4) + 4));
+    const size_t total = block_bytes(n) + n * (sizeof(uint4) + 8 + 4);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), total);
     if (e != hipSuccess) return fail_hip(e, "image records allocation", __FILE__, __LINE__);
     r.frags = reinterpret_cast<TriFrag*>(base);
     r.cand = reinterpret_cast<uint32_t*>(base + n * sizeof(TriFrag));
     r.big_count = reinterpret_cast<uint32_t*>(base + n * (sizeof(TriFrag) + 4));
     r.big4 = reinterpret_cast<uint4*>(base + block_bytes(n));
-    r.big_queue = reinterpret_cast<uint32_t*>(base + block_bytes(n) + n * sizeof(uint4));
+    r.mom = reinterpret_cast<unsigned long long*>(base + block_bytes(n) + n * sizeof(uint4));
+    r.big_queue = reinterpret_cast<uint32_t*>(base + block_bytes(n) + n * (sizeof(uint4) + 8));
     r.P = P;
-    r.clean = false;
+    SMESH_HIP(hipMemsetAsync(base, 0, total, st));    // once: every pass leaves big4 / mom zero behind it
+    r.clean = true;
   }
-  if (!r.clean) SMESH_HIP(hipMemsetAsync(r.frags, 0, block_bytes(P ? P : 1) + (size_t)(P ? P : 1) * sizeof(uint4), st));
-  r.clean = false;   // until image_records_clear has run
   const uint64_t N = W * H;
+  r.moments = use_moments(W, H);
+  if (r.moments) {
+    // frags may hold the last image's records: pass R rewrites whatever differs
+    r.clean = false;
+    static const int dbg = getenv("SMESH_REC_DBG") ? atoi(getenv("SMESH_REC_DBG")) : 0;   // development ablation (timing only: wrong results)
+    const uint32_t strips_y = (uint32_t)div_up(H, kTY), nstrips = (uint32_t)div_up(W, kSX) * strips_y;
+    const uint32_t strips_per_xcd = (uint32_t)div_up(nstrips, 8);
+    hipLaunchKernelGGL(k_rec_moments, dim3(strips_per_xcd * 8), dim3(kWave), 0, st, d_idx, (uint32_t)W, (uint32_t)H, (uint32_t)P, strips_y, nstrips,
+                       strips_per_xcd, r.tag, dbg, r.mom, r.frags, r.big_count);
+    hipLaunchKernelGGL(k_rec_resolve, dim3((uint32_t)div_up(P ? P : 1, kBlock)), dim3(kBlock), 0, st, d_idx, (uint32_t)W, (uint32_t)H, (uint32_t)P,
+                       r.tag, dbg, r.mom, r.frags, r.big_queue, r.big_count);
+    r.tag ^= 6u;      // 2 <-> 4
+    SMESH_HIP(hipGetLastError());
+    return SMESH_OK;
+  }
+  if (!r.clean) SMESH_HIP(hipMemsetAsync(r.frags, 0, block_bytes(P ? P : 1), st));
+  r.clean = false;   // until image_records_clear has run
   const dim3 grid((uint32_t)div_up(N, kBlock)), block(kBlock);
   hipLaunchKernelGGL(k_rec_origin, grid, block, 0, st, d_idx, N, (uint32_t)H, (uint32_t)P, r.cand);
   hipLaunchKernelGGL(k_rec_mask, grid, block, 0, st, d_idx, N, (uint32_t)H, (uint32_t)P, r.cand, r.big4, r.frags, r.big_queue, r.big_count);
@@ -239,21 +517,46 @@ int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, 
   return SMESH_OK;
 }
 
+// Passes E, C' and D of the moments variant (between the build and the fusion launch); nothing for passes A / B.
+int image_records_pending(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
+                          uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st) {
+  if (!r.moments) return SMESH_OK;
+  const uint64_t N = W * H;
+  const dim3 grid((uint32_t)std::min<uint64_t>(div_up(N, kBlock), 2u * (uint32_t)std::max(1, ctx->num_cus))), block(kBlock);
+  switch (kind) {
+    case SMESH_AGG_SUM:
+      hipLaunchKernelGGL(k_rec_tail<SMESH_AGG_SUM>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)H, (uint32_t)r.P, C, iew, r.frags, r.big4,
+                         r.big_queue, r.big_count, acc);
+      break;
+    case SMESH_AGG_SUMMAX:
+      hipLaunchKernelGGL(k_rec_tail<SMESH_AGG_SUMMAX>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)H, (uint32_t)r.P, C, iew, r.frags, r.big4,
+                         r.big_queue, r.big_count, acc);
+      break;
+    default:
+      hipLaunchKernelGGL(k_rec_tail<SMESH_AGG_MUL>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)H, (uint32_t)r.P, C, iew, r.frags, r.big4,
+                         r.big_queue, r.big_count, acc);
+      break;
+  }
+  SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
+}
+
 int image_records_scatter_sparse(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
-                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc) {
+                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st) {
+  if (r.moments) return SMESH_OK;     // (pass D ran inside k_rec_tail, ahead of the fusion)
   const uint64_t N = W * H;
   const dim3 grid((uint32_t)div_up(N, kBlock)), block(kBlock);
   switch (kind) {
     case SMESH_AGG_SUM:
-      hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_SUM>, grid, block, 0, ctx->stream, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
+      hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_SUM>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
                          r.big_count, acc);
       break;
     case SMESH_AGG_SUMMAX:
-      hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_SUMMAX>, grid, block, 0, ctx->stream, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
+      hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_SUMMAX>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
                          r.big_count, acc);
       break;
     default:
-      hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_MUL>, grid, block, 0, ctx->stream, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
+      hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_MUL>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
                          r.big_count, acc);
       break;
   }
@@ -261,12 +564,13 @@ int image_records_scatter_sparse(DeviceCtx* ctx, ImageRecords& r, int kind, cons
   return SMESH_OK;
 }
 
-int image_records_clear(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H) {
+int image_records_clear(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, hipStream_t st) {
   const uint64_t N = W * H;
+  if (r.moments) return SMESH_OK;     // nothing to clear: the next build's pass R rewrites the records
   if (r.P <= N) {
-    SMESH_HIP(hipMemsetAsync(r.frags, 0, block_bytes(r.P ? r.P : 1), ctx->stream));
+    SMESH_HIP(hipMemsetAsync(r.frags, 0, block_bytes(r.P ? r.P : 1), st));
   } else {
-    hipLaunchKernelGGL(k_rec_clear, dim3((uint32_t)div_up(N, kBlock)), dim3(kBlock), 0, ctx->stream, d_idx, N, (uint32_t)r.P, r.cand, r.frags,
+    hipLaunchKernelGGL(k_rec_clear, dim3((uint32_t)div_up(N, kBlock)), dim3(kBlock), 0, st, d_idx, N, (uint32_t)r.P, r.cand, r.frags,
                        r.big_count);
     SMESH_HIP(hipGetLastError());
   }

@@ -103,10 +103,14 @@ class _MeshAggregator:
                 if matched.value:
                     release_to(self.device, streams)
                     return
-        _lib.check(_lib.lib().smesh_aggregator_add(
+        # Host images are consumed before the call returns (Fusion.h:45-47).  Device images are read asynchronously: this library's own
+        # DeviceArrays are freed behind its streams, other frameworks' streams are put behind the reads by release_to() -- so the
+        # record passes of the next add() on a foreign image can run beside this call's fusion (fusion.hip, add_device).
+        _lib.check(_lib.lib().smesh_aggregator_add_async(
             self._h, ctypes.c_void_p(ip), _IDX_CODES[idt], _c64(istr), imem,
             ctypes.c_void_p(pp), _c64(pstr), pmem,
             None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H))
+        release_to(self.device, streams)
 
     # class-wide switch for the content check above
     match_renders = os.environ.get("SMESH_MATCH_RENDERS", "1") != "0"
