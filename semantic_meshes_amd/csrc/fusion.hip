@@ -1934,13 +1934,14 @@ int stage_in(DeviceCtx* ctx, Scratch& st, const void* host, size_t bytes, const 
 
 size_t idx_itemsize(int dt) { return (dt == SMESH_IDX_U64 || dt == SMESH_IDX_I64) ? 8 : 4; }
 
-// Class count from which add() on a foreign image rebuilds per-primitive records and fuses in triangle order (image_records.hip):
-// building them costs a fixed ~3 integer atomics per run of pixels (~100 us per cfg2-sized image), the scatter-add float atomics
-// in proportion to the row width.  At cfg2's geometry, ms per view records / scatter: C = 19 0.149 / 0.122, 24 0.163 / 0.168,
-// 28 0.175 / 0.167, 32 0.196 / 0.391, 36 0.202 / 0.303, 48 0.230 / 0.498, 64 0.357 / 0.805, 150 0.780 / 1.511
-// (tools/generic_add_sweep.py); cfg5: 3.5 / 7.4.  Below the threshold the records path is still available (SMESH_ADD_RECORDS_MIN_C=0)
-// for callers who want the deterministic, reference-ordered sums more than the last 20 %.
-constexpr uint32_t kAddRecordsMinC = 32;
+// Class count from which add() on a foreign image rebuilds per-primitive records and fuses in triangle order (image_records.hip).
+// Round 2 (passes A / B, ~3 integer atomics per run of pixels, ~100 us per cfg2-sized image) set it to 32: ms per view records /
+// scatter at cfg2's geometry C = 19 0.149 / 0.122, 32 0.196 / 0.391.  Round 3 (passes M / R: one atomic per (primitive, strip) group,
+// asynchronous add): 2 0.053 / 0.093, 5 0.053 / 0.063, 13 0.066 / 0.105, 19 0.075 / 0.110, 27 0.108 / 0.144, 32 0.121 / 0.374,
+// 48 0.157, 64 0.294, 150 0.717 (tools/generic_add_sweep.py, profiles/r03_foreign_images_class_sweep.txt): the records win at every
+// class count, and they are deterministic with the reference's order of additions.  SMESH_ADD_RECORDS_MIN_C moves the threshold,
+// SMESH_ADD_RECORDS=0 turns the records off.
+constexpr uint32_t kAddRecordsMinC = 0;
 
 // Core of add() once every buffer is in device memory.
 int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int64_t is[2],

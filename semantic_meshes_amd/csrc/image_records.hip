@@ -175,11 +175,19 @@ constexpr int kMomCountBits = 24, kMomSumBits = 20;
 
 typedef uint32_t u32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load at 4-byte alignment (a window row of the index image)
 
+__device__ __forceinline__ unsigned long long shfl64(unsigned long long x, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)x, src), hi = (uint32_t)__shfl((int)(uint32_t)(x >> 32), src);
+  return (unsigned long long)lo | ((unsigned long long)hi << 32);
+}
+
+// Pass M.  The strip's runs, links and groups are those of strip.inc.hpp (build_strip: the histogram and scatter-add kernels), but
+// worked out in registers: equal neighbours across columns are three wave shuffles and ballots, a run's first match in the next
+// column is bit arithmetic on them, and the (at most four) runs of a chain are folded into its root by two pointer-doubling hops --
+// no LDS, no loops over rows.
 __global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t strips_y,
                                                        uint32_t nstrips, uint32_t strips_per_xcd, uint32_t tag, int dbg,
                                                        unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
                                                        uint32_t* __restrict__ big_count) {
-  __shared__ StripLists L;
   const uint32_t b = blockIdx.x;
   const int l = threadIdx.x;
   if (b == 0u && l == 0) { big_count[0] = 0u; big_count[2] = 0u; big_count[3] = 0u; }   // (R, later on the stream, is the first to touch them)
@@ -190,36 +198,69 @@ __global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restric
   const uint32_t x0 = bx * kSX, y0 = by * kTY;
   const int cx = l / kTY, ty = l - cx * kTY;
   const bool in = x0 + (uint32_t)cx < W && y0 + (uint32_t)ty < H;
-  const uint32_t v = in ? idx[(uint64_t)(x0 + cx) * H + y0 + ty] : 0xFFFFFFFFu;
-  const StripRuns r = build_strip(L, v, P, l);
-  if (!r.root) return;
-  // the chain: at most four runs, one per column, left to right
-  uint32_t n = 0, sx = 0, sy = 0;
-  int ymin = kTY, ymax = -1;
+  uint32_t v = in ? idx[(uint64_t)(x0 + cx) * H + y0 + ty] : 0xFFFFFFFFu;
+  if (v >= P) v = 0xFFFFFFFFu;
+  const bool valid = v != 0xFFFFFFFFu;
+  // ---- runs down the columns
+  const uint32_t prev = (uint32_t)__shfl_up((int)v, 1);
+  const bool head = ty == 0 || v != prev;
+  const unsigned long long heads = __ballot(head);
+  const unsigned long long upto = (2ull << l) - 1ull;          // bits 0 .. l (l = 63: all ones)
+  const unsigned long long later = heads & ~upto;
+  const int len = (later ? (__ffsll((long long)later) - 1) : kWave) - l;     // (head lanes: at most 16, a head starts every column)
+  const unsigned long long run = (((1ull << (len & 31)) - 1ull) | (len >= 32 ? ~0ull : 0ull)) << l;   // this lane .. the end of its run
+  // ---- equal pixels in the column to the right, one row up / level / one row down (8-connectivity)
+  auto right_equal = [&](int d) -> bool {
+    const uint32_t o = (uint32_t)__shfl((int)v, (l + kTY + d) & (kWave - 1));
+    return valid && cx < kSX - 1 && (unsigned)(ty + d) < (unsigned)kTY && o == v;
+  };
+  const unsigned long long B0 = __ballot(right_equal(0)), Bp = __ballot(right_equal(1)), Bm = __ballot(right_equal(-1));
+  // the same relation seen from the right-hand pixel: its left neighbours
+  const unsigned long long G0 = B0 << kTY, Gp = Bm << (kTY - 1), Gm = Bp << (kTY + 1);
+  auto head_of = [&](int q) -> int { return 63 - __clzll((long long)(heads & ((2ull << q) - 1ull))); };
+  // first row of the neighbouring column, from one above the run to one below it, that holds the same primitive -> that run's head
+  int rc = kNone, lp = kNone;
   {
-    int q = l;
-    for (int hop = 0; hop < kSX && q != kNone; hop++) {
-      const uint32_t len = L.slen[q];
-      const int qx = q / kTY, qy = q - qx * kTY;
-      n += len;
-      sx += len * (x0 + (uint32_t)qx);
-      sy += len * (y0 + (uint32_t)qy) + ((len * (len - 1u)) >> 1);
-      ymin = min(ymin, qy);
-      ymax = max(ymax, qy + (int)len - 1);
-      q = L.child[q];
+    const unsigned long long rows_r = (B0 & run) | ((Bp & run) << 1) | ((Bm & run) >> 1);
+    const unsigned long long rows_l = (G0 & run) | ((Gp & run) << 1) | ((Gm & run) >> 1);
+    if (rows_r) rc = head_of(__builtin_ctzll(rows_r) + kTY);
+    if (rows_l) lp = head_of(__builtin_ctzll(rows_l) - kTY);
+  }
+  // ---- a link exists only when both runs chose each other, so chains never fork
+  const int lp_of_rc = __shfl(lp, rc != kNone ? rc : l), rc_of_lp = __shfl(rc, lp != kNone ? lp : l);
+  const bool hv = head && valid;
+  const int child = (hv && rc != kNone && lp_of_rc == l) ? rc : kNone;
+  const bool root = hv && !(lp != kNone && rc_of_lp == l);
+  // ---- fold the chain into its root: count | sum x | sum y (the moment word) and the strip-relative pixel mask (bit = lane)
+  const uint32_t ulen = (uint32_t)len;
+  unsigned long long pk = 0ull, sm = 0ull;
+  if (hv) {
+    pk = (unsigned long long)ulen | ((unsigned long long)(ulen * (x0 + (uint32_t)cx)) << kMomCountBits) |
+         ((unsigned long long)(ulen * (y0 + (uint32_t)ty) + ((ulen * (ulen - 1u)) >> 1)) << (kMomCountBits + kMomSumBits));
+    sm = run;
+  }
+  const bool has1 = child != kNone;
+  const int c2raw = __shfl(child, has1 ? child : l);
+  const bool has2 = has1 && c2raw != kNone;
+  if (__ballot(has1) != 0ull) {
+    // hop 1: every head adds its child's run; hop 2: its grandchild's, which by then holds grandchild + great-grandchild
+    const unsigned long long opk = shfl64(pk, has1 ? child : l), osm = shfl64(sm, has1 ? child : l);
+    if (has1) { pk += opk; sm |= osm; }
+    if (__ballot(has2) != 0ull) {
+      const unsigned long long opk2 = shfl64(pk, has2 ? c2raw : l), osm2 = shfl64(sm, has2 ? c2raw : l);
+      if (has2) { pk += opk2; sm |= osm2; }
     }
   }
-  if (!(dbg & 4))
-    atomicAdd(&mom[v], (unsigned long long)n | ((unsigned long long)sx << kMomCountBits) | ((unsigned long long)sy << (kMomCountBits + kMomSumBits)));
+  if (!root) return;
+  if (!(dbg & 4)) atomicAdd(&mom[v], pk);
+  uint32_t rows = (uint32_t)(sm | (sm >> 32));
+  rows = (rows | (rows >> 16)) & 0xFFFFu;
+  const int ymin = __builtin_ctz(rows), ymax = 31 - __builtin_clz(rows);
   if (ymax - ymin < 8 && !(dbg & 2)) {
-    unsigned long long mask = 0ull;
-    int q = l;
-    for (int hop = 0; hop < kSX && q != kNone; hop++) {
-      const uint32_t len = L.slen[q];
-      const int qx = q / kTY, qy = q - qx * kTY;
-      mask |= ((1ull << len) - 1ull) << ((qx - cx) * 8 + (qy - ymin));     // bit dx * 8 + dy (common.hpp, TriFrag)
-      q = L.child[q];
-    }
+    unsigned long long mask = 0ull;               // bit dx * 8 + dy (common.hpp, TriFrag); the chain's columns are cx, cx + 1, ...
+#pragma unroll
+    for (int j = 0; j < kSX; j++)
+      if (cx + j < kSX) mask |= (unsigned long long)(((uint32_t)(sm >> (kTY * (cx + j))) & 0xFFFFu) >> ymin & 0xFFu) << (8 * j);
     *reinterpret_cast<uint4*>(&frags[v]) = make_uint4((x0 + (uint32_t)cx) | ((y0 + (uint32_t)ymin) << 16), 1u | (tag << 16),
                                                       (uint32_t)mask, (uint32_t)(mask >> 32));
   }
@@ -256,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_rec_resolve(const uint32_t* __restri
   const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
   if (v >= P) return;
   const unsigned long long m = mom[v];
-  uint4 raw = *reinterpret_cast<const uint4*>(&frags[v]);
+  const uint4 raw = *reinterpret_cast<const uint4*>(&frags[v]);
   if (m == 0ull) {                       // not in this image: no record (whatever the last image left is cleared)
     if (raw.x | raw.y | raw.z | raw.w) *reinterpret_cast<uint4*>(&frags[v]) = make_uint4(0u, 0u, 0u, 0u);
     return;
@@ -266,16 +307,32 @@ __global__ __launch_bounds__(kBlock) void k_rec_resolve(const uint32_t* __restri
   const unsigned long long smask = (unsigned long long)raw.z | ((unsigned long long)raw.w << 32);
   // One group holds every pixel: its record stands as it is.  (`tag` alternates between calls, and every record this pass meets was
   // left by the previous call or written by this call's pass M: a stale record never carries this call's tag.)
+  // (Compacting the others -- a sixth of cfg2's primitives, spread over every wave -- through LDS so that one wave of the workgroup
+  // repairs them was measured slower: 13.8 -> 15.4 us.)
   if (((raw.y >> 16) == tag && (uint32_t)__popcll(smask) == n) || (dbg & 1)) return;
   uint4 rec = make_uint4(0u, kPadPending << 16, n, 0u);                      // pending: kind 0, the pixel count parked in the mask
   bool queue = true;
   if (n <= 64u) {
     const uint32_t fx = (uint32_t)((m >> kMomCountBits) & ((1ull << kMomSumBits) - 1ull)) / n;
     const uint32_t fy = (uint32_t)(m >> (kMomCountBits + kMomSumBits)) / n;
-    // a primitive of at most 8 x 8 pixels lies within 7 pixels of (the floor of) its centroid; most lie within [-3, +4]
+    // a primitive of at most 8 x 8 pixels lies within 7 pixels of (the floor of) its centroid; most lie within [-3, +4], and the
+    // typical one here -- two or three pixels cut by a strip border -- within [-1, +2]: four loads instead of sixteen
+    unsigned long long m4 = 0ull;
+    const uint32_t xq = min(fx > 1u ? fx - 1u : 0u, W - 4u), yq = min(fy > 1u ? fy - 1u : 0u, H - 4u);
+    if (n <= 16u) {
+#pragma unroll
+      for (int dx = 0; dx < 4; dx++) {
+        const u32x4u a = *reinterpret_cast<const u32x4u*>(idx + (uint64_t)(xq + dx) * H + yq);
+        m4 |= (unsigned long long)((a.x == v ? 1u : 0u) | (a.y == v ? 2u : 0u) | (a.z == v ? 4u : 0u) | (a.w == v ? 8u : 0u)) << (dx * 8);
+      }
+    }
+    const bool found4 = n <= 16u && (uint32_t)__popcll(m4) == n;
     const uint32_t xs = min(fx > 3u ? fx - 3u : 0u, W - 8u), ys = min(fy > 3u ? fy - 3u : 0u, H - 8u);
-    const unsigned long long m8 = scan8(idx, H, xs, ys, v);
-    if ((uint32_t)__popcll(m8) == n) {
+    const unsigned long long m8 = found4 ? 0ull : scan8(idx, H, xs, ys, v);
+    if (found4) {
+      rec = record_from_window(m4, xq, yq);
+      queue = false;
+    } else if ((uint32_t)__popcll(m8) == n) {
       rec = record_from_window(m8, xs, ys);
       queue = false;
     } else {

@@ -116,7 +116,8 @@ class _MeshAggregator:
     match_renders = os.environ.get("SMESH_MATCH_RENDERS", "1") != "0"
 
     def _records_from_image(self):
-        """From 32 classes up smesh_aggregator_add rebuilds the per-primitive records from ANY dense image (image_records.hip) and
+        """smesh_aggregator_add rebuilds the per-primitive records from ANY dense image (image_records.hip; every class count since
+        round 3, SMESH_ADD_RECORDS_MIN_C moves the threshold) and
         runs the same triangle-order kernels as a matched render would -- without the content checksum's read-back, which costs more
         than the records do.  (Texel renderers keep the match: their records carry the texel tables.)"""
         if os.environ.get("SMESH_ADD_RECORDS") == "0" or os.environ.get("SMESH_FUSE") == "strip":
@@ -124,7 +125,7 @@ class _MeshAggregator:
         from .render import _live_renderers
         if any(getattr(rb, "is_texel", False) and rb.getPrimitivesNum() == self.primitives for rb in list(_live_renderers)):
             return False
-        return self.classes >= int(os.environ.get("SMESH_ADD_RECORDS_MIN_C", "32"))
+        return self.classes >= int(os.environ.get("SMESH_ADD_RECORDS_MIN_C", "0"))
 
     def reset(self):
         _lib.check(_lib.lib().smesh_aggregator_reset(self._h))

@@ -16,8 +16,8 @@ STRIP = os.environ.get("SMESH_FUSE") == "strip" or os.environ.get("SMESH_ADD_REC
 
 @pytest.fixture(autouse=True)
 def records_for_every_class_count():
-    """add() rebuilds records from the image for class counts from 32 by default (below that the scatter-add is ~20 % faster);
-    here every class count takes them.  SMESH_ADD_RECORDS_MIN_C is read per call."""
+    """add() rebuilds records from the image for every class count by default (round 2: from 32); pinned here so that an
+    environment that sets SMESH_ADD_RECORDS_MIN_C does not change what these tests cover.  The knob is read per call."""
     old = os.environ.get("SMESH_ADD_RECORDS_MIN_C")
     os.environ["SMESH_ADD_RECORDS_MIN_C"] = "0"
     yield
@@ -214,13 +214,19 @@ def test_scatter_path_in_subprocess():
     assert res.returncode == 0, res.stdout[-3000:] + res.stderr[-2000:]
 
 
-def test_default_threshold(sm, oracle):
-    """Without the knob: narrow rows take the scatter-add, rows of 32 classes and more the image records."""
+@pytest.mark.parametrize("min_c", [None, 32])
+def test_default_threshold(sm, oracle, min_c):
+    """Without the knob every class count takes the image records (round 3: the moments passes made them faster than the scatter-add
+    at every class count, tools/generic_add_sweep.py); SMESH_ADD_RECORDS_MIN_C = 32 restores round 2's split."""
     os.environ.pop("SMESH_ADD_RECORDS_MIN_C", None)
+    if min_c is not None:
+        os.environ["SMESH_ADD_RECORDS_MIN_C"] = str(min_c)
     W, H, P = 160, 120, 300
     rng = np.random.default_rng(4)
     img = blob_image(rng, W, H, P, 250)
-    for C, want in ((19, "scatter"), (31, "scatter"), (32, "image-records"), (150, "image-records")):
+    for C, want in ((2, "image-records"), (19, "image-records"), (31, "image-records"), (32, "image-records"), (150, "image-records")):
+        if min_c is not None and C < min_c:
+            want = "scatter"
         agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
         oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
         probs = random_probs(rng, W, H, C)

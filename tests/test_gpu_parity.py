@@ -593,6 +593,7 @@ def test_fuse_views_medium_triangles(sm, oracle, kind, C, iew):
         want = oagg.get()
         assert (want.sum(axis=1) > 0.5).sum() > P // 2
         # (Mul behind SMESH_FUSE=strip: the generic scatter-add adds in float32 on the hi plane, as in the tests above)
+        import os
         tol = 5e-3 if kind == "mul" and os.environ.get("SMESH_FUSE") == "strip" else 1e-5
         assert_fused_close(group.get(), want, rtol=tol)
         assert_fused_close(single.get(), want, rtol=tol)
@@ -776,13 +777,19 @@ def test_fuse_view_texels_big_triangles(sm, oracle, kind):
     assert_fused_close(agg.get(), oagg2.get(), rtol=2e-5)
 
 
-def test_add_after_render_takes_triangle_order_path(sm, oracle):
+@pytest.mark.parametrize("content_match", [False, True])
+def test_add_after_render_takes_triangle_order_path(sm, oracle, monkeypatch, content_match):
     """The reference's two-call loop `idx, depth = renderer.render(cam); aggregator.add(idx, probs)`
-    (colorize_cityscapes_mesh.py:65-67): add() recognises the output of one of the last six renders -- by identity when it
-    is the untouched DeviceArray, by CONTENT when it went through another framework or numpy -- and runs the triangle-order
-    fusion on the records that render left ("render-records"); an older render, or an image that was changed, has its
-    records rebuilt from the image ("image-records", image_records.hip).  All give the oracle's result."""
+    (colorize_cityscapes_mesh.py:65-67): add() recognises the untouched DeviceArray of one of the last six renders by identity and
+    runs the triangle-order fusion on the records that render left ("render-records").  An image that went through another framework
+    or numpy, an older render, an image that was changed: its records are rebuilt from the image ("image-records",
+    image_records.hip) -- or, with SMESH_ADD_RECORDS_MIN_C above the class count (round 2's default below 32 classes;
+    `content_match`), recognised by CONTENT ("render-records") and otherwise handed to the scatter-add.  All give the oracle's result."""
     import os
+    if content_match:
+        monkeypatch.setenv("SMESH_ADD_RECORDS_MIN_C", "32")
+    else:
+        monkeypatch.delenv("SMESH_ADD_RECORDS_MIN_C", raising=False)
     from semantic_meshes_amd.device import to_device
     mesh, cams = small_scene(120, 60, 320, 240, views=8)
     P, C = len(mesh.faces), 19
@@ -795,8 +802,11 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
     oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
     forced_generic = os.environ.get("SMESH_FUSE") == "strip"
     fast = "k_scatter_strip" if forced_generic else "k_fuse_tri"
-    matched = "scatter" if forced_generic else "render-records"
-    generic = "scatter"        # (C = 19: below the class count from which add() rebuilds records from the image, test_gpu_image_records.py)
+    matched = "scatter" if forced_generic else "render-records"                    # by identity
+    records_off = forced_generic or os.environ.get("SMESH_ADD_RECORDS") == "0"       # (test_gpu_image_records.py runs this file that way too)
+    content_match = content_match or records_off
+    generic = "scatter" if content_match else "image-records"                      # no render recognised
+    matched_c = matched if content_match else generic                              # a copy of a render: by content, or as any image
     for cam in cams[:3]:
         probs = random_probs(rng, *cam.resolution, C)
         weights = rng.random(cam.resolution, dtype=np.float32)
@@ -821,7 +831,7 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
     _ = kept[5].__cuda_array_interface__
     assert kept[5]._exported
     agg.add(kept[5], probs)
-    assert last() == fast and path() == matched
+    assert last() == fast and path() == matched_c
     oagg.add(o.render(cams[5])[0], probs)
     # ... and after someone changed a single pixel of it the generic path takes over (and honours the change)
     _ = kept[4].__cuda_array_interface__          # exported (the library takes the plane's checksum at this point) ...
@@ -834,10 +844,10 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle):
     oagg.add(changed, probs)
     # 3. a numpy COPY of a render (DLPack -> framework -> .numpy() in the reference's harness) with host probs
     agg.add(np.asarray(kept[2]), probs)
-    assert last() == fast and path() == matched
+    assert last() == fast and path() == matched_c
     oagg.add(o.render(cams[2])[0], probs)
     agg.add(np.asarray(kept[2]).astype(np.int32), probs)          # int32 copies too (-1 == 0xFFFFFFFF)
-    assert last() == fast and path() == matched
+    assert last() == fast and path() == matched_c
     oagg.add(o.render(cams[2])[0], probs)
     agg.add(np.asarray(kept[2]).astype(np.int64), probs)          # 64-bit images are never a copy of a plane: records from the image
     assert path() == generic
