@@ -189,7 +189,8 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
     """add() on index images the library did not render (the reference's add() takes any (W,H) image, Mesh.h:65-107; its
     harness reloads renders from an .npz cache, eval_scannet.py:168-185): device-resident COPIES of renders -- no render
     matches by identity, content matching off -- with device-resident probs.  Per-primitive records are rebuilt from the image
-    and fused in triangle order from 32 classes up, the atomic scatter-add runs below (fusion.hip, kAddRecordsMinC).  Never `value`."""
+    (image_records.hip: one atomic per (primitive, strip) group, round 3) and fused in triangle order at every class count; the atomic
+    scatter-add remains behind SMESH_ADD_RECORDS=0 (fusion.hip, kAddRecordsMinC).  Never `value`."""
     from semantic_meshes_amd.device import to_device
     images = [to_device(np.asarray(renderer.render(cams[k % len(cams)])[0]), device) for k in range(views)]
     agg = fusion.MeshAggregator(primitives=P, classes=C, device=device)
@@ -208,7 +209,8 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
     bytes_per_view = 4 * W * H + 4 * W * H * C + 8 * C * T_mean
     scatter_path, scatter_kernel = _lib.lib().smesh_last_add_path().decode(), _lib.lib().smesh_last_fuse_kernel().decode()
     # ... and the same copies with content matching ON, of renders that were exported (np.asarray seals a plane): the harness-shaped
-    # case (eval_scannet.py:211-238), recognised by checksum and fused in triangle order on the renderer's records
+    # case (eval_scannet.py:211-238).  Round 2 recognised them by checksum and fused on the renderer's records; since round 3 the
+    # Python layer skips the checksum (a host read-back per call) wherever add() rebuilds the records from the image -- `path` says which
     matched = None
     try:
         nm = min(views, 6)                                                # the renderer keeps the records of its last six renders
@@ -230,8 +232,8 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
         matched = {"ms_per_view": round(1e3 * best, 4), "kernels": sorted(kernels),
                    "frac": round(bytes_per_view / best / 1e9 / HBM_PEAK_GBS, 4),
                    "path": _lib.lib().smesh_last_add_path().decode(),
-                   "what": "add(device copy of an EXPORTED render, device probs), content matching on "
-                           "(below 32 classes: checksum match -> the renderer's records), %d views" % nm}
+                   "what": "add(device copy of an EXPORTED render, device probs), content matching allowed "
+                           "(taken only where the image records are off: SMESH_ADD_RECORDS_MIN_C / texel renderers), %d views" % nm}
     except Exception as e:
         matched = {"error": str(e)[:200]}
     return {"matched_copies": matched, "ms_per_view": round(1e3 * dt, 4), "views_per_s": round(1.0 / dt, 1), "path": scatter_path,
