@@ -4,7 +4,9 @@
 // of the atomic scatter-add: every accumulator row then has one owner, the additions happen in the reference's pixel order
 // (Mesh.h:94-106 run single-threaded) and the result no longer depends on the order in which float atomics land.
 //
-// What the rasteriser leaves per triangle (common.hpp, TriFrag) is rebuilt per PRIMITIVE from the image alone:
+// What the rasteriser leaves per triangle (common.hpp, TriFrag) is rebuilt per PRIMITIVE from the image alone.  Round 3's passes
+// (M, R, E / C' / D: one atomic per (primitive, strip) group, further down) serve every image of 16 .. 16383 pixels a side with fewer
+// than 2^24 pixels; round 2's passes serve the rest and stay behind SMESH_REC_MOMENTS=0:
 //   pass A  k_rec_origin   per run of equal indices in a column: ONE 32-bit atomic that leaves the primitive's first pixel in
 //                          (x, y) order -- its smallest x, and the smallest y of that column (atomic max on the complement of
 //                          x << 16 | y: the cleared state, 0, means "no pixel")
@@ -160,14 +162,15 @@ __global__ __launch_bounds__(kBlock) void k_rec_big(const uint32_t* __restrict__
 //   pass M  k_rec_moments  one wave per strip (strip.inc.hpp: runs linked into chains across the strip's four columns); the root
 //                          lane of each group adds the group's pixel count, sum of x and sum of y to the primitive's 64-bit moment
 //                          word (count: 24 bits, sums: 20 bits each -- exact for up to 64 pixels below 16384 x 16384; beyond, only
-//                          the count is used) and STORES the group's own 8 x 8 record (plainly, tagged kPadSpec).
+//                          the count is used) and STORES the group's own 8 x 8 record (plainly, tagged with the call's tag).
 //   pass R  k_rec_resolve  one lane per primitive: a stored record whose population count equals the primitive's total count IS the
 //                          primitive (a group that holds every pixel has no rival writer) -- 85 % of cfg2's primitives.  Otherwise
 //                          the lane scans the index image around the centroid (8 x 8, then 16 x 16 pixels): all `count` pixels found
 //                          -> the exact record (mask at the true origin, or a kind 2 box); else (more than 64 pixels, or pixels
 //                          further than 7 from the centroid) the primitive is queued as "pending", and
-//   pass E  k_rec_extent   (leaves at once when nothing is pending) per run of a pending primitive: its extent by atomics,
-//   pass C' k_rec_pending  per pending primitive: kind 2 record, or "sparse" exactly as k_rec_big decides it.
+//   passes E, C', D  k_rec_tail  (one launch, grid barriers; leaves at once when nothing is pending) E: per run of a pending primitive
+//                          its extent by atomics; C': per pending primitive the kind 2 record, or "sparse" exactly as k_rec_big
+//                          decides it; D: the sparse primitives' pixels by float atomics, ahead of the fusion launch.
 // No clear pass: R rewrites every record that differs and zeroes the moment words it consumed, C' its extent words, M the counters.
 // ================================================================================================================================
 constexpr uint32_t kPadPending = 3u;    // (1: sparse, k_rec_big; 2 and 4: the alternating tags of pass M's own records)
