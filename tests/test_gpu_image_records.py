@@ -306,3 +306,128 @@ def test_foreign_image_cfg5_full_size(sm):
             np.testing.assert_allclose(ra, rb, rtol=1e-5, atol=1e-7)
         else:
             np.testing.assert_array_equal(ra.view(np.uint32), rb.view(np.uint32))
+
+
+# ---- round 3: records from moments (passes M / R / E / C' / D of image_records.hip) ----------------------------------------------
+
+def _crafted_image(W, H, shift=0):
+    """Primitives placed to hit every branch of k_rec_resolve / k_rec_tail.  Strips are 4 columns x 16 rows: borders at x = 4k, y = 16k.
+    Returns the image and the number of primitives it uses."""
+    img = np.full((W, H), BG, np.uint32)
+    p = lambda k: np.uint32((k + shift) % 12)
+    img[3:5, 7] = p(0)                                  # two pixels cut by a vertical strip border: the 4 x 4 window
+    img[3:6, 15:18] = p(1)                              # 3 x 3 over a strip corner (four groups)
+    img[10:18, 20:28] = p(2)                            # exactly 8 x 8 = 64 pixels over several strips: the 8 x 8 window
+    img[20:29, 20:28] = p(3)                            # 9 x 8 = 72 pixels: pending -> extent -> kind 2
+    img[0, 0] = p(4); img[W - 1, H - 1] = p(4)          # two pixels at opposite corners: pending -> sparse
+    img[30:37, 3] = p(5); img[30, 3:10] = p(5)          # an L of 13 pixels in a 7 x 7 box
+    for k in range(8):
+        img[40 + k, 30 + k] = p(6)                      # a diagonal (8-connected only) across strips
+    img[30, 40] = p(7); img[38, 40] = p(7)              # two pixels 8 apart: outside 8 x 8, inside 16 x 16 -> kind 2 from the lane
+    img[W - 2:, H - 2] = p(8)                           # next to the image corner: clamped windows
+    img[50, 1:13] = p(9)                                # a run of 12 in one column: one group that does not fit 8 x 8
+    img[44:46, 16:18] = p(10)                           # 2 x 2 whose centroid falls between pixels
+    img[56, 20] = p(11); img[56, 27] = p(11)            # two pixels 7 apart in y: the 8 x 8 window, exactly
+    return img
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C", [3, 19, 70])
+def test_moments_every_repair_branch(sm, oracle, kind, C):
+    """Crafted primitives for every branch of the moments passes (group record stands; 4 x 4, 8 x 8, 16 x 16 windows; kind 2 found by
+    the lane; pending -> extent -> kind 2; pending -> sparse; windows clamped at the image corner), three calls with the primitive
+    numbers rotated -- every record of call k is stale in call k+1, under the other tag -- against the float64 oracle."""
+    if STRIP:
+        pytest.skip("records are off")
+    W, H, P = 64, 48, 12
+    rng = np.random.default_rng(C + len(kind))
+    agg = sm.fusion.MeshAggregator(P, C, kind, 0.5)
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind, 0.5)
+        for call in range(3):
+            img = _crafted_image(W, H, shift=5 * call)
+            probs = random_probs(rng, W, H, C)
+            if kind == "mul":
+                probs = np.maximum(probs, 1e-3).astype(np.float32)
+            weights = (rng.random((W, H), dtype=np.float32) + 0.25).astype(np.float32) if call == 1 else None
+            agg.add(img, probs, weights)
+            assert path(sm) == "image-records"
+            oagg.add(img, probs, weights)
+            assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else 5e-3)   # (Mul: the sparse primitive's float atomics on the hi plane)
+    finally:
+        oracle.set_accum_double(False)
+
+
+@pytest.mark.parametrize("shape", [(16, 16), (17, 16), (16, 33), (15, 40), (40, 15), (1, 70), (333, 16)])
+def test_moments_smallest_images_and_the_switch_to_the_old_passes(sm, oracle, shape):
+    """Sides of 16 pixels and more take the moments passes, smaller images round 2's passes A / B -- the same aggregator alternates
+    between them (the scratch each leaves behind must be what the other expects)."""
+    if STRIP:
+        pytest.skip("records are off")
+    P, C = 40, 7
+    rng = np.random.default_rng(shape[0] * 100 + shape[1])
+    agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+    oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
+    for W, H in (shape, (64, 48), shape, (9, 9), shape):
+        img = blob_image(rng, W, H, P, 25)
+        probs = random_probs(rng, W, H, C)
+        agg.add(img, probs)
+        assert path(sm) == "image-records"
+        oagg.add(img, probs)
+        assert_fused_close(agg.get(), oagg.get())
+
+
+def test_moments_largest_image(sm, oracle):
+    """4096 x 4095 pixels, just under the 2^24 the moment word's count field holds (one primitive covers most of the image: its
+    count must not spill into the sums of the small ones), and 4096 x 4096, which takes round 2's passes."""
+    if STRIP:
+        pytest.skip("records are off")
+    from semantic_meshes_amd.device import to_device
+    P, C = 5000, 2
+    rng = np.random.default_rng(77)
+    oracle.set_accum_double(True)            # (primitive 0 sums 16 million terms: a sequential float32 sum is no yardstick for that)
+    try:
+        _largest_images(sm, oracle, to_device, rng, P, C)
+    finally:
+        oracle.set_accum_double(False)
+
+
+def _largest_images(sm, oracle, to_device, rng, P, C):
+    for W, H in ((4096, 4095), (4096, 4096)):
+        img = np.zeros((W, H), np.uint32)                              # primitive 0: everything else
+        xs, ys = rng.integers(0, W - 8, 4000), rng.integers(0, H - 8, 4000)
+        for k in range(4000):
+            img[xs[k]:xs[k] + 1 + k % 5, ys[k]:ys[k] + 1 + k % 7] = 1 + k   # small blocks, some overwriting each other
+        probs = np.empty((W, H, C), np.float32)
+        probs[..., 0] = rng.random((W, H), dtype=np.float32)
+        probs[..., 1] = 1.0 - probs[..., 0]
+        agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+        oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
+        agg.add(to_device(img), to_device(probs))
+        assert path(sm) == "image-records"
+        oagg.add(img, probs)
+        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        del agg
+
+
+def test_async_add_is_ordered_before_get_and_reset(sm, oracle):
+    """add() on device images returns before its kernels have run (smesh_aggregator_add_async): get(), get_raw() and reset() that follow
+    are ordered behind them, and freeing the images right after the call is safe."""
+    from semantic_meshes_amd.device import to_device
+    W, H, P, C = 320, 200, 3000, 19
+    rng = np.random.default_rng(12)
+    agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
+    oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
+    for k in range(6):
+        img = blob_image(rng, W, H, P, 2500)
+        probs = random_probs(rng, W, H, C)
+        d_img, d_probs = to_device(img), to_device(probs)
+        agg.add(d_img, d_probs)
+        del d_img, d_probs                                           # freed behind the library's stream
+        oagg.add(img, probs)
+        if k == 2:
+            assert_fused_close(agg.get(), oagg.get())
+            agg.reset()
+            oagg.reset()
+    assert_fused_close(agg.get(), oagg.get())
