@@ -44,7 +44,7 @@ for kind in ("sum", "summax", "mul"):
     kernel = _lib.lib().smesh_last_fuse_kernel().decode()
     assert kernel.startswith("k_fuse_tri"), kernel            # the HIP triangle-order path ran on this rank's shard
     got = agg.get()
-    # two partial float32 sums added once instead of eight terms in order: 1e-5 (Mul: log-domain partial sums rounded to float32)
+    # partial float32 sums added once instead of eight terms in order: 1e-5 (Mul: log-domain partial sums rounded to float32)
     assert_fused_close(got, want, rtol=2e-4 if kind == "mul" else 1e-5)
     np.testing.assert_allclose(agg.get_raw(), want_raw, rtol=1e-5, atol=1e-5)
     assert (want.sum(axis=1) > 0.5).sum() > P // 3
@@ -69,13 +69,15 @@ def _free_port():
     return port
 
 
-def test_two_ranks_on_one_gpu_hip_aggregators_equal_the_single_process_job(tmp_path, sm, oracle):
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_on_one_gpu_hip_aggregators_equal_the_single_process_job(tmp_path, sm, oracle, world):
+    """Two ranks, and cfg3's eight (one view per rank of the eight-view scene), sharing the test box's GPU."""
     script = os.path.join(tmp_path, "worker.py")
     open(script, "w").write(WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SMESH_ROOT=ROOT, SMESH_OUT=os.path.join(tmp_path, "rank%d.npz" % rank), OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
@@ -89,10 +91,10 @@ def test_two_ranks_on_one_gpu_hip_aggregators_equal_the_single_process_job(tmp_p
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-3000:])
         assert "rank %d ok" % rank in out
-    # both ranks hold the same result (an all-reduce), and it is the oracle's fusion of all eight views
+    # every rank holds the same result (an all-reduce), and it is the oracle's fusion of all eight views
     from helpers import small_scene, assert_fused_close
     from semantic_meshes_amd import synth
-    r0, r1 = np.load(os.path.join(tmp_path, "rank0.npz")), np.load(os.path.join(tmp_path, "rank1.npz"))
+    r0, r1 = np.load(os.path.join(tmp_path, "rank0.npz")), np.load(os.path.join(tmp_path, "rank%d.npz" % (world - 1)))
     mesh, cams = small_scene(60, 30, 320, 240, views=8)
     P, C = len(mesh.faces), 19
     oracle.set_accum_double(True)
