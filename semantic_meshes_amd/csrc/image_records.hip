@@ -525,10 +525,12 @@ void ImageRecords::release() {
   P = 0; clean = false;
 }
 
-// Moments (passes M, R, E, C') when the packed sums are exact: fewer than 2^24 pixels, sides of 16 .. 16383 pixels.
-static bool use_moments(uint64_t W, uint64_t H) {
+// Moments (passes M, R, E, C') when the packed sums are exact: fewer than 2^24 pixels, sides of 16 .. 16383 pixels -- and when pass R's
+// sweep over all P primitives (24 bytes each) is not what the call costs: up to eight primitives per pixel (cfg5: 2.3); beyond,
+// passes A / B and their per-pixel clear stay O(pixels).
+static bool use_moments(uint64_t W, uint64_t H, uint64_t P) {
   static const bool off = getenv("SMESH_REC_MOMENTS") && atoi(getenv("SMESH_REC_MOMENTS")) == 0;
-  return !off && W >= 16 && H >= 16 && W < 16384 && H < 16384 && W * H < (1ull << kMomCountBits);
+  return !off && W >= 16 && H >= 16 && W < 16384 && H < 16384 && W * H < (1ull << kMomCountBits) && P <= 8 * W * H;
 }
 
 int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, uint64_t P) {
@@ -552,7 +554,7 @@ int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, 
     r.clean = true;
   }
   const uint64_t N = W * H;
-  r.moments = use_moments(W, H);
+  r.moments = use_moments(W, H, P);
   if (r.moments) {
     // frags may hold the last image's records: pass R rewrites whatever differs
     r.clean = false;
