@@ -212,9 +212,13 @@ __global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restric
   const unsigned long long later = heads & ~upto;
   const int len = (later ? (__ffsll((long long)later) - 1) : kWave) - l;     // (head lanes: at most 16, a head starts every column)
   const unsigned long long run = (((1ull << (len & 31)) - 1ull) | (len >= 32 ? ~0ull : 0ull)) << l;   // this lane .. the end of its run
-  // ---- equal pixels in the column to the right, one row up / level / one row down (8-connectivity)
+  // ---- equal pixels in the column to the right, one row up / level / one row down (8-connectivity): the pixel level with this one by
+  // a wave shuffle, its neighbours above and below from the neighbouring lanes' copies (DPP row shifts: a column is one 16-lane row)
+  const uint32_t o_level = (uint32_t)__shfl((int)v, (l + kTY) & (kWave - 1));
+  const uint32_t o_below = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o_level, 0x101, 0xF, 0xF, true);   // row_shl:1 -- lane i reads lane i + 1
+  const uint32_t o_above = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o_level, 0x111, 0xF, 0xF, true);   // row_shr:1 -- lane i reads lane i - 1
   auto right_equal = [&](int d) -> bool {
-    const uint32_t o = (uint32_t)__shfl((int)v, (l + kTY + d) & (kWave - 1));
+    const uint32_t o = d == 0 ? o_level : (d > 0 ? o_below : o_above);
     return valid && cx < kSX - 1 && (unsigned)(ty + d) < (unsigned)kTY && o == v;
   };
   const unsigned long long B0 = __ballot(right_equal(0)), Bp = __ballot(right_equal(1)), Bm = __ballot(right_equal(-1));
@@ -234,12 +238,13 @@ __global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restric
   const bool hv = head && valid;
   const int child = (hv && rc != kNone && lp_of_rc == l) ? rc : kNone;
   const bool root = hv && !(lp != kNone && rc_of_lp == l);
-  // ---- fold the chain into its root: count | sum x | sum y (the moment word) and the strip-relative pixel mask (bit = lane)
+  // ---- fold the chain into its root: count | sum of columns | sum of rows, strip-relative in one 32-bit word (7 + 8 + 10 bits), and the
+  // strip-relative pixel mask (bit = lane)
   const uint32_t ulen = (uint32_t)len;
-  unsigned long long pk = 0ull, sm = 0ull;
+  uint32_t wm = 0u;
+  unsigned long long sm = 0ull;
   if (hv) {
-    pk = (unsigned long long)ulen | ((unsigned long long)(ulen * (x0 + (uint32_t)cx)) << kMomCountBits) |
-         ((unsigned long long)(ulen * (y0 + (uint32_t)ty) + ((ulen * (ulen - 1u)) >> 1)) << (kMomCountBits + kMomSumBits));
+    wm = ulen | (__umul24(ulen, (uint32_t)cx) << 7) | ((__umul24(ulen, (uint32_t)ty) + (__umul24(ulen, ulen - 1u) >> 1)) << 15);
     sm = run;
   }
   const bool has1 = child != kNone;
@@ -247,15 +252,22 @@ __global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restric
   const bool has2 = has1 && c2raw != kNone;
   if (__ballot(has1) != 0ull) {
     // hop 1: every head adds its child's run; hop 2: its grandchild's, which by then holds grandchild + great-grandchild
-    const unsigned long long opk = shfl64(pk, has1 ? child : l), osm = shfl64(sm, has1 ? child : l);
-    if (has1) { pk += opk; sm |= osm; }
+    const uint32_t owm = (uint32_t)__shfl((int)wm, has1 ? child : l);
+    const unsigned long long osm = shfl64(sm, has1 ? child : l);
+    if (has1) { wm += owm; sm |= osm; }
     if (__ballot(has2) != 0ull) {
-      const unsigned long long opk2 = shfl64(pk, has2 ? c2raw : l), osm2 = shfl64(sm, has2 ? c2raw : l);
-      if (has2) { pk += opk2; sm |= osm2; }
+      const uint32_t owm2 = (uint32_t)__shfl((int)wm, has2 ? c2raw : l);
+      const unsigned long long osm2 = shfl64(sm, has2 ? c2raw : l);
+      if (has2) { wm += owm2; sm |= osm2; }
     }
   }
   if (!root) return;
-  if (!(dbg & 4)) atomicAdd(&mom[v], pk);
+  {
+    const uint32_t n = wm & 127u, scx = (wm >> 7) & 255u, sty = wm >> 15;
+    const unsigned long long pk = (unsigned long long)n | ((unsigned long long)(__umul24(n, x0) + scx) << kMomCountBits) |
+                                  ((unsigned long long)(__umul24(n, y0) + sty) << (kMomCountBits + kMomSumBits));
+    if (!(dbg & 4)) atomicAdd(&mom[v], pk);
+  }
   uint32_t rows = (uint32_t)(sm | (sm >> 32));
   rows = (rows | (rows >> 16)) & 0xFFFFu;
   const int ymin = __builtin_ctz(rows), ymax = 31 - __builtin_clz(rows);

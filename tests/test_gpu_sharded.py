@@ -46,7 +46,7 @@ for kind in ("sum", "summax", "mul"):
     got = agg.get()
     # partial float32 sums added once instead of eight terms in order: 1e-5 (Mul: log-domain partial sums rounded to float32)
     assert_fused_close(got, want, rtol=2e-4 if kind == "mul" else 1e-5)
-    np.testing.assert_allclose(agg.get_raw(), want_raw, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(agg.get_raw(), want_raw, rtol=1e-5, atol=1e-4 if kind == "mul" else 1e-5)   # (Mul: log-domain rows of magnitude 10-20, up to eight float32 partial sums)
     assert (want.sum(axis=1) > 0.5).sum() > P // 3
     # opt-in exchange: this rank normalises its own slice of rows
     agg2 = sm.fusion.MeshAggregator(P, C, kind)
