@@ -25,6 +25,8 @@ for seed in range(first, first + count):
     kind = str(rng.choice(["sum", "summax", "mul"]))
     iew = float(rng.choice([0.0, 0.5, 1.0]))
     family = str(rng.choice(["blob", "blob_many", "noise", "vstripes", "hstripes", "checker", "one", "empty", "border", "diag"]))
+    if os.environ.get("SWEEP_LOG"):
+        open(os.environ["SWEEP_LOG"], "a").write("%d %s %dx%d P=%d C=%d %s\n" % (seed, family, W, H, P, C, kind))
     agg = sm.fusion.MeshAggregator(P, C, kind, iew)
     oracle.set_accum_double(True)
     oagg = oracle.OracleAggregator(P, C, kind, iew)
@@ -34,7 +36,9 @@ for seed in range(first, first + count):
         if family == "blob":
             img = blob_image(rng, W, H, P, max(1, min(P, int(rng.integers(1, 400)))))
         elif family == "blob_many":
-            img = blob_image(rng, W, H, P, int(rng.integers(P + 1, P + 400))); sparse = True
+            # (blob_image builds a W x H x seeds distance array on the HOST: 333 x 257 pixels x 200 000 seeds would be 137 GB -- seed 31591
+            # took a GPU box down that way; bounded to ~1 GB here)
+            img = blob_image(rng, W, H, P, min(int(rng.integers(P + 1, P + 400)), max(2, int(1.2e8 // (W * H))))); sparse = True
         elif family == "noise":
             img = rng.integers(0, P, (W, H)).astype(np.uint32); sparse = True
         elif family == "vstripes":
