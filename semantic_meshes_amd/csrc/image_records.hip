@@ -165,7 +165,7 @@ __global__ __launch_bounds__(kBlock) void k_rec_big(const uint32_t* __restrict__
 //                          the count is used) and STORES the group's own 8 x 8 record (plainly, tagged with the call's tag).
 //   pass R  k_rec_resolve  one lane per primitive: a stored record whose population count equals the primitive's total count IS the
 //                          primitive (a group that holds every pixel has no rival writer) -- 85 % of cfg2's primitives.  Otherwise
-//                          the lane scans the index image around the centroid (8 x 8, then 16 x 16 pixels): all `count` pixels found
+//                          the lane scans the index image around the centroid (4 x 4, 8 x 8, then 16 x 16 pixels): all `count` pixels found
 //                          -> the exact record (mask at the true origin, or a kind 2 box); else (more than 64 pixels, or pixels
 //                          further than 7 from the centroid) the primitive is queued as "pending", and
 //   passes E, C', D  k_rec_tail  (one launch, grid barriers; leaves at once when nothing is pending) E: per run of a pending primitive
@@ -184,7 +184,7 @@ __device__ __forceinline__ unsigned long long shfl64(unsigned long long x, int s
 }
 
 // Pass M.  The strip's runs, links and groups are those of strip.inc.hpp (build_strip: the histogram and scatter-add kernels), but
-// worked out in registers: equal neighbours across columns are three wave shuffles and ballots, a run's first match in the next
+// worked out in registers: equal neighbours across columns are one wave shuffle, two DPP row shifts and three ballots, a run's first match in the next
 // column is bit arithmetic on them, and the (at most four) runs of a chain are folded into its root by two pointer-doubling hops --
 // no LDS, no loops over rows.
 __global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t strips_y,
