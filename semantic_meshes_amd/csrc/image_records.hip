@@ -472,7 +472,7 @@ __global__ __launch_bounds__(kBlock) void k_rec_tail(const uint32_t* __restrict_
     atomicMax(&b[2], 65536u - x);        // 65536 - smallest x
     atomicMax(&b[3], 65536u - y);        // 65536 - smallest y
   }
-  // (the launch has at most two workgroups per CU: all resident, or waiting only for other kernels to end)
+  // (the launch has at most one workgroup per CU: all resident, or waiting only for other kernels to end)
   grid_barrier(&big_count[3], gridDim.x);
   for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < nbig; q += gridDim.x * kBlock) {
     const uint32_t v = big_queue[q];
@@ -596,7 +596,9 @@ int image_records_pending(DeviceCtx* ctx, ImageRecords& r, int kind, const uint3
                           uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st) {
   if (!r.moments) return SMESH_OK;
   const uint64_t N = W * H;
-  const dim3 grid((uint32_t)std::min<uint64_t>(div_up(N, kBlock), 2u * (uint32_t)std::max(1, ctx->num_cus))), block(kBlock);
+  // one workgroup per CU: the grid barriers need every workgroup resident at once, also when other processes share the GPU (each of
+  // them may be inside this launch); a barrier that is not met within seconds ends in a reported fault, not a hang
+  const dim3 grid((uint32_t)std::min<uint64_t>(div_up(N, kBlock), (uint32_t)std::max(1, ctx->num_cus))), block(kBlock);
   switch (kind) {
     case SMESH_AGG_SUM:
       hipLaunchKernelGGL(k_rec_tail<SMESH_AGG_SUM>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)H, (uint32_t)r.P, C, iew, r.frags, r.big4,
