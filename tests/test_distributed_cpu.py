@@ -1,4 +1,4 @@
-"""world_size-2 gloo test of the N > 1 path: view sharding + one sum all-reduce of the raw accumulator
+"""world_size-2 and -8 gloo tests of the N > 1 path: view sharding + one sum all-reduce of the raw accumulator
 equals fusing every view on one rank.  Runs on CPU; the per-rank compute is the oracle
 aggregator (test infrastructure) because the product has no CPU path."""
 import os
@@ -65,13 +65,18 @@ def _free_port():
     return port
 
 
-def test_two_ranks_gloo_equal_single_rank(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_ranks_gloo_equal_single_rank(tmp_path, world):
+    """Two ranks, and cfg3's eight: with five views, three of the eight ranks have no view of their own and still take part in the exchange."""
     script = os.path.join(tmp_path, "worker.py")
     open(script, "w").write(WORKER)
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    SMESH_ROOT=ROOT, OMP_NUM_THREADS="1")
         procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = []
