@@ -254,6 +254,11 @@ def main():
                     help="measure roofline.traffic in this run: two extra short passes of this script under rocprofv3 --pmc (about a minute)")
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("SMESH_BENCH_VIEWS_PER_CALL", "8")),
                     help="views handed to the library per call (fuse_views; 1 = one fuse_view call per view)")
+    ap.add_argument("--exchange-parts", type=int, default=int(os.environ.get("SMESH_BENCH_EXCHANGE_PARTS", "4")),
+                    help="N > 1: the rank's last --held-views views are fused by accumulator row range and the all-reduce of every finished "
+                         "range runs on the exchange stream beside the fusion of the next (1 = one all-reduce after the last view)")
+    ap.add_argument("--held-views", type=int, default=int(os.environ.get("SMESH_BENCH_HELD_VIEWS", "24")),
+                    help="N > 1: how many of the rank's last views are fused by row range (at most 32)")
     ap.add_argument("--group-pipeline", action="store_true",
                     help="SMESH_GROUP_PIPELINE=1: the rasteriser of group g+1 beside the fusion of group g (two streams, two banks of "
                          "view slots); more views/s, but the fusion kernel's own duration -- the roofline divisor -- stretches")
@@ -294,6 +299,9 @@ def main():
                 # device_id: the communicator is bound to this GPU and created now, not inside the timed region
                 dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
                 allreduce_impl = "torch.distributed nccl (RCCL), in place on the accumulator"
+            if dist.get_world_size() != world or dist.get_rank() != rank:
+                raise SystemExit("bench: the process group spans rank %d of %d, the launcher said rank %d of %d"
+                                 % (dist.get_rank(), dist.get_world_size(), rank, world))
 
     cfg = synth.CONFIGS[args.workload]
     W, H, C = cfg["width"], cfg["height"], cfg["classes"]
@@ -357,6 +365,34 @@ def main():
         elif dist is not None:
             smdist.allreduce_raw(agg)
 
+    # The exchange under the fusion (N > 1, all-reduce): the rank's last `held` views are fused by accumulator row range, and the
+    # all-reduce of every range that is final goes to the exchange stream while the next range is fused -- the same ONE sum of the
+    # same 4 P C bytes, in `parts` pieces, of which only the last is exposed.  (torch.distributed plumbing: the ranges are exchanged
+    # synchronously -- through host copies under gloo; the row arithmetic is the same, the overlap is not there.)
+    parts = max(1, min(64, args.exchange_parts))
+    held = max(0, min(32, args.held_views, args.steps))
+    ranged = launched and exchange == "allreduce" and parts > 1 and held > 0 and not texels
+    exchange_host_s = [0.0]
+
+    def exchange_rows(lo, hi):
+        t = time.perf_counter()
+        smdist.allreduce_rows_raw(agg, lo, hi, comm=comm)     # native: queued on the exchange stream, returns at once
+        exchange_host_s[0] += time.perf_counter() - t
+
+    def fuse_and_exchange(first, last):
+        """views [first, last) and the exchange; returns the row ranges that were exchanged one by one (None: one exchange at the end)"""
+        if not ranged:
+            fuse_range(first, last)
+            mark(1)
+            allreduce()
+            return None
+        cut = max(first, last - held)
+        fuse_range(first, cut)
+        ranges = agg.fuse_views_ranged(renderer, cams[cut:last], probs[cut:last], nparts=parts, on_rows=exchange_rows)
+        mark(1)                                                   # behind the last part's fusion kernels on the main stream
+        _lib.check(_lib.lib().smesh_exchange_join(agg._h))         # the main stream waits (on the device) for the exchange stream
+        return ranges
+
     def mark(i):
         _lib.check(_lib.lib().smesh_stream_mark(device, i))    # an event record on the library stream, no host wait
 
@@ -386,12 +422,18 @@ def main():
         agg.fuse_views(renderer, [cams[i] for i in prime], [probs[i] for i in prime])
         agg.fuse_view(renderer, cams[0], probs[0])     # a trailing odd view takes the one-view kernels: load them too
         _lib.synchronize(device)
-    fuse_range(0, args.warmup)
-    allreduce()    # untimed: RCCL builds its channels for this message size on first use
+    mark(0)
+    if ranged:
+        # untimed: the held views' record sets and index planes are allocated, RCCL builds its channels for the ranges' sizes
+        fuse_and_exchange(0, min(total_views, max(args.warmup, held)))
+    else:
+        fuse_range(0, args.warmup)
+        allreduce()    # untimed: RCCL builds its channels for this message size on first use
     barrier()
     agg.reset()
+    exchange_host_s[0] = 0.0
     _lib.check(_lib.lib().smesh_profile_reset(device))
-    prof_mask = 0xFF if os.environ.get("SMESH_BENCH_PROFILE_ALL") else (1 << _lib.PROF_FUSE_SCATTER)
+    prof_mask = 0xFF if os.environ.get("SMESH_BENCH_PROFILE_ALL") else ((1 << _lib.PROF_FUSE_SCATTER) | (1 << _lib.PROF_EXCHANGE))
     if os.environ.get("SMESH_BENCH_NO_PROFILE"):   # experiment: what do the HIP events around the kernel cost?
         prof_mask = 0
     # HIP events on the library's stream around every 8th launch of the dominant kernel when every view is its own call (an event
@@ -406,32 +448,40 @@ def main():
     _lib.synchronize(device)
     t0 = time.perf_counter()
     mark(0)
-    fuse_range(args.warmup, total_views)
-    mark(1)
-    allreduce()
+    ranges = fuse_and_exchange(args.warmup, total_views)     # (records mark 1 behind the last fusion kernel)
     mark(2)
     barrier()                      # the only host synchronisation of the timed region
     dt = time.perf_counter() - t0
     _lib.check(_lib.lib().smesh_profile_enable(device, 0))
-    # where this rank's device time went: marks 0 -> 1 = its views (render + fuse), 1 -> 2 = the exchange as this rank saw it
-    # (its own transfers AND the wait for the slowest rank to arrive).  Over all ranks: the max of each.
-    compute_ms, exchange_ms = elapsed(0, 1), elapsed(1, 2)
-    compute_ms_max, exchange_ms_max, exchange_ms_min = compute_ms, exchange_ms, exchange_ms
+    # where this rank's device time went on the MAIN stream: marks 0 -> 1 = its views (render + fuse), 1 -> 2 = the part of the
+    # exchange that nothing hid (its own transfers AND the wait for the slowest rank to arrive; with the exchange under the fusion:
+    # what was left of the collectives when the last range had been fused).  Over all ranks: the max of each.
+    compute_ms, exposed_ms = elapsed(0, 1), elapsed(1, 2)
+    # the collectives themselves (HIP events around them on the stream they run on): equals the exposed part when nothing overlaps
+    exchange_ms = prof_read(device, _lib.PROF_EXCHANGE)[0] if (comm is not None and prof_mask) else exposed_ms
+    if ranged and comm is None:
+        exchange_ms = 1e3 * exchange_host_s[0]                # (torch plumbing: host-timed, synchronous)
+    compute_ms_max, exposed_ms_max, exposed_ms_min, exchange_ms_max = compute_ms, exposed_ms, exposed_ms, exchange_ms
     if comm is not None:
-        dt, compute_ms_max, exchange_ms_max, neg_min = comm.reduce_scalars([dt, compute_ms, exchange_ms, -exchange_ms], "max")
-        exchange_ms_min = -neg_min
+        dt, compute_ms_max, exposed_ms_max, neg_min, exchange_ms_max = comm.reduce_scalars(
+            [dt, compute_ms, exposed_ms, -exposed_ms, exchange_ms], "max")
+        exposed_ms_min = -neg_min
     elif dist is not None:
         import torch
-        t = torch.tensor([dt, compute_ms, exchange_ms, -exchange_ms], dtype=torch.float64,
+        t = torch.tensor([dt, compute_ms, exposed_ms, -exposed_ms, exchange_ms], dtype=torch.float64,
                          device="cpu" if backend == "gloo" else "cuda:%d" % device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, compute_ms_max, exchange_ms_max, neg_min = (float(v) for v in t.tolist())
-        exchange_ms_min = -neg_min
+        dt, compute_ms_max, exposed_ms_max, neg_min, exchange_ms_max = (float(v) for v in t.tolist())
+        exposed_ms_min = -neg_min
 
     t1 = time.perf_counter()
     fused = agg.get() if exchange == "allreduce" else agg.get_rows(*owned)
     get_ms = 1e3 * (time.perf_counter() - t1)
     annotated = int((fused.sum(axis=1) > 0.9).sum())
+    if os.environ.get("SMESH_BENCH_DUMP") and rank == 0 and exchange == "allreduce":
+        # (tests: a sample of the fused rows, to be compared with a single-process fusion of the same views)
+        sample_rows = np.unique(np.linspace(0, max(P - 1, 0), 4096).astype(np.int64))
+        np.savez(os.environ["SMESH_BENCH_DUMP"], rows=sample_rows, fused=fused[sample_rows])
     del fused
     nranks_reported = world
     if comm is not None:
@@ -525,9 +575,15 @@ def main():
                        "allreduce": allreduce_impl, "exchange": exchange, "nranks": nranks_reported,
                        # the exchange moves the raw accumulator once: ring all-reduce 2 (N-1)/N x, reduce-scatter (N-1)/N x per link
                        "allreduce_bytes": int(4 * P * C) if launched else 0,
+                       # compute_ms + exchange_exposed_ms ~ timed_region_ms; exchange_ms = the collectives' own duration (under the fusion
+                       # when exchange_parts > 1: then exchange_ms > exchange_exposed_ms is the point)
                        "compute_ms": round(compute_ms_max, 3), "exchange_ms": round(exchange_ms_max, 3),
-                       "exchange_ms_fastest_rank": round(exchange_ms_min, 3),
-                       "rank0": {"compute_ms": round(compute_ms, 3), "exchange_ms": round(exchange_ms, 3)},
+                       "exchange_exposed_ms": round(exposed_ms_max, 3),
+                       "exchange_exposed_ms_fastest_rank": round(exposed_ms_min, 3),
+                       "exchange_parts": (len(ranges) if ranges else 1), "held_views": (held if ranges else 0),
+                       "exchange_row_ranges": ranges,
+                       "rank0": {"compute_ms": round(compute_ms, 3), "exchange_ms": round(exchange_ms, 3),
+                                 "exchange_exposed_ms": round(exposed_ms, 3)},
                        "timed_region_ms": round(1e3 * dt, 3),
                        "host_syncs_in_timed_region": 1 if (comm is not None or dist is None) else 4,
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},

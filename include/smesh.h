@@ -178,6 +178,11 @@ int smesh_aggregator_get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t r
  * New functionality: this is what is summed across GPUs before get(). */
 int smesh_aggregator_get_raw(smesh_aggregator_t* a, float* out, int memkind);
 int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind);
+/* Rows [row_lo, row_hi) of ONE PLANE of the raw state as dense float32[row_hi - row_lo, C]: plane 0 = the accumulator as stored (Mul:
+ * the hi plane, not folded), plane 1 = Mul's lo plane (a Mul element's value is hi + lo).  What a host-side exchange of a row range
+ * moves (semantic_meshes_amd/distributed.py: several ranks sharing one GPU exchange through gloo). */
+int smesh_aggregator_get_raw_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, int plane, float* out, int memkind);
+int smesh_aggregator_set_raw_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, int plane, const float* in, int memkind);
 /* In-place access for the RCCL all-reduce: the accumulator as it lives in device memory, P rows of
  * `row_stride` floats (row_stride >= C, padding is zero and stays zero under a sum), num_floats =
  * P * row_stride.  Oracle: host pointer, row_stride == C. */
@@ -205,9 +210,33 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
 /* Opt-in alternative to smesh_allreduce: ONE in-place ncclReduceScatter (half the bytes per xGMI link).  Afterwards rank r holds the
  * sum over all ranks in rows [*row_lo, *row_hi) of its accumulator: q = floor(P / nranks / 4) * 4 rows per rank (every slice starts
  * on a 16-byte boundary), the < 5 * nranks rows beyond nranks * q are all-reduced and counted into the last rank's range.  The other
- * rows keep the rank's own partial sums, so only smesh_aggregator_get_rows(a, *row_lo, *row_hi, ...) is meaningful afterwards: each
- * rank normalises (Fusion.h:79-104) its own slice.  Asynchronous like smesh_allreduce. */
+ * rows keep the rank's own partial sums, so only smesh_aggregator_get_rows inside [*row_lo, *row_hi) is meaningful afterwards: each
+ * rank normalises (Fusion.h:79-104) its own slice, and until smesh_aggregator_reset / _set_raw every other use of the accumulator
+ * (get, get_raw, add, fuse_view, a second exchange) returns SMESH_ERR_INVALID.  Asynchronous like smesh_allreduce. */
 int smesh_reduce_scatter(smesh_comm_t* c, smesh_aggregator_t* a, uint64_t* row_lo, uint64_t* row_hi);
+/* ---- sharded jobs: exchange under the fusion (new; no reference counterpart -- the reference is single-GPU) ------- */
+/* smesh_fuse_views cut by ACCUMULATOR ROW RANGE, so that the exchange of the rows that are already final runs beside the fusion of
+ * the rest (the one collective of the sharded path would otherwise be fully exposed at the end of a rank's views).
+ * smesh_fuse_views_begin rasterises all `n` views (n <= 32: their per-triangle records and index planes stay resident), then fuses
+ * part 0 of `nparts`: for ALL n views, in order, only the triangles whose rows lie in [*row_lo, *row_hi) -- whole 64-row blocks,
+ * part p = blocks [B p / nparts, B (p+1) / nparts) of the B = ceil(P / 64).  smesh_fuse_views_continue(part = 1, 2 ... nparts-1, in
+ * that order) fuses the next range and returns it.  When a call returns (asynchronously, like smesh_fuse_views) the rows it names hold
+ * everything the n views contribute to them: hand them to smesh_allreduce_rows and go on with the next part.  Per row the additions
+ * are those of smesh_fuse_views on the same views, in its order (primitives wider than 8 x 8 pixels of at most 16 x 16: float atomics,
+ * all with part 0).  Keep the DEVICE images valid until the last part has been queued.  Where rows are not in triangle order or the
+ * views cannot be held (texel renderers, re-ordered meshes, HOST images, n > 32, class counts beyond the triangle-order kernels)
+ * part 0 does the whole job -- rows [0, P) -- and the later parts are empty (*row_lo == *row_hi). */
+int smesh_fuse_views_begin(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cameras, uint64_t n,
+                           const float* const* probs, const float* const* weights, int memkind, int nparts,
+                           uint64_t* row_lo, uint64_t* row_hi);
+int smesh_fuse_views_continue(smesh_renderer_t* r, smesh_aggregator_t* a, int part, uint64_t* row_lo, uint64_t* row_hi);
+/* smesh_allreduce for the rows [row_lo, row_hi) only, on the library's EXCHANGE stream: starts when what is queued on the main stream
+ * so far has finished (an event, no host wait) and runs beside what the main stream is given next.  The main stream waits for it
+ * (device-side) at the next entry point that touches the accumulator -- get(), add(), reset(), smesh_allreduce ... -- or at
+ * smesh_exchange_join.  Every rank issues the same sequence of ranges.  Mul aggregators exchange their (hi, lo) float32 pairs as
+ * float64 (twice the bytes; a float32 sum of log-domain partial sums misses 1e-5 on get()), here and in smesh_allreduce. */
+int smesh_allreduce_rows(smesh_comm_t* c, smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi);
+int smesh_exchange_join(smesh_aggregator_t* a);
 /* Blocking reduction of `n` <= 64 host doubles over the communicator (op 0 = sum, 2 = max): a harness's barrier and its
  * max-over-ranks clock without a second communication library. */
 int smesh_comm_allreduce_f64(smesh_comm_t* c, double* values, int n, int op);

@@ -174,6 +174,7 @@ class OracleAggregator:
     def __init__(self, primitives, classes, aggregator="sum", images_equal_weight=0.5):
         self.P, self.C = int(primitives), int(classes)
         self.primitives, self.classes = self.P, self.C     # (the product aggregator's attribute names)
+        self.kind = aggregator[:1].upper() + aggregator[1:].lower()
         self._h = ctypes.c_void_p()
         _check(lib().smesh_aggregator_create(ctypes.c_uint64(self.P), ctypes.c_uint32(self.C), AGG_KINDS[aggregator.lower()],
                                              ctypes.c_float(images_equal_weight), 0, ctypes.byref(self._h)))
@@ -232,6 +233,18 @@ class OracleAggregator:
         if raw.shape != (self.P, self.C):
             raise ValueError("shape mismatch")
         _check(lib().smesh_aggregator_set_raw(self._h, raw.ctypes.data_as(ctypes.c_void_p), 0))
+
+
+    def get_raw_rows(self, row_lo, row_hi, plane=0):
+        out = np.empty((int(row_hi) - int(row_lo), self.C), np.float32)
+        _check(lib().smesh_aggregator_get_raw_rows(self._h, ctypes.c_uint64(int(row_lo)), ctypes.c_uint64(int(row_hi)), int(plane),
+                                                   out.ctypes.data_as(ctypes.c_void_p), 0))
+        return out
+
+    def set_raw_rows(self, row_lo, raw, plane=0):
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        _check(lib().smesh_aggregator_set_raw_rows(self._h, ctypes.c_uint64(int(row_lo)), ctypes.c_uint64(int(row_lo) + raw.shape[0]), int(plane),
+                                                   raw.ctypes.data_as(ctypes.c_void_p), 0))
 
 
 def render_annotations(aggregator, idx, background):

@@ -826,6 +826,42 @@ int smesh_comm_rank(const smesh_comm_t*, int*, int*) { return fail(SMESH_ERR_NOD
 int smesh_allreduce(smesh_comm_t* const*, smesh_aggregator_t* const*, int) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
 int smesh_reduce_scatter(smesh_comm_t*, smesh_aggregator_t*, uint64_t*, uint64_t*) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
 int smesh_comm_allreduce_f64(smesh_comm_t*, double*, int, int) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
+int smesh_allreduce_rows(smesh_comm_t*, smesh_aggregator_t*, uint64_t, uint64_t) { return fail(SMESH_ERR_NODEVICE, "oracle has no communicator"); }
+int smesh_exchange_join(smesh_aggregator_t*) { return SMESH_OK; }
+// fusion by row range: the oracle fuses everything with part 0 (rows [0, P)); the later parts are empty
+int smesh_fuse_views_begin(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cams, uint64_t n, const float* const* probs,
+                           const float* const* weights, int memkind, int nparts, uint64_t* row_lo, uint64_t* row_hi) {
+  if (!a || !row_lo || !row_hi || nparts < 1) return fail(SMESH_ERR_INVALID, "bad argument");
+  const int st = smesh_fuse_views(r, a, cams, n, probs, weights, memkind);
+  *row_lo = 0; *row_hi = a->P;
+  return st;
+}
+int smesh_fuse_views_continue(smesh_renderer_t*, smesh_aggregator_t* a, int, uint64_t* row_lo, uint64_t* row_hi) {
+  if (!a || !row_lo || !row_hi) return fail(SMESH_ERR_INVALID, "bad argument");
+  *row_lo = *row_hi = a->P;
+  return SMESH_OK;
+}
+// plane 0: the state rounded to float32 (the product's hi plane); plane 1 (Mul, float64 yardstick only): what the rounding left, so
+// that hi + lo carries the state across a host-side exchange as the product's (hi, lo) pairs do (set: plane 0 first, then plane 1)
+int smesh_aggregator_get_raw_rows(smesh_aggregator_t* a, uint64_t lo, uint64_t hi, int plane, float* out, int memkind) {
+  if (!a || !out || memkind != SMESH_MEM_HOST || lo > hi || hi > a->P || plane < 0 || plane > 1) return fail(SMESH_ERR_INVALID, "bad argument");
+  if (plane == 1 && a->kind != SMESH_AGG_MUL) return fail(SMESH_ERR_INVALID, "plane 1 is the Mul aggregator's");
+  for (uint64_t i = lo * a->C; i < hi * a->C; i++) {
+    const float h = g_accum_double ? (float)a->accd[i] : a->acc[i];
+    out[i - lo * a->C] = plane == 0 ? h : ((g_accum_double && std::isfinite(h)) ? (float)(a->accd[i] - (double)h) : 0.0f);
+  }
+  return SMESH_OK;
+}
+int smesh_aggregator_set_raw_rows(smesh_aggregator_t* a, uint64_t lo, uint64_t hi, int plane, const float* in, int memkind) {
+  if (!a || !in || memkind != SMESH_MEM_HOST || lo > hi || hi > a->P || plane < 0 || plane > 1) return fail(SMESH_ERR_INVALID, "bad argument");
+  if (plane == 1 && a->kind != SMESH_AGG_MUL) return fail(SMESH_ERR_INVALID, "plane 1 is the Mul aggregator's");
+  for (uint64_t i = lo * a->C; i < hi * a->C; i++) {
+    const float v = in[i - lo * a->C];
+    if (plane == 0) { if (g_accum_double) a->accd[i] = v; else a->acc[i] = v; }
+    else if (g_accum_double) a->accd[i] += (double)v;
+  }
+  return SMESH_OK;
+}
 int smesh_profile_enable(int, int) { return SMESH_OK; }
 int smesh_profile_sample_every(int, uint32_t) { return SMESH_OK; }
 int smesh_profile_read(int, int, double* ms, uint64_t* n) { if (ms) *ms = 0; if (n) *n = 0; return SMESH_OK; }

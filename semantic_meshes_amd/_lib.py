@@ -76,6 +76,12 @@ SIGNATURES = {
     "smesh_comm_rank": (c_int, [c_void_p, P(c_int), P(c_int)]),
     "smesh_allreduce": (c_int, [P(c_void_p), P(c_void_p), c_int]),
     "smesh_reduce_scatter": (c_int, [c_void_p, c_void_p, P(c_u64), P(c_u64)]),
+    "smesh_fuse_views_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_u64, P(c_void_p), P(c_void_p), c_int, c_int, P(c_u64), P(c_u64)]),
+    "smesh_fuse_views_continue": (c_int, [c_void_p, c_void_p, c_int, P(c_u64), P(c_u64)]),
+    "smesh_allreduce_rows": (c_int, [c_void_p, c_void_p, c_u64, c_u64]),
+    "smesh_exchange_join": (c_int, [c_void_p]),
+    "smesh_aggregator_get_raw_rows": (c_int, [c_void_p, c_u64, c_u64, c_int, c_void_p, c_int]),
+    "smesh_aggregator_set_raw_rows": (c_int, [c_void_p, c_u64, c_u64, c_int, c_void_p, c_int]),
     "smesh_comm_allreduce_f64": (c_int, [c_void_p, P(ctypes.c_double), c_int, c_int]),
     "smesh_aggregator_renderer": (c_int, [c_void_p, P(c_void_p)]),
     "smesh_annotation_renderer_render": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int, c_void_p, c_void_p, c_int, c_u64, c_u64]),

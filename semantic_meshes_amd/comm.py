@@ -129,7 +129,11 @@ class Communicator:
         port = int(os.environ.get("SMESH_COMM_PORT", int(os.environ.get("MASTER_PORT", "29500")) + port_offset))
         uid = cls.unique_id() if rank == 0 else None
         uid = exchange_id(uid, rank, world, addr, port)
-        return cls(device, rank, world, uid)
+        c = cls(device, rank, world, uid)
+        got = c.nranks()
+        if got != (rank, world):
+            raise RuntimeError("RCCL communicator spans rank %d of %d, the launcher said rank %d of %d" % (got + (rank, world)))
+        return c
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -146,6 +150,13 @@ class Communicator:
         _lib.check(_lib.lib().smesh_allreduce(comms, aggs, 1))
         return aggregator
 
+    def allreduce_rows(self, aggregator, row_lo, row_hi):
+        """`allreduce` for the rows [row_lo, row_hi) only, on the library's exchange stream: it starts when what is queued on the main
+        stream so far has finished and runs beside whatever the main stream is given next (`MeshAggregator.fuse_views_ranged` calls it
+        through `on_rows`).  The main stream picks the result up at the aggregator's next use (`get()` ...)."""
+        _lib.check(_lib.lib().smesh_allreduce_rows(self._h, aggregator._h, int(row_lo), int(row_hi)))
+        return aggregator
+
     def reduce_scatter(self, aggregator):
         """Opt-in alternative to `allreduce` (`smesh_reduce_scatter`: one in-place ncclReduceScatter, half the bytes per link).
         Returns `(row_lo, row_hi)`: the rows of THIS rank's accumulator that now hold the sum over all ranks -- fetch them
@@ -153,6 +164,12 @@ class Communicator:
         lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
         _lib.check(_lib.lib().smesh_reduce_scatter(self._h, aggregator._h, ctypes.byref(lo), ctypes.byref(hi)))
         return int(lo.value), int(hi.value)
+
+    def nranks(self):
+        """(rank, number of ranks) as the RCCL communicator itself reports them."""
+        rk, nr = ctypes.c_int(), ctypes.c_int()
+        _lib.check(_lib.lib().smesh_comm_rank(self._h, ctypes.byref(rk), ctypes.byref(nr)))
+        return int(rk.value), int(nr.value)
 
     def reduce_scalars(self, values, op="sum"):
         """Blocking reduction of a few host floats over all ranks (`op` sum | max)."""

@@ -35,6 +35,14 @@ struct smesh_aggregator;
 DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a);
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a);
 int smesh_aggregator_acc(smesh_aggregator* a, float** acc, uint64_t* num_floats, uint32_t* row_stride, uint64_t* rows);
+uint64_t smesh_aggregator_primitives(smesh_aggregator* a);
+int smesh_aggregator_join_exchange(smesh_aggregator* a);
+int smesh_aggregator_refuse_scattered(smesh_aggregator* a, const char* what);
+void smesh_aggregator_mark_scattered(smesh_aggregator* a, uint64_t lo, uint64_t hi);
+int smesh_aggregator_exchange_begin(smesh_aggregator* a, uint64_t lo, uint64_t hi, hipStream_t st, void** buf, uint64_t* count, int* is_f64);
+int smesh_aggregator_exchange_end(smesh_aggregator* a, uint64_t lo, uint64_t hi, hipStream_t st);
+int smesh_aggregator_exchange_events(smesh_aggregator* a, hipEvent_t* ev_part, hipEvent_t* ev_xchg);
+void smesh_aggregator_exchange_pending(smesh_aggregator* a);
 
 namespace {
 
@@ -198,14 +206,20 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     if (hipSetDevice(ctx->device) != hipSuccess) { status = fail(SMESH_ERR_RUNTIME, "hipSetDevice failed"); break; }
     uint64_t count = 0;
-    float* acc = nullptr;
+    void* buf = nullptr;
+    int f64 = 0;
     // a failure here must surface: a rank that skipped the collective would leave its peers blocked inside theirs.  An EMPTY
     // accumulator (P == 0) is empty on every rank (same num_primitives is a precondition), so skipping it is collective-safe.
-    status = smesh_aggregator_acc(aggs[i], &acc, &count, nullptr, nullptr);
+    // Mul: the (hi, lo) pairs travel as float64 (smesh_aggregator_exchange_begin), twice the bytes, exact to 1e-16.
+    status = smesh_aggregator_refuse_scattered(aggs[i], "allreduce");
+    if (status == SMESH_OK) status = smesh_aggregator_join_exchange(aggs[i]);
+    const uint64_t P = smesh_aggregator_primitives(aggs[i]);
+    if (status == SMESH_OK) status = smesh_aggregator_exchange_begin(aggs[i], 0, P, ctx->stream, &buf, &count, &f64);
     if (status != SMESH_OK || count == 0) continue;
     ProfScope prof(ctx, SMESH_PROF_EXCHANGE);
-    const ncclResult_t e = r->AllReduce(acc, acc, (size_t)count, ncclFloat32, ncclSum, comms[i]->comm, ctx->stream);
+    const ncclResult_t e = r->AllReduce(buf, buf, (size_t)count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, comms[i]->comm, ctx->stream);
     if (e != ncclSuccess) status = fail_rccl(r, e, "ncclAllReduce");
+    else status = smesh_aggregator_exchange_end(aggs[i], 0, P, ctx->stream);
   }
   if (n > 1) {
     const ncclResult_t e = r->GroupEnd();
@@ -240,7 +254,55 @@ int smesh_reduce_scatter(smesh_comm_t* c, smesh_aggregator_t* a, uint64_t* row_l
   if (q) SMESH_RCCL(r, r->ReduceScatter(acc, acc + *row_lo * S, (size_t)(q * S), ncclFloat32, ncclSum, c->comm, ctx->stream));
   const uint64_t tail = q * (uint64_t)c->nranks;
   if (tail < P) SMESH_RCCL(r, r->AllReduce(acc + tail * S, acc + tail * S, (size_t)((P - tail) * S), ncclFloat32, ncclSum, c->comm, ctx->stream));
+  if (c->nranks > 1) smesh_aggregator_mark_scattered(a, *row_lo, *row_hi);   // the other rows hold partial sums: get() / add() / a second exchange are refused until reset()
   return SMESH_OK;
+}
+
+// smesh_allreduce for the rows [row_lo, row_hi) only, on the EXCHANGE stream: it starts when everything queued so far on the main
+// stream has finished (an event, no host wait) and runs beside whatever the main stream is given next -- the fusion of the next
+// triangle range (smesh_fuse_views_continue), which does not touch these rows.  The main stream picks the result up at the next
+// entry point that uses the accumulator (smesh_aggregator_join_exchange: a device-side wait).  Collectives of successive calls run
+// in call order; every rank must issue the same sequence of ranges.
+int smesh_allreduce_rows(smesh_comm_t* c, smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi) {
+  if (!c || !a) return fail(SMESH_ERR_INVALID, "NULL communicator / aggregator");
+  if (smesh_aggregator_ctx(a) != c->ctx) return fail(SMESH_ERR_INVALID, "aggregator and communicator live on different devices");
+  Rccl* r;
+  SMESH_TRY(need_rccl(&r));
+  std::lock_guard<std::mutex> g(smesh_aggregator_mutex(a));
+  DeviceCtx* ctx = c->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_refuse_scattered(a, "allreduce_rows"));
+  if (row_lo > row_hi || row_hi > smesh_aggregator_primitives(a)) return fail(SMESH_ERR_INVALID, "bad row range");
+  if (row_lo == row_hi) return SMESH_OK;   // (empty on every rank: the ranges are a function of P and the part alone)
+  hipEvent_t ev_part, ev_xchg;
+  SMESH_TRY(smesh_aggregator_exchange_events(a, &ev_part, &ev_xchg));
+  hipStream_t xs = ctx->exchange_stream;
+  SMESH_HIP(hipEventRecord(ev_part, ctx->stream));
+  SMESH_HIP(hipStreamWaitEvent(xs, ev_part, 0));
+  void* buf = nullptr;
+  uint64_t count = 0;
+  int f64 = 0;
+  SMESH_TRY(smesh_aggregator_exchange_begin(a, row_lo, row_hi, xs, &buf, &count, &f64));
+  {
+    ProfScope prof(ctx, SMESH_PROF_EXCHANGE, xs);
+    SMESH_RCCL(r, r->AllReduce(buf, buf, (size_t)count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, c->comm, xs));
+  }
+  SMESH_TRY(smesh_aggregator_exchange_end(a, row_lo, row_hi, xs));
+  SMESH_HIP(hipEventRecord(ev_xchg, xs));
+  smesh_aggregator_exchange_pending(a);
+  return SMESH_OK;
+}
+
+// The main stream of the aggregator's device waits (device-side) for the row exchanges queued so far.  Every entry point that
+// touches the accumulator does this itself; a harness calls it to place a time stamp behind the exchange (smesh_stream_mark).
+int smesh_exchange_join(smesh_aggregator_t* a) {
+  if (!a) return fail(SMESH_ERR_INVALID, "NULL aggregator");
+  std::lock_guard<std::mutex> g(smesh_aggregator_mutex(a));
+  DeviceCtx* ctx = smesh_aggregator_ctx(a);
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  return smesh_aggregator_join_exchange(a);
 }
 
 // Small reduction of host values over the same communicator (op: 0 = sum, 2 = max), blocking: what a benchmark harness needs

@@ -45,6 +45,7 @@ struct DeviceCtx {
   int device = -1;
   hipStream_t stream = nullptr;         // main stream: fusion kernels, copies, everything by default
   hipStream_t raster_stream = nullptr;  // smesh_fuse_view rasterises view k+1 here while view k is being fused
+  hipStream_t exchange_stream = nullptr;   // smesh_allreduce_rows: the collective of a finished row range runs here, beside the fusion of the next
   hipEvent_t ev_order = nullptr;        // smesh_stream_wait: marks the producer's stream
   hipEvent_t ev_release = nullptr;      // smesh_stream_release: marks the library's stream
   int num_cus = 256;
@@ -121,6 +122,11 @@ struct TriFuseArgs {
   double* acc_d;              // Mul + texel primitives: [P][C] sums of ONE view's terms, all zero between launches (big triangles only)
   int mid;                    // k_fuse_tri: nonzero = k_fuse_mid takes the queued triangles with at most kMidBox pixels per view (the tail waves skip them)
   uint32_t ps0, ps1;          // k_fuse_tri / fuse_box only: element strides of x and y of the class-vector image (dense: H * C and C); the class stride is 1
+  // Fusion by triangle RANGE (smesh_fuse_views_begin / _continue: the rows of a finished range are exchanged between GPUs while the
+  // next range is fused).  Main block b of the launch takes the triangles of block blk_first + b; the waves that walk the queues of
+  // big triangles take only triangles at positions [f_lo, f_hi).  A launch over everything: blk_first = 0, f_lo = 0, f_hi = F.
+  uint32_t blk_first;
+  uint32_t f_lo, f_hi;
 };
 
 // What k_fuse_tri needs to know about ONE of the views it fuses in a launch (the per-view part of TriFuseArgs), and NV of them.
@@ -173,10 +179,9 @@ struct ImageRecords {
   void release();
 };
 int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, uint64_t P);
-int image_records_pending(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
-                          uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st);
+int image_records_pending(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, hipStream_t st);
 int image_records_scatter_sparse(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
-                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st);
+                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, float* acc_lo, double* acc_d, hipStream_t st);
 int image_records_clear(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, hipStream_t st);
 
 }  // namespace smesh

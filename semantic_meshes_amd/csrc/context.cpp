@@ -47,6 +47,16 @@ int get_ctx(int device, DeviceCtx** out) {
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     SMESH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     SMESH_HIP(hipStreamCreateWithFlags(&ctx->raster_stream, hipStreamNonBlocking));
+    {
+      // the exchange stream gets the greatest priority there is: a collective's few workgroups must not queue behind the tens of
+      // thousands of one-wave workgroups of the fusion launch it runs beside
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
+      if (hipStreamCreateWithPriority(&ctx->exchange_stream, hipStreamNonBlocking, greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        SMESH_HIP(hipStreamCreateWithFlags(&ctx->exchange_stream, hipStreamNonBlocking));
+      }
+    }
     g_ctx[device] = std::move(ctx);
   }
   *out = g_ctx[device].get();
@@ -58,7 +68,8 @@ ProfScope::ProfScope(DeviceCtx* c, int s, hipStream_t stream) : ctx(c), slot(s),
   ProfSlot& ps = ctx->slots[slot];
   if (ps.depth++ > 0) { counted = true; return; }   // inside an open region of this slot
   counted = true;
-  if (ps.seen++ % std::max(1u, ctx->profile_every) != 0) return;
+  // (sampling applies to the per-view slots; get() and the exchange are rare and always bracketed)
+  if (ps.seen++ % (slot <= SMESH_PROF_RASTER ? std::max(1u, ctx->profile_every) : 1u) != 0) return;
   if (!ps.pool.empty()) {
     start = ps.pool.back().first;
     stop = ps.pool.back().second;
@@ -130,6 +141,7 @@ int smesh_synchronize(int device) {
   SMESH_HIP(hipSetDevice(device));
   SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  SMESH_HIP(hipStreamSynchronize(ctx->exchange_stream));
   return SMESH_OK;
 }
 
@@ -230,6 +242,7 @@ static int drain(DeviceCtx* ctx) {
   SMESH_HIP(hipSetDevice(ctx->device));
   SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  SMESH_HIP(hipStreamSynchronize(ctx->exchange_stream));
   for (auto& ps : ctx->slots) {
     for (auto& ev : ps.pending) {
       float ms = 0.f;

@@ -393,7 +393,7 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const T
             else mine = counts;
           }
         }
-        take = mine && !earlier;
+        take = mine && !earlier && fi >= a.f_lo && fi < a.f_hi;   // (f_lo, f_hi: fusion by triangle range; 0, F otherwise)
       }
     }
     unsigned long long todo = __ballot(take);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> 
     fuse_big_triangles<CT, KIND, EXACT, NV>(a, vw, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, lds_list);
     return;
   }
-  const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
+  const uint64_t f0 = ((uint64_t)a.blk_first + blockIdx.x) * kWave;   // (blk_first: fusion by triangle range; 0 otherwise)
   const uint64_t f = f0 + l;
   // per view: box origin (x0 | y0 << 16) and the mask of this triangle's VISIBLE pixels inside its <= 8 x 8 box
   uint32_t org[NV];

@@ -835,7 +835,7 @@ __device__ __forceinline__ void fuse_big_triangles_any(const TriFuseArgs& a, con
         if (!located) {
           if (qq < len[j]) {
             fi = vw.v[j].big_queue[qq];
-            take = vw.v[j].frags[fi].kind == 2;
+            take = vw.v[j].frags[fi].kind == 2 && fi >= a.f_lo && fi < a.f_hi;   // (f_lo, f_hi: fusion by triangle range)
 #pragma unroll
             for (int i = 0; i < 8; i++) if (i < j && vw.v[i].frags[fi].kind == 2) take = false;   // an earlier view's queue has it
             located = true;
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, TriViews<
   const int l = threadIdx.x;
   const uint32_t C = a.C;
   const int g = l % G;                                   // rank inside the group
-  const uint64_t fi = (uint64_t)blockIdx.x * TPW + (uint32_t)(l / G);   // position in the renderer's triangle order
+  const uint64_t fi = ((uint64_t)a.blk_first + blockIdx.x) * TPW + (uint32_t)(l / G);   // position in the renderer's triangle order (blk_first: fusion by range)
   const uint64_t f = (a.prim_id && fi < a.F) ? (uint64_t)a.prim_id[fi] : fi;   // primitive id (index image value, accumulator row)
   const uint32_t SL = G == 1 ? C : (((C + G - 1) / G + 3u) & ~3u);   // classes per lane (whole float4s when the row is split)
   const uint32_t c_lo = (uint32_t)g * SL;
@@ -1149,7 +1149,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
   __shared__ ViewState S;
   const int l = threadIdx.x;
   const uint32_t C = a.C;
-  const uint64_t f0 = (uint64_t)blockIdx.x * kWave;
+  const uint64_t f0 = ((uint64_t)a.blk_first + blockIdx.x) * kWave;   // (blk_first: fusion by triangle range; 0 otherwise)
   const uint64_t f = f0 + l;
   const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // primitive id (index image value, accumulator row)
   unsigned long long win[8];
@@ -1666,6 +1666,39 @@ __global__ void k_scatter_flat(ScatterArgs a, const float* __restrict__ wpix, co
   unsafeAtomicAdd(&a.acc[(uint64_t)a.idx[i] * a.S + c], contribution<KIND>(a.probs[e], w));
 }
 
+// Mul on the generic path: one float64 atomic per (pixel, class) into the aggregator's scratch rows (all zero between calls), then
+// every row that received terms folds them into its (hi, lo) pair (k_fold_rows) -- "Mul state", fuse_tri.inc.hpp.  Float32 atomics on
+// the hi plane (rounds 1-3) missed 1e-5 on get() by two orders of magnitude; this path is what is left when the image records do
+// not apply (padded rows, SMESH_ADD_RECORDS=0, SMESH_FUSE=strip), so it is sized for exactness, not speed.
+__global__ void k_scatter_flat_mul(ScatterArgs a, const float* __restrict__ wpix, double* __restrict__ acc_d) {
+  const uint64_t e = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.N * a.C) return;
+  const uint64_t i = e / a.C;
+  const uint32_t c = (uint32_t)(e - i * a.C);
+  const float w = wpix[i];
+  if (w == 0.0f) return;
+  unsafeAtomicAdd(&acc_d[(uint64_t)a.idx[i] * a.C + c], (double)contribution<SMESH_AGG_MUL>(a.probs[e], w));
+}
+__global__ void k_fold_rows(float* __restrict__ acc, float* __restrict__ acc_lo, double* __restrict__ acc_d, const uint32_t* __restrict__ count,
+                            uint64_t P, uint32_t C, uint32_t S) {
+  const uint64_t v = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= P || (count && count[v] == 0u)) return;     // (count: this view's histogram, when there is one)
+  double* drow = acc_d + v * C;
+  bool any = false;
+  for (uint32_t c = 0; c < C; c++) any = any || drow[c] != 0.0;
+  if (!any) return;
+  float* hi = acc + v * S;
+  float* lo = acc_lo + v * S;
+  float m = -INFINITY;
+  for (uint32_t c = 0; c < C; c++) { const float h = hi[c]; if (h > m && h < INFINITY) m = h; }
+  const float centre = m > -INFINITY ? m : 0.0f;
+  for (uint32_t c = 0; c < C; c++) {
+    float h = hi[c], r = lo[c];
+    mul_fold(h, r, centre, drow[c]);
+    hi[c] = h; lo[c] = r; drow[c] = 0.0;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // get(): load -> [Mul: / max element] -> L1 normalise -> NaN/Inf -> 0   (Fusion.h:79-104)
 // Reads padded rows [P][S], writes dense [P][C].
@@ -1905,13 +1938,27 @@ struct smesh_aggregator {
   hipEvent_t ev_staged = nullptr;        // host inputs have been copied into the staging buffers
   Scratch out_tmp;                       // get(): normalised result before the D2H copy
   ImageRecords rec;                      // add() on an image the library did not render: per-primitive records (image_records.hip)
+  // Exchange of row ranges beside the fusion (smesh_allreduce_rows, comm.cpp): ev_part marks the main stream where the range became
+  // final, ev_xchg the exchange stream behind the range's collective; xchg_pending: the main stream has not yet waited for ev_xchg.
+  hipEvent_t ev_part = nullptr, ev_xchg = nullptr;
+  bool xchg_pending = false;
+  Scratch xchg_stage;                    // Mul: float64 image of the rows being exchanged ((hi, lo) pairs summed exactly)
+  // After smesh_reduce_scatter only rows [owned_lo, owned_hi) hold the sum over the ranks: everything but get_rows inside that
+  // range and reset() is refused until reset() (scattered == true).
+  bool scattered = false;
+  uint64_t owned_lo = 0, owned_hi = 0;
   std::mutex mu;
 };
+
+int smesh_aggregator_join_exchange(smesh_aggregator* a);
+int smesh_aggregator_refuse_scattered(smesh_aggregator* a, const char* what);
+static int ensure_acc_d(smesh_aggregator* a);
 
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
-                                    const RenderedView* views, int nviews);
+                                    const RenderedView* views, int nviews, int part = 0, int nparts = 1);
+void smesh_fuse_part_rows(uint64_t F, int part, int nparts, uint64_t* f_lo, uint64_t* f_hi);
 void smesh_note_fuse(const char* kernel, const char* path);   // raster.hip: what smesh_last_fuse_kernel / smesh_last_add_path report
 
 namespace {
@@ -2000,15 +2047,16 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
       ProfScope prof(ctx, SMESH_PROF_FUSE_HIST);
       SMESH_TRY(image_records_build(ctx, rec, idx, W, H, a->P));
     }
-    SMESH_TRY(image_records_pending(ctx, rec, a->kind, idx, probs, weights, W, H, C, a->iew, a->acc, st));
+    SMESH_TRY(image_records_pending(ctx, rec, idx, W, H, st));
     const RenderedView rv{rec.frags, rec.big_queue, rec.big_count, idx, probs, weights, W, H};
     SMESH_TRY(smesh_aggregator_fuse_triangles(a, a->P, nullptr, (uint32_t)a->P, &rv, 1));
-    SMESH_TRY(image_records_scatter_sparse(ctx, rec, a->kind, idx, probs, weights, W, H, C, a->iew, a->acc, st));
+    if (a->kind == SMESH_AGG_MUL) SMESH_TRY(ensure_acc_d(a));   // (float64 scratch rows of the sparse primitives' terms; all zero between calls)
+    SMESH_TRY(image_records_scatter_sparse(ctx, rec, a->kind, idx, probs, weights, W, H, C, a->iew, a->acc, a->acc_lo, a->acc_d, st));
     SMESH_TRY(image_records_clear(ctx, rec, idx, W, H, st));
     smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, false), "image-records");
     return SMESH_OK;
   }
-  smesh_note_fuse(strip_path(C) ? "k_scatter_strip" : "k_scatter_flat", "scatter");
+  smesh_note_fuse(strip_path(C) && a->kind != SMESH_AGG_MUL ? "k_scatter_strip" : "k_scatter_flat", "scatter");
 
   ScatterArgs args;
   args.idx = idx; args.probs = probs; args.weights = weights; args.pw = nullptr;
@@ -2027,7 +2075,8 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
 
   // ---- F2 scatter-add -------------------------------------------------------------------------
   SMESH_TRY(mul_recentre(a));
-  if (strip_path(C)) {
+  const bool mul = a->kind == SMESH_AGG_MUL;      // Mul: float64 atomics + one fold per touched row (k_scatter_flat_mul)
+  if (strip_path(C) && !mul) {
     args.pw = nullptr;
     if (need_hist || weights) {
       SMESH_TRY(a->pw.reserve(N * 4));
@@ -2061,8 +2110,10 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
         hipLaunchKernelGGL(k_scatter_flat<SMESH_AGG_SUMMAX>, g2, b, 0, st, args, wpix, amax);
         break;
       default:
+        SMESH_TRY(ensure_acc_d(a));
         hipLaunchKernelGGL(k_pixel_weight<SMESH_AGG_MUL>, g1, b, 0, st, args, wpix, amax);
-        hipLaunchKernelGGL(k_scatter_flat<SMESH_AGG_MUL>, g2, b, 0, st, args, wpix, amax);
+        hipLaunchKernelGGL(k_scatter_flat_mul, g2, b, 0, st, args, wpix, a->acc_d);
+        hipLaunchKernelGGL(k_fold_rows, dim3((uint32_t)div_up(a->P, 256)), b, 0, st, a->acc, a->acc_lo, a->acc_d, args.count, a->P, C, a->S);
         break;
     }
     SMESH_HIP(hipGetLastError());
@@ -2168,12 +2219,29 @@ bool smesh_aggregator_takes_strided_probs(smesh_aggregator* a, int64_t ps0, int6
   return a->C <= kFuseTriMaxC && !(a->C > 40u && nviews > 2);
 }
 
-// `nviews` = 1, or 2 (smesh_aggregator_can_fuse_pair): views[0] then views[1] of the same renderer in one launch.
+// Fusion by triangle range (smesh_fuse_views_begin / _continue): part `part` of `nparts` covers the triangles at positions
+// [*f_lo, *f_hi) of the renderer's order -- whole 64-triangle blocks, so that every kernel's workgroups (64, 32 .. 1 triangles each) and
+// the 64-row accumulator blocks of k_fuse_tri fall inside one part.  Without a re-ordered mesh these are also the accumulator rows
+// the part leaves final.
+void smesh_fuse_part_rows(uint64_t F, int part, int nparts, uint64_t* f_lo, uint64_t* f_hi) {
+  const uint64_t B = div_up(F, 64);
+  *f_lo = std::min(F, 64 * (B * (uint64_t)part / (uint64_t)nparts));
+  *f_hi = std::min(F, 64 * (B * (uint64_t)(part + 1) / (uint64_t)nparts));
+}
+
+// `nviews` = 1, 2, 4 or 8 (smesh_aggregator_max_fused_views): views[0], views[1] ... of the same renderer in one launch.
+// `part` / `nparts`: only the triangles of smesh_fuse_part_rows(F, part, nparts) -- the queued medium triangles (k_fuse_mid, float
+// atomics) all go with part 0, the queued big ones with the part their position falls into.
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
-                                    const RenderedView* views, int nviews) {
+                                    const RenderedView* views, int nviews, int part, int nparts) {
   DeviceCtx* ctx = a->ctx;
   hipStream_t st = ctx->stream;
   if (F == 0) return SMESH_OK;
+  if (nparts < 1 || part < 0 || part >= nparts) return fail(SMESH_ERR_INVALID, "fuse_triangles: bad part");
+  SMESH_TRY(smesh_aggregator_refuse_scattered(a, "fuse_view()"));
+  uint64_t f_lo, f_hi;
+  smesh_fuse_part_rows(F, part, nparts, &f_lo, &f_hi);
+  if (f_lo >= f_hi && part != 0) return SMESH_OK;   // (part 0 still owns the medium triangles)
   if ((nviews != 1 && nviews != 2 && nviews != 4 && nviews != 8) || nviews > smesh_aggregator_max_fused_views(a))
     return fail(SMESH_ERR_INVALID, "fuse_triangles: unsupported view count");
   const uint64_t N = views[0].W * views[0].H;
@@ -2199,6 +2267,9 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     x.tex_first = nullptr; x.tex_res = nullptr; x.count = nullptr; x.acc_d = nullptr;
     x.prim_id = prim_id;
     x.mid = 0;
+    x.blk_first = (uint32_t)(f_lo / kWave);
+    x.tri_blocks = (uint32_t)div_up(f_hi - f_lo, kWave);
+    x.f_lo = (uint32_t)f_lo; x.f_hi = (uint32_t)f_hi;
   }
   // k_fuse_tri (row in registers; the wave's 64-row block staged through LDS unless the mesh was re-ordered) takes C <= 48: exact instances for 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 .. 48 for the rest
   // (tri_ct 41 = the run-time instance with 40 slots).
@@ -2223,16 +2294,18 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
       SMESH_TRY(a->fb_amax.reserve(scratch_stride * (uint64_t)nviews * 4));
       amax = static_cast<uint32_t*>(a->fb_amax.ptr);
     }
-    t.tri_blocks = wide_chunks ? (uint32_t)div_up(F, kWave) : (uint32_t)div_up(F, kWave / G);
+    const uint64_t tpb = wide_chunks ? (uint64_t)kWave : (uint64_t)(kWave / G);   // triangles per workgroup
+    t.blk_first = (uint32_t)(f_lo / tpb);
+    t.tri_blocks = (uint32_t)div_up(f_hi - f_lo, tpb);
   }
   static const uint32_t big_per_cu = getenv("SMESH_BIG_WAVES") ? (uint32_t)std::max(1, atoi(getenv("SMESH_BIG_WAVES"))) : 16u;
   const uint32_t big_waves = big_per_cu * (uint32_t)std::max(1, ctx->num_cus);    // one wave per queued big triangle at a time; they exit at once if the queue is empty
   const dim3 grid(t.tri_blocks + big_waves), block(kWave);
   const dim3 tgrid(t.tri_blocks), bgrid(big_waves);                        // any-C paths: big triangles in a second launch
-  if (!specialised) SMESH_TRY(mul_recentre(a));
+  if (!specialised && part == 0) SMESH_TRY(mul_recentre(a));   // (a pass over ALL rows: never beside the exchange of a finished range)
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
-    prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, (uint64_t)nviews);
+    prof_note(ctx, SMESH_PROF_FUSE_SCATTER, 1, part == 0 ? (uint64_t)nviews : 0);
 #define SMESH_FA(K)                                                                            \
     switch (G) {                                                                               \
       case 1:  hipLaunchKernelGGL((k_fuse_tri_any<K, 1>), tgrid, block, 0, st, t, tv, nviews); break;  \
@@ -2264,7 +2337,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
       case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
       case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
       default:                                                                                \
-        if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                               \
+        if (!t.tri_blocks) { } else if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }   \
         hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, tv, nviews, pw, amax, scratch_stride);             \
         break;                                                                                \
     }
@@ -2279,7 +2352,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
       if (mid_mode && listed && a->kind != SMESH_AGG_MUL) {      // (Mul's (hi, lo) rows cannot take k_fuse_mid's atomics)
         t.mid = mid_mode == 2 ? 0 : 1;
         const int slots = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : a->C <= 40 ? 40 : 48;
-        if (mid_mode != 3) smesh_launch_fuse_mid(a->kind, slots, nviews, dim3(6u * (uint32_t)std::max(1, ctx->num_cus)), st, t, tv);
+        if (mid_mode != 3 && part == 0) smesh_launch_fuse_mid(a->kind, slots, nviews, dim3(6u * (uint32_t)std::max(1, ctx->num_cus)), st, t, tv);
       }
     }
     if (nviews >= 2 && specialised) {   // the several-view instances of k_fuse_tri live in fusion_pair.hip / fusion_multi*.hip
@@ -2322,6 +2395,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.acc_lo = a->acc_lo; t.F = F; t.C = a->C;
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
+  t.blk_first = 0u; t.f_lo = 0u; t.f_hi = (uint32_t)F;
   t.dbg = 0; t.prim_id = nullptr;
   SMESH_TRY(ensure_acc_d(a));
   t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count; t.acc_d = a->acc_d;
@@ -2367,6 +2441,7 @@ int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const ui
   t.acc = a->acc; t.acc_lo = a->acc_lo; t.F = F; t.C = a->C; t.W = (uint32_t)views[0].W; t.H = (uint32_t)views[0].H; t.iew = a->iew;
   t.big_queue = views[0].big_queue; t.big_len = views[0].big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
+  t.blk_first = 0u; t.f_lo = 0u; t.f_hi = (uint32_t)F;
   t.dbg = 0; t.prim_id = nullptr;
   SMESH_TRY(ensure_acc_d(a));
   t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count; t.acc_d = a->acc_d;
@@ -2402,6 +2477,8 @@ DeviceCtx* smesh_aggregator_ctx(smesh_aggregator* a) { return a->ctx; }
 int smesh_aggregator_acc(smesh_aggregator* a, float** acc, uint64_t* num_floats, uint32_t* row_stride, uint64_t* rows) {
   if (acc) *acc = nullptr;
   if (num_floats) *num_floats = 0;
+  SMESH_TRY(smesh_aggregator_refuse_scattered(a, "exchange"));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
   SMESH_TRY(mul_normalise(a, true));
   if (acc) *acc = a->acc;
   if (num_floats) *num_floats = a->P * a->S;
@@ -2410,6 +2487,78 @@ int smesh_aggregator_acc(smesh_aggregator* a, float** acc, uint64_t* num_floats,
   return SMESH_OK;
 }
 uint32_t smesh_aggregator_classes(smesh_aggregator* a) { return a->C; }
+uint64_t smesh_aggregator_primitives(smesh_aggregator* a) { return a->P; }
+
+// The main stream waits (on the device, not the host) for the collectives that smesh_allreduce_rows put on the exchange stream.
+// Called by every entry point that reads or writes the accumulator on the main stream, with the aggregator and context locked.
+int smesh_aggregator_join_exchange(smesh_aggregator* a) {
+  if (!a->xchg_pending) return SMESH_OK;
+  SMESH_HIP(hipStreamWaitEvent(a->ctx->stream, a->ev_xchg, 0));
+  a->xchg_pending = false;
+  return SMESH_OK;
+}
+
+// A reduce-scatter leaves the rows outside [owned_lo, owned_hi) holding this rank's partial sums only.
+int smesh_aggregator_refuse_scattered(smesh_aggregator* a, const char* what) {
+  if (!a->scattered) return SMESH_OK;
+  return fail(SMESH_ERR_INVALID, std::string(what) + ": the accumulator was reduce-scattered -- only get_rows() inside the owned rows and "
+                                                     "reset() are meaningful until reset()");
+}
+void smesh_aggregator_mark_scattered(smesh_aggregator* a, uint64_t lo, uint64_t hi) { a->scattered = true; a->owned_lo = lo; a->owned_hi = hi; }
+
+namespace {
+// Mul: the exact value of an accumulator element is hi + lo (two float32 planes, fuse_tri.inc.hpp "Mul state").  Across ranks the
+// pairs are summed in float64: a float32 all-reduce of a folded hi plane loses the difference between a row's leading classes to the
+// ulp of the sums (get() was off by up to 2e-4 relative with eight ranks; 1e-5 is the bar).
+__global__ void k_mul_rows_to_f64(const float* __restrict__ hi, const float* __restrict__ lo, double* __restrict__ out, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)hi[i] + (double)lo[i];
+}
+__global__ void k_mul_rows_from_f64(const double* __restrict__ in, float* __restrict__ hi, float* __restrict__ lo, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double v = in[i];
+  const float h = (float)v;
+  hi[i] = h;
+  lo[i] = (h > -INFINITY && h < INFINITY) ? (float)(v - (double)h) : 0.0f;   // (-inf / NaN: no remainder, as mul_fold)
+}
+}  // namespace
+
+// What a sum over ranks of rows [lo, hi) operates on, prepared on stream `st`: Sum / Summax -- the float32 rows in place; Mul -- a
+// float64 image of the (hi, lo) pairs in the aggregator's staging buffer (*is_f64 = 1), written back by smesh_aggregator_exchange_end.
+int smesh_aggregator_exchange_begin(smesh_aggregator* a, uint64_t lo, uint64_t hi, hipStream_t st, void** buf, uint64_t* count, int* is_f64) {
+  *buf = nullptr; *count = 0; *is_f64 = 0;
+  if (lo > hi || hi > a->P) return fail(SMESH_ERR_INVALID, "bad row range");
+  const uint64_t n = (hi - lo) * a->S;
+  if (n == 0) return SMESH_OK;
+  *count = n;
+  if (a->kind != SMESH_AGG_MUL) { *buf = a->acc + lo * a->S; return SMESH_OK; }
+  if (a->xchg_stage.bytes < n * 8) {
+    SMESH_HIP(hipStreamSynchronize(st));   // growing the staging buffer frees the old one: the previous range's collective must be through
+    SMESH_TRY(a->xchg_stage.reserve(n * 8));
+  }
+  hipLaunchKernelGGL(k_mul_rows_to_f64, dim3((uint32_t)div_up(n, 256)), dim3(256), 0, st, a->acc + lo * a->S, a->acc_lo + lo * a->S,
+                     static_cast<double*>(a->xchg_stage.ptr), n);
+  SMESH_HIP(hipGetLastError());
+  *buf = a->xchg_stage.ptr; *is_f64 = 1;
+  return SMESH_OK;
+}
+int smesh_aggregator_exchange_end(smesh_aggregator* a, uint64_t lo, uint64_t hi, hipStream_t st) {
+  const uint64_t n = (hi - lo) * a->S;
+  if (n == 0 || a->kind != SMESH_AGG_MUL) return SMESH_OK;
+  hipLaunchKernelGGL(k_mul_rows_from_f64, dim3((uint32_t)div_up(n, 256)), dim3(256), 0, st, static_cast<const double*>(a->xchg_stage.ptr),
+                     a->acc + lo * a->S, a->acc_lo + lo * a->S, n);
+  SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
+}
+// The events that hand a row range from the main stream to the exchange stream and back (comm.cpp: smesh_allreduce_rows).
+int smesh_aggregator_exchange_events(smesh_aggregator* a, hipEvent_t* ev_part, hipEvent_t* ev_xchg) {
+  if (!a->ev_part) SMESH_HIP(hipEventCreateWithFlags(&a->ev_part, hipEventDisableTiming));
+  if (!a->ev_xchg) SMESH_HIP(hipEventCreateWithFlags(&a->ev_xchg, hipEventDisableTiming));
+  *ev_part = a->ev_part; *ev_xchg = a->ev_xchg;
+  return SMESH_OK;
+}
+void smesh_aggregator_exchange_pending(smesh_aggregator* a) { a->xchg_pending = true; }
 std::mutex& smesh_aggregator_mutex(smesh_aggregator* a) { return a->mu; }
 // Contiguous (W,H,C) copy, in the aggregator's scratch, of class vectors that sit in DEVICE memory with other (non-negative) strides
 // -- a (H,W,C) tensor seen as (W,H,C), the view a framework's transpose / permute returns -- or at an address the 16-byte loads of
@@ -2473,6 +2622,10 @@ int smesh_aggregator_destroy(smesh_aggregator_t* a) {
   if (a->acc_d) (void)hipFree(a->acc_d);
   (void)hipFree(a->count);
   if (a->ev_staged) (void)hipEventDestroy(a->ev_staged);
+  (void)hipStreamSynchronize(a->ctx->exchange_stream);
+  if (a->ev_part) (void)hipEventDestroy(a->ev_part);
+  if (a->ev_xchg) (void)hipEventDestroy(a->ev_xchg);
+  a->xchg_stage.release();
   for (Scratch* s : {&a->st_idx, &a->st_probs, &a->st_w, &a->nm_idx, &a->nm_probs, &a->nm_w, &a->fb_w, &a->fb_amax, &a->pw, &a->out_tmp})
     s->release();
   a->rec.release();
@@ -2485,6 +2638,8 @@ int smesh_aggregator_reset(smesh_aggregator_t* a) {
   std::lock_guard<std::mutex> g(a->mu);
   std::lock_guard<std::recursive_mutex> lock(a->ctx->mu);
   SMESH_HIP(hipSetDevice(a->ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
+  a->scattered = false;
   SMESH_HIP(hipMemsetAsync(a->acc, 0, (size_t)a->P * a->S * 4, a->ctx->stream));
   if (a->acc_lo) SMESH_HIP(hipMemsetAsync(a->acc_lo, 0, (size_t)a->P * a->S * 4, a->ctx->stream));
   return SMESH_OK;
@@ -2504,6 +2659,8 @@ static int aggregator_add(smesh_aggregator_t* a, const void* indices, int idx_dt
   DeviceCtx* ctx = a->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
+  SMESH_TRY(smesh_aggregator_refuse_scattered(a, "add()"));
 
   const void* d_idx = indices;
   const float* d_probs = probs;
@@ -2596,6 +2753,8 @@ int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind) {
   DeviceCtx* ctx = a->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
+  SMESH_TRY(smesh_aggregator_refuse_scattered(a, "get()"));
   const size_t bytes = (size_t)a->P * a->C * 4;
   if (bytes == 0) return SMESH_OK;
   if (memkind == SMESH_MEM_DEVICE) {
@@ -2617,6 +2776,9 @@ int smesh_aggregator_get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t r
   DeviceCtx* ctx = a->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
+  if (a->scattered && (row_lo < a->owned_lo || row_hi > a->owned_hi))
+    return fail(SMESH_ERR_INVALID, "get_rows(): after a reduce-scatter only the owned rows hold the fused result");
   const size_t bytes = (size_t)(row_hi - row_lo) * a->C * 4;
   if (bytes == 0) return SMESH_OK;
   float* d_out = out;
@@ -2636,6 +2798,8 @@ int smesh_aggregator_get_raw(smesh_aggregator_t* a, float* out, int memkind) {
   DeviceCtx* ctx = a->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
+  SMESH_TRY(smesh_aggregator_refuse_scattered(a, "get_raw()"));
   const size_t bytes = (size_t)a->P * a->C * 4;
   if (!bytes) return SMESH_OK;
   SMESH_TRY(mul_normalise(a, true));
@@ -2652,6 +2816,8 @@ int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind
   DeviceCtx* ctx = a->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
+  a->scattered = false;   // every row is being overwritten
   const size_t bytes = (size_t)a->P * a->C * 4;
   if (!bytes) return SMESH_OK;
   if (a->acc_lo) SMESH_HIP(hipMemsetAsync(a->acc_lo, 0, (size_t)a->P * a->S * 4, ctx->stream));
@@ -2662,10 +2828,41 @@ int smesh_aggregator_set_raw(smesh_aggregator_t* a, const float* in, int memkind
   return SMESH_OK;
 }
 
+// Rows [row_lo, row_hi) of one PLANE of the raw state, dense float32[row_hi - row_lo, C]: plane 0 = the accumulator as it is stored
+// (Mul: the hi plane, NOT folded), plane 1 = Mul's lo plane.  What a host-side exchange of a row range moves (distributed.py).
+static int raw_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, int plane, float* buf, int memkind, bool set) {
+  if (!a || !buf) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (row_lo > row_hi || row_hi > a->P) return fail(SMESH_ERR_INVALID, "bad row range");
+  if (plane != 0 && !(plane == 1 && a->kind == SMESH_AGG_MUL)) return fail(SMESH_ERR_INVALID, "plane must be 0 (or 1 for the Mul aggregator's lo plane)");
+  std::lock_guard<std::mutex> g(a->mu);
+  DeviceCtx* ctx = a->ctx;
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
+  SMESH_TRY(smesh_aggregator_refuse_scattered(a, set ? "set_raw_rows()" : "get_raw_rows()"));
+  if (row_lo == row_hi) return SMESH_OK;
+  float* rows = (plane ? a->acc_lo : a->acc) + row_lo * a->S;
+  if (set)
+    SMESH_HIP(hipMemcpy2DAsync(rows, (size_t)a->S * 4, buf, (size_t)a->C * 4, (size_t)a->C * 4, row_hi - row_lo,
+                               memkind == SMESH_MEM_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, ctx->stream));
+  else
+    SMESH_HIP(hipMemcpy2DAsync(buf, (size_t)a->C * 4, rows, (size_t)a->S * 4, (size_t)a->C * 4, row_hi - row_lo,
+                               memkind == SMESH_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, ctx->stream));
+  SMESH_HIP(hipStreamSynchronize(ctx->stream));
+  return SMESH_OK;
+}
+int smesh_aggregator_get_raw_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, int plane, float* out, int memkind) {
+  return raw_rows(a, row_lo, row_hi, plane, out, memkind, false);
+}
+int smesh_aggregator_set_raw_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, int plane, const float* in, int memkind) {
+  return raw_rows(a, row_lo, row_hi, plane, const_cast<float*>(in), memkind, true);
+}
+
 int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* n) {
   if (!a || !ptr) return fail(SMESH_ERR_INVALID, "NULL argument");
   // callers (the RCCL all-reduce) use this from another stream: make sure our work is done first
   SMESH_HIP(hipSetDevice(a->ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
   SMESH_TRY(mul_normalise(a, true));
   SMESH_HIP(hipStreamSynchronize(a->ctx->stream));
   *ptr = a->acc;
@@ -2703,6 +2900,8 @@ int smesh_aggregator_renderer(smesh_aggregator_t* a, smesh_annotation_renderer_t
   DeviceCtx* ctx = a->ctx;
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));
+  SMESH_TRY(smesh_aggregator_refuse_scattered(a, "renderer()"));
   auto* r = new (std::nothrow) smesh_annotation_renderer();
   if (!r) return fail(SMESH_ERR_RUNTIME, "out of memory");
   r->ctx = ctx; r->P = a->P; r->C = a->C;

@@ -390,7 +390,7 @@ __global__ __launch_bounds__(kBlock) void k_rec_resolve(const uint32_t* __restri
 template <int KIND>
 __device__ __forceinline__ void scatter_sparse_pixel(uint64_t i, const uint32_t* __restrict__ idx, const float* __restrict__ probs,
                                                      const float* __restrict__ weights, uint32_t P, uint32_t C, float iew,
-                                                     const TriFrag* __restrict__ frags, float* __restrict__ acc) {
+                                                     const TriFrag* __restrict__ frags, float* __restrict__ acc, double* __restrict__ acc_d) {
   const uint32_t v = idx[i];
   if (v >= P) return;
   const TriFrag rec = frags[v];
@@ -408,48 +408,62 @@ __device__ __forceinline__ void scatter_sparse_pixel(uint64_t i, const uint32_t*
   float* __restrict__ row = acc + (uint64_t)v * C;
   if (KIND == SMESH_AGG_SUMMAX) {
     atomicAdd(&row[am], best * w);
+  } else if (KIND == SMESH_AGG_MUL) {
+    // Mul: this image's terms of a sparse primitive are summed in DOUBLE in the aggregator's scratch rows (all zero between calls;
+    // MI355X adds float64 in memory natively) and folded into the (hi, lo) row by k_fold_sparse -- float32 atomics on the hi plane
+    // missed 1e-5 on get() by three orders of magnitude for primitives of thousands of pixels
+    double* __restrict__ drow = acc_d + (uint64_t)v * C;
+    for (uint32_t c = 0; c < C; c++) unsafeAtomicAdd(&drow[c], (double)contribution<KIND>(pr[c], w));
   } else {
     for (uint32_t c = 0; c < C; c++) atomicAdd(&row[c], contribution<KIND>(pr[c], w));
   }
 }
 
+// Pass D: the pixels of the sparse primitives, a grid-stride loop of a small persistent grid (an image without sparse primitives --
+// every rendering -- leaves at the first test, and a few hundred workgroups doing so cost less than one per 256 pixels).
 template <int KIND>
 __global__ __launch_bounds__(kBlock) void k_scatter_sparse(const uint32_t* __restrict__ idx, const float* __restrict__ probs,
                                                            const float* __restrict__ weights, uint64_t N, uint32_t P, uint32_t C, float iew,
                                                            const TriFrag* __restrict__ frags, const uint32_t* __restrict__ big_count,
-                                                           float* __restrict__ acc) {
+                                                           float* __restrict__ acc, double* __restrict__ acc_d) {
   if (big_count[2] == 0u) return;
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= N) return;
-  scatter_sparse_pixel<KIND>(i, idx, probs, weights, P, C, iew, frags, acc);
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (uint64_t)gridDim.x * kBlock)
+    scatter_sparse_pixel<KIND>(i, idx, probs, weights, P, C, iew, frags, acc, acc_d);
 }
 
-// Pending primitives (more than 64 pixels, or pixels far from the centroid): passes E, C' and D in ONE launch of co-resident workgroups
-// with grid barriers between them (big_count[3]); every workgroup leaves at once when nothing is pending -- every rendering of a
-// finely tessellated mesh, for which three launches that find nothing to do would cost a sixth of the whole call.  E: extent by
-// atomics, one set per run of a column.  C': the kind 2 record, or "sparse" as k_rec_big decides.  D: the pixels of sparse primitives,
-// float atomics in pixel order -- ahead of the fusion launch, whose waves write whole blocks of rows back.
-__device__ __forceinline__ void grid_barrier(uint32_t* counter, uint32_t target) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    atomicAdd(counter, 1u);
-    // (bounded: a launch whose workgroups never all become resident ends in a reported kernel fault after a few seconds, not in a hang)
-    for (uint32_t spins = 0; __hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; spins++) {
-      __builtin_amdgcn_s_sleep(8);
-      if (spins > (1u << 24)) __builtin_trap();
+// Mul, behind pass D: every sparse primitive (they are all in the queue) folds the float64 sums of this image's terms into its (hi, lo)
+// row, re-centred on the row's largest finite element ("Mul state", fuse_tri.inc.hpp), and leaves the scratch row zero again.
+__global__ __launch_bounds__(kBlock) void k_fold_sparse(const TriFrag* __restrict__ frags, const uint32_t* __restrict__ big_queue,
+                                                        const uint32_t* __restrict__ big_count, uint32_t C, float* __restrict__ acc,
+                                                        float* __restrict__ acc_lo, double* __restrict__ acc_d) {
+  if (big_count[2] == 0u) return;
+  const uint32_t nbig = big_count[0];
+  for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < nbig; q += gridDim.x * kBlock) {
+    const uint32_t v = big_queue[q];
+    const TriFrag rec = frags[v];
+    if (!(rec.kind == 0 && rec.pad == 1)) continue;
+    float* hi = acc + (uint64_t)v * C;
+    float* lo = acc_lo + (uint64_t)v * C;
+    double* drow = acc_d + (uint64_t)v * C;
+    float m = -INFINITY;
+    for (uint32_t c = 0; c < C; c++) { const float h = hi[c]; if (h > m && h < INFINITY) m = h; }
+    const float centre = m > -INFINITY ? m : 0.0f;
+    for (uint32_t c = 0; c < C; c++) {
+      float h = hi[c], r = lo[c];
+      mul_fold(h, r, centre, __hip_atomic_load(&drow[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));   // (written by atomics: read where they landed)
+      hi[c] = h; lo[c] = r; drow[c] = 0.0;
     }
-    __threadfence();
   }
-  __syncthreads();
 }
 
-template <int KIND>
-__global__ __launch_bounds__(kBlock) void k_rec_tail(const uint32_t* __restrict__ idx, const float* __restrict__ probs,
-                                                     const float* __restrict__ weights, uint64_t N, uint32_t H, uint32_t P, uint32_t C, float iew,
-                                                     TriFrag* __restrict__ frags, uint4* __restrict__ big4,
-                                                     const uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count,
-                                                     float* __restrict__ acc) {
+// Pending primitives (more than 64 pixels, or pixels far from the centroid): passes E and C' in ONE launch of a small persistent grid;
+// every workgroup leaves at once when nothing is pending -- every rendering of a finely tessellated mesh.  E: extent by atomics, one
+// set per run of a column.  C': the kind 2 record, or "sparse" as k_rec_big decides -- by the workgroup that finishes pass E LAST
+// (a ticket counter, big_count[3]: it has seen every other workgroup's fence, so their atomics have landed).  No workgroup ever
+// waits for another one: nothing here depends on how many of them are resident at once (round 3's grid barrier did).
+__global__ __launch_bounds__(kBlock) void k_rec_extent(const uint32_t* __restrict__ idx, uint64_t N, uint32_t H, uint32_t P,
+                                                       TriFrag* __restrict__ frags, uint4* __restrict__ big4,
+                                                       const uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
   const uint32_t nbig = big_count[0];       // final: pass R ran before this launch
   if (nbig == 0u) return;
   for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < N; base += (uint64_t)gridDim.x * kBlock) {
@@ -472,9 +486,16 @@ __global__ __launch_bounds__(kBlock) void k_rec_tail(const uint32_t* __restrict_
     atomicMax(&b[2], 65536u - x);        // 65536 - smallest x
     atomicMax(&b[3], 65536u - y);        // 65536 - smallest y
   }
-  // (the launch has at most one workgroup per CU: all resident, or waiting only for other kernels to end)
-  grid_barrier(&big_count[3], gridDim.x);
-  for (uint32_t q = blockIdx.x * kBlock + threadIdx.x; q < nbig; q += gridDim.x * kBlock) {
+  __shared__ uint32_t s_ticket;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    s_ticket = atomicAdd(&big_count[3], 1u);   // (reset by the next call's pass M)
+  }
+  __syncthreads();
+  if (s_ticket != gridDim.x - 1u) return;
+  __threadfence();
+  for (uint32_t q = threadIdx.x; q < nbig; q += kBlock) {
     const uint32_t v = big_queue[q];
     TriFrag rec = frags[v];
     if (rec.pad != kPadPending) continue;          // a kind 2 record k_rec_resolve finished itself
@@ -503,10 +524,6 @@ __global__ __launch_bounds__(kBlock) void k_rec_tail(const uint32_t* __restrict_
     frags[v] = rec;
     big4[v] = make_uint4(0u, 0u, 0u, 0u);
   }
-  grid_barrier(&big_count[3], 2u * gridDim.x);
-  if (__hip_atomic_load(&big_count[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) return;
-  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (uint64_t)gridDim.x * kBlock)
-    scatter_sparse_pixel<KIND>(i, idx, probs, weights, P, C, iew, frags, acc);
 }
 
 // After the fusion, when the image is much smaller than the primitive count: only the records the image touched.
@@ -591,49 +608,36 @@ int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, 
   return SMESH_OK;
 }
 
-// Passes E, C' and D of the moments variant (between the build and the fusion launch); nothing for passes A / B.
-int image_records_pending(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
-                          uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st) {
+// Passes E and C' of the moments variant (between the build and the fusion launch); nothing for passes A / B.
+int image_records_pending(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, hipStream_t st) {
   if (!r.moments) return SMESH_OK;
   const uint64_t N = W * H;
-  // one workgroup per CU: the grid barriers need every workgroup resident at once, also when other processes share the GPU (each of
-  // them may be inside this launch); a barrier that is not met within seconds ends in a reported fault, not a hang
   const dim3 grid((uint32_t)std::min<uint64_t>(div_up(N, kBlock), (uint32_t)std::max(1, ctx->num_cus))), block(kBlock);
-  switch (kind) {
-    case SMESH_AGG_SUM:
-      hipLaunchKernelGGL(k_rec_tail<SMESH_AGG_SUM>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)H, (uint32_t)r.P, C, iew, r.frags, r.big4,
-                         r.big_queue, r.big_count, acc);
-      break;
-    case SMESH_AGG_SUMMAX:
-      hipLaunchKernelGGL(k_rec_tail<SMESH_AGG_SUMMAX>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)H, (uint32_t)r.P, C, iew, r.frags, r.big4,
-                         r.big_queue, r.big_count, acc);
-      break;
-    default:
-      hipLaunchKernelGGL(k_rec_tail<SMESH_AGG_MUL>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)H, (uint32_t)r.P, C, iew, r.frags, r.big4,
-                         r.big_queue, r.big_count, acc);
-      break;
-  }
+  hipLaunchKernelGGL(k_rec_extent, grid, block, 0, st, d_idx, N, (uint32_t)H, (uint32_t)r.P, r.frags, r.big4, r.big_queue, r.big_count);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }
 
+// Pass D, behind the fusion launch (whose waves write whole blocks of rows back: the float atomics must not run beside it): the pixels
+// of the sparse primitives.  `acc_lo` / `acc_d`: the Mul aggregator's lo plane and its float64 scratch rows (else null).
 int image_records_scatter_sparse(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
-                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, hipStream_t st) {
-  if (r.moments) return SMESH_OK;     // (pass D ran inside k_rec_tail, ahead of the fusion)
+                                 uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, float* acc_lo, double* acc_d, hipStream_t st) {
   const uint64_t N = W * H;
-  const dim3 grid((uint32_t)div_up(N, kBlock)), block(kBlock);
+  const dim3 grid((uint32_t)std::min<uint64_t>(div_up(N, kBlock), 2u * (uint32_t)std::max(1, ctx->num_cus))), block(kBlock);
   switch (kind) {
     case SMESH_AGG_SUM:
       hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_SUM>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
-                         r.big_count, acc);
+                         r.big_count, acc, acc_d);
       break;
     case SMESH_AGG_SUMMAX:
       hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_SUMMAX>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
-                         r.big_count, acc);
+                         r.big_count, acc, acc_d);
       break;
     default:
+      if (!acc_lo || !acc_d) return fail(SMESH_ERR_RUNTIME, "image records: the Mul aggregator's float64 scratch rows are missing");
       hipLaunchKernelGGL(k_scatter_sparse<SMESH_AGG_MUL>, grid, block, 0, st, d_idx, d_probs, d_w, N, (uint32_t)r.P, C, iew, r.frags,
-                         r.big_count, acc);
+                         r.big_count, acc, acc_d);
+      hipLaunchKernelGGL(k_fold_sparse, dim3((uint32_t)std::max(1, ctx->num_cus)), block, 0, st, r.frags, r.big_queue, r.big_count, C, acc, acc_lo, acc_d);
       break;
   }
   SMESH_HIP(hipGetLastError());

@@ -43,7 +43,10 @@ int smesh_aggregator_max_fused_views(smesh_aggregator* a);
 bool smesh_aggregator_takes_strided_probs(smesh_aggregator* a, int64_t ps0, int64_t ps1, int nviews);
 int smesh_aggregator_dense_probs(smesh_aggregator* a, const float* d_probs, const int64_t ps[3], uint64_t W, uint64_t H, const float** out);
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
-                                    const RenderedView* views, int nviews);
+                                    const RenderedView* views, int nviews, int part = 0, int nparts = 1);
+void smesh_fuse_part_rows(uint64_t F, int part, int nparts, uint64_t* f_lo, uint64_t* f_hi);
+uint64_t smesh_aggregator_primitives(smesh_aggregator* a);
+int smesh_aggregator_join_exchange(smesh_aggregator* a);
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
 bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P);
 int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
@@ -1055,6 +1058,8 @@ __global__ void k_texel_area(const float* __restrict__ verts, const int32_t* __r
 }  // namespace
 
 constexpr int kSlots = 2 * kMaxGroup;   // two banks of view slots: smesh_fuse_views rasterises group g+1 into one while group g is fused from the other
+constexpr int kHeld = 32;          // smesh_fuse_views_begin: views whose records and index planes stay resident until the job's last part
+constexpr int kSides = kSlots + kHeld;   // record sets / index planes: one per view slot, then the held ones (they need no rasteriser scratch)
 constexpr int kRecordSides = 6;   // render_device() rotates over this many sets of per-triangle records (<= kMaxGroup)
 
 struct ImagePair {
@@ -1091,12 +1096,21 @@ struct smesh_renderer {
     uint32_t* big_queue = nullptr;   // [big_capacity] triangles with a bounding box > 8 x 8
     uint32_t* big_count = nullptr;   // [0] length of the queue; emptied by the next render's vertex kernel
     TriFrag* frags = nullptr;        // [F] per-triangle fragment records
-  } side[kSlots];
+  } side[kSides];
   uint32_t big_capacity = 0;
   std::vector<ImagePair> images;   // pooled output planes
   Scratch own_idx;                 // for the host-output entry point
   // smesh_fuse_view pipeline: two index/depth slots, rasterised on ctx->raster_stream
-  Scratch fused[kSlots];   // index planes of fuse_view (slots 0, 1) / fuse_views (one per view of a group)
+  Scratch fused[kSides];   // index planes of fuse_view (slots 0, 1) / fuse_views (one per view of a group) / held views
+  // smesh_fuse_views_begin / _continue: the job whose views sit in side[kSlots ...] / fused[kSlots ...]
+  struct HeldJob {
+    int n = 0, nparts = 0, next_part = 0;
+    bool ranged = false;             // false: everything went with part 0 (the later parts are empty)
+    smesh_aggregator* agg = nullptr;
+    const float* probs[kHeld] = {};
+    const float* weights[kHeld] = {};
+    uint64_t W[kHeld] = {}, H[kHeld] = {};
+  } held;
   // smesh_fuse_views, group pipeline: bank b (slots b * kMaxGroup ...) has been rasterised / its fusion has been queued
   hipEvent_t ev_bank_rendered[2] = {nullptr, nullptr}, ev_bank_consumed[2] = {nullptr, nullptr}, ev_main_fence = nullptr;
   uint64_t group_seq = 0;
@@ -1350,7 +1364,10 @@ int prepare_group_slots(smesh_renderer* r, const smesh_camera_t* cams, int n, hi
   return SMESH_OK;
 }
 
-int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st, int base = 0) {
+// `side_base`: where the records and index planes go (side[side_base + v], fused[side_base + v]) when that is not the view slots'
+// own set (held views: the rasteriser scratch of slots base .. base + n - 1 is free again after the launches, the records stay).
+int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st, int base = 0, int side_base = -1) {
+  if (side_base < 0) side_base = base;
   DeviceCtx* ctx = r->ctx;
   ProjectGroup pg;
   RasterGroup rg;
@@ -1359,25 +1376,25 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   uint32_t tiles = 0;
   for (int v = 0; v < n; v++) {
     const uint64_t W = cams[v].width, H = cams[v].height, N = W * H;
-    SMESH_HIP(alloc_side(r, base + v));
+    SMESH_HIP(alloc_side(r, side_base + v));
     SMESH_HIP(alloc_scratch(r, base + v));
     smesh_renderer::ViewScratch& vs = r->vs[base + v];
     SMESH_TRY(ensure_keys(vs, W, H, st));
     int qs = SMESH_OK;
     if (!ensure_queues(r, vs, W, H, st, &qs)) return qs != SMESH_OK ? qs : fail(SMESH_ERR_RUNTIME, "fragment queues unavailable");
-    if (r->fused[base + v].bytes < N * 8) {
+    if (r->fused[side_base + v].bytes < N * 8) {
       SMESH_HIP(hipStreamSynchronize(st));   // growing a slot frees the old buffer: nothing may still be reading it
       SMESH_HIP(hipStreamSynchronize(r->ctx->stream));
-      SMESH_TRY(r->fused[base + v].reserve(N * 8));
+      SMESH_TRY(r->fused[side_base + v].reserve(N * 8));
     }
-    if (base + v < kRecordSides) { r->last_idx[base + v] = nullptr; r->rec_valid[base + v] = false; }   // the records of a render_device() on this side are being overwritten
+    if (side_base + v < kRecordSides) { r->last_idx[side_base + v] = nullptr; r->rec_valid[side_base + v] = false; }   // the records of a render_device() on this side are being overwritten
     pg.cam[v] = camera_args(&cams[v]);
     pg.sv[v] = vs.sv;
-    pg.big_count[v] = r->side[base + v].big_count;
-    rg.view[v] = raster_args(r, vs, base + v, W, H);
+    pg.big_count[v] = r->side[side_base + v].big_count;
+    rg.view[v] = raster_args(r, vs, side_base + v, W, H);
     rg.view[v].cam = pg.cam[v];
     rg.view[v].q = vs.fq;
-    rg.idx[v] = static_cast<uint32_t*>(r->fused[base + v].ptr);
+    rg.idx[v] = static_cast<uint32_t*>(r->fused[side_base + v].ptr);
     tiles += (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
     rg.tile_end[v] = tiles;
   }
@@ -1807,6 +1824,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));   // (rows still being exchanged on the exchange stream: smesh_allreduce_rows)
   const uint64_t W = cam->width, H = cam->height, N = W * H;
   // Optional two-stage pipeline over two HIP streams (SMESH_FUSE_PIPELINE=1): the rasteriser of this view
   // runs on the raster stream while the main stream is still fusing the previous view; events hand the index
@@ -1890,6 +1908,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
     std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     SMESH_HIP(hipSetDevice(ctx->device));
+    SMESH_TRY(smesh_aggregator_join_exchange(a));   // (rows still being exchanged on the exchange stream: smesh_allreduce_rows)
     static const bool group_pipeline_on = getenv("SMESH_GROUP_PIPELINE") && atoi(getenv("SMESH_GROUP_PIPELINE")) != 0;
     const bool use_pipeline = grouped && group_pipeline_on;
     if (!use_pipeline) {
@@ -1993,6 +2012,120 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
   return SMESH_OK;
 }
 
+}  // extern "C"
+
+// ---- sharded jobs: a rank's last views fused by triangle range (smesh.h) -----------------------------------
+// One launch per (group of up to eight held views, part): the records of all held views stay in side[kSlots ...], their index
+// planes in fused[kSlots ...]; part p reads them again.  Per accumulator row the additions are those of smesh_fuse_views, in
+// its order (rows of queued medium triangles excepted: their float atomics all go with part 0).
+static int fuse_held_part(smesh_renderer* r, smesh_aggregator* a, int part) {
+  DeviceCtx* ctx = r->ctx;
+  const smesh_renderer::HeldJob& h = r->held;
+  const int max_nv = smesh_aggregator_max_fused_views(a);
+  static const int group_max = getenv("SMESH_RASTER_GROUP") ? std::min(kMaxGroup, std::max(2, atoi(getenv("SMESH_RASTER_GROUP")))) : kMaxGroup;
+  for (int i = 0; i < h.n; i += group_max) {
+    const int gn = std::min(group_max, h.n - i);
+    ProfScope fuse_region(ctx, SMESH_PROF_FUSE_SCATTER);
+    for (int j = 0; j < gn;) {
+      int nv = 1;
+      while (nv * 2 <= std::min(max_nv, gn - j)) nv *= 2;
+      RenderedView rv[kMaxGroup];
+      for (int v = 0; v < nv; v++) {
+        const int k = i + j + v;
+        const smesh_renderer::Side& sd = r->side[kSlots + k];
+        rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[kSlots + k].ptr), h.probs[k],
+                             h.weights[k], h.W[k], h.H[k], 0, 0, true};
+      }
+      SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, nullptr, r->big_capacity, rv, nv, part, h.nparts));
+      j += nv;
+    }
+  }
+  return SMESH_OK;
+}
+
+extern "C" {
+
+int smesh_fuse_views_begin(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_camera_t* cams, uint64_t n,
+                           const float* const* probs, const float* const* weights, int memkind, int nparts,
+                           uint64_t* row_lo, uint64_t* row_hi) {
+  if (!r || !a || !row_lo || !row_hi || (n && (!cams || !probs))) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (nparts < 1 || nparts > 64) return fail(SMESH_ERR_INVALID, "nparts must be in [1, 64]");
+  for (uint64_t i = 0; i < n; i++) {
+    SMESH_TRY(check_camera(&cams[i]));
+    if (!probs[i]) return fail(SMESH_ERR_INVALID, "NULL probs image");
+  }
+  DeviceCtx* ctx = r->ctx;
+  if (smesh_aggregator_ctx(a) != ctx) return fail(SMESH_ERR_INVALID, "renderer and aggregator live on different devices");
+  const uint64_t P = smesh_aggregator_primitives(a);
+  static const bool ranges_off = getenv("SMESH_FUSE_RANGES") && atoi(getenv("SMESH_FUSE_RANGES")) == 0;
+  bool ranged;
+  {
+    std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
+    ranged = !ranges_off && nparts > 1 && n >= 1 && n <= (uint64_t)kHeld && memkind == SMESH_MEM_DEVICE && !r->texels && r->F != 0 &&
+             r->V != 0 && r->prim_id == nullptr && smesh_aggregator_can_fuse_triangles(a, r->F);
+  }
+  for (uint64_t i = 0; i < n && ranged; i++) ranged = queues_fit_group(cams[i].width, cams[i].height);
+  if (!ranged) {
+    // Texel renderers, re-ordered meshes (rows are not in triangle order), host images, more views than can be held: the whole job
+    // goes with part 0, whose rows are then all of them; the later parts are empty.
+    SMESH_TRY(smesh_fuse_views(r, a, cams, n, probs, weights, memkind));
+    std::lock_guard<std::mutex> g(r->mu);
+    r->held = smesh_renderer::HeldJob();
+    r->held.nparts = nparts; r->held.next_part = 1; r->held.agg = a; r->held.ranged = false;
+    *row_lo = 0; *row_hi = P;
+    return SMESH_OK;
+  }
+  std::lock_guard<std::mutex> g(r->mu);
+  std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(ctx->device));
+  SMESH_TRY(smesh_aggregator_join_exchange(a));   // (an exchange of an earlier job still in flight on the exchange stream)
+  if (r->raster_pending) {
+    SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
+    r->raster_pending = false;
+  }
+  r->main_pending = true;
+  smesh_renderer::HeldJob& h = r->held;
+  h = smesh_renderer::HeldJob();
+  h.n = (int)n; h.nparts = nparts; h.next_part = 1; h.agg = a; h.ranged = true;
+  for (uint64_t i = 0; i < n; i++) {
+    h.probs[i] = probs[i]; h.weights[i] = weights ? weights[i] : nullptr; h.W[i] = cams[i].width; h.H[i] = cams[i].height;
+  }
+  static const int group_max = getenv("SMESH_RASTER_GROUP") ? std::min(kMaxGroup, std::max(2, atoi(getenv("SMESH_RASTER_GROUP")))) : kMaxGroup;
+  for (int i = 0; i < h.n; i += group_max)
+    SMESH_TRY(render_group_into(r, &cams[i], std::min(group_max, h.n - i), ctx->stream, 0, kSlots + i));
+  SMESH_TRY(fuse_held_part(r, a, 0));
+  smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, false), "render-records");
+  r->fused_seq += n;
+  smesh_fuse_part_rows(r->F, 0, nparts, row_lo, row_hi);
+  if (nparts == 1) h = smesh_renderer::HeldJob();
+  return SMESH_OK;
+}
+
+int smesh_fuse_views_continue(smesh_renderer_t* r, smesh_aggregator_t* a, int part, uint64_t* row_lo, uint64_t* row_hi) {
+  if (!r || !a || !row_lo || !row_hi) return fail(SMESH_ERR_INVALID, "NULL argument");
+  DeviceCtx* ctx = r->ctx;
+  if (smesh_aggregator_ctx(a) != ctx) return fail(SMESH_ERR_INVALID, "renderer and aggregator live on different devices");
+  std::lock_guard<std::mutex> g(r->mu);
+  std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  smesh_renderer::HeldJob& h = r->held;
+  if (h.agg != a || h.nparts < 2 || part != h.next_part || part >= h.nparts)
+    return fail(SMESH_ERR_INVALID, "smesh_fuse_views_continue: no such part of a job begun with smesh_fuse_views_begin (parts go in order)");
+  SMESH_HIP(hipSetDevice(ctx->device));
+  if (h.ranged) {
+    SMESH_TRY(fuse_held_part(r, a, part));
+    smesh_fuse_part_rows(r->F, part, h.nparts, row_lo, row_hi);
+  } else {
+    *row_lo = *row_hi = smesh_aggregator_primitives(a);
+  }
+  if (++h.next_part == h.nparts) h = smesh_renderer::HeldJob();   // the job is over: its records may be overwritten
+  return SMESH_OK;
+}
+
+}  // extern "C"
+
+extern "C" {
 // add() for an index image that is the unmodified device output of `r`'s most recent smesh_renderer_render_device():
 // the reference's two-call convention (render, then add: colorize_cityscapes_mesh.py:65-67) at the speed of
 // smesh_fuse_view.  Anything else is forwarded to smesh_aggregator_add.
@@ -2013,6 +2146,7 @@ int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t* r, co
     std::lock_guard<std::mutex> g(r->mu);
     std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    SMESH_TRY(smesh_aggregator_join_exchange(a));   // (rows still being exchanged on the exchange stream: smesh_allreduce_rows)
     int side = -1;
     for (int sd = 0; sd < kRecordSides; sd++)
       if (idx_dev == r->last_idx[sd] && W == r->last_W[sd] && H == r->last_H[sd]) side = sd;
@@ -2064,6 +2198,7 @@ int smesh_aggregator_add_matched(smesh_aggregator_t* a, smesh_renderer_t* r,
   std::lock_guard<std::mutex> g(r->mu);
   std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_TRY(smesh_aggregator_join_exchange(a));   // (rows still being exchanged on the exchange stream: smesh_allreduce_rows)
   if (!((!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) || (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives))))
     return SMESH_OK;
   bool any = false;

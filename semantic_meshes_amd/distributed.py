@@ -55,10 +55,40 @@ def allreduce_raw(aggregator, group=None, comm=None):
         import ctypes
         _lib.check(_lib.lib().smesh_stream_wait(flat.device, ctypes.c_void_p(int(torch.cuda.current_stream(flat.device).cuda_stream))))
         return aggregator
+    if hasattr(aggregator, "get_raw_rows"):
+        return allreduce_rows_raw(aggregator, 0, aggregator.primitives, group)
     raw = np.ascontiguousarray(aggregator.get_raw(), dtype=np.float32)
     t = torch.from_numpy(raw)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     aggregator.set_raw(raw)
+    return aggregator
+
+
+def allreduce_rows_raw(aggregator, row_lo, row_hi, group=None, comm=None):
+    """`allreduce_raw` for the rows [row_lo, row_hi) only -- what `MeshAggregator.fuse_views_ranged` hands to `on_rows` in a sharded job.
+    `comm`: `smesh_allreduce_rows`, one ncclAllReduce of the range on the library's exchange stream, beside the fusion of the next
+    range.  Otherwise through `torch.distributed` with host copies of the range (gloo: CPU-only test machines, several ranks sharing one
+    GPU) -- synchronous, same sums.  Mul aggregators exchange their (hi, lo) float32 pairs as float64 either way."""
+    if comm is not None:
+        return comm.allreduce_rows(aggregator, row_lo, row_hi)
+    dist = _dist()
+    if not dist.is_available() or not dist.is_initialized() or row_hi <= row_lo:
+        return aggregator
+    import torch
+    if getattr(aggregator, "kind", None) == "Mul":
+        v = aggregator.get_raw_rows(row_lo, row_hi, 0).astype(np.float64) + aggregator.get_raw_rows(row_lo, row_hi, 1)
+        t = torch.from_numpy(v)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        with np.errstate(invalid="ignore"):
+            hi = v.astype(np.float32)
+            lo = np.where(np.isfinite(hi), v - hi, 0.0).astype(np.float32)
+        aggregator.set_raw_rows(row_lo, hi, 0)
+        aggregator.set_raw_rows(row_lo, lo, 1)
+        return aggregator
+    raw = aggregator.get_raw_rows(row_lo, row_hi, 0)
+    t = torch.from_numpy(raw)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    aggregator.set_raw_rows(row_lo, raw, 0)
     return aggregator
 
 
@@ -101,13 +131,18 @@ def reduce_scatter_raw(aggregator, group=None, comm=None):
 
 
 def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None, contiguous=True, batch=8, comm=None,
-                       exchange=None):
-    """Fuse this rank's share of `cameras` and exchange.  `probs_of_view(k)` returns the (W,H,C)
-    class-probability image of view k (host or device).  `comm`: native communicator (see allreduce_raw).
-    `exchange` (default: SMESH_EXCHANGE, else "allreduce"): "allreduce" -- every rank ends with the whole fusion, returns the
-    aggregator; "reduce_scatter" -- returns `(row_lo, row_hi)`, the rows this rank owns (`aggregator.get_rows`)."""
-    import os
-    exchange = exchange or os.environ.get("SMESH_EXCHANGE", "allreduce")
+                       exchange="allreduce", nparts=4, held=24):
+    """Fuse this rank's share of `cameras` and exchange.  `probs_of_view(k)` returns the (W,H,C) class-probability image of view k
+    (host or device).  `comm`: native communicator (see allreduce_raw).  Returns `(aggregator, (row_lo, row_hi))`: the rows of
+    THIS rank's accumulator that hold the fusion of all views afterwards.
+
+    `exchange` (an explicit argument, never the environment):
+      "allreduce" (default, what north_star names) -- every rank ends with the whole fusion, rows (0, P).  With `nparts` > 1 the last
+         `held` (at most 32) views of the rank are fused by accumulator row range (`MeshAggregator.fuse_views_ranged`) and the
+         all-reduce of every finished range is queued on the exchange stream while the next range is fused: the same ONE sum over the
+         same bytes, in `nparts` pieces, of which only the last is exposed.  `nparts` = 1: one all-reduce after the last view.
+      "reduce_scatter" -- one in-place reduce-scatter after the last view; rank r owns `owned_rows(P, r, world)`, fetch them with
+         `aggregator.get_rows(row_lo, row_hi)` (everything else is refused until `reset()`)."""
     if exchange not in ("allreduce", "reduce_scatter"):
         raise ValueError("exchange must be 'allreduce' or 'reduce_scatter'")
     if comm is not None:
@@ -119,15 +154,25 @@ def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None,
         else:
             rank, world = 0, 1
     mine = list(shard_views(len(cameras), rank, world, contiguous))
+    ranged = exchange == "allreduce" and int(nparts) > 1 and hasattr(aggregator, "fuse_views_ranged") and len(mine) > 0
+    tail = mine[max(0, len(mine) - min(int(held), 32)):] if ranged else []
+    head = mine[:len(mine) - len(tail)]
     if hasattr(aggregator, "fuse_views"):
-        # eight views per call: the library shares rasteriser launches between them and fuses them two by two
-        for b in range(0, len(mine), batch):
-            ks = mine[b:b + batch]
+        # eight views per call: the library shares rasteriser and fusion launches between them
+        for b in range(0, len(head), batch):
+            ks = head[b:b + batch]
             aggregator.fuse_views(renderer, [cameras[k] for k in ks], [probs_of_view(k) for k in ks])
     else:
-        for k in mine:
+        for k in head:
             idx, _ = renderer.render(cameras[k])
             aggregator.add(idx, probs_of_view(k))
     if exchange == "reduce_scatter":
-        return reduce_scatter_raw(aggregator, group, comm)
-    return allreduce_raw(aggregator, group, comm)
+        return aggregator, tuple(reduce_scatter_raw(aggregator, group, comm))
+    if ranged:
+        images = [probs_of_view(k) for k in tail]      # (kept alive until the last part has been queued)
+        aggregator.fuse_views_ranged(renderer, [cameras[k] for k in tail], images, nparts=int(nparts),
+                                     on_rows=lambda lo, hi: allreduce_rows_raw(aggregator, lo, hi, group, comm))
+        del images
+    else:
+        allreduce_raw(aggregator, group, comm)
+    return aggregator, (0, aggregator.primitives)

@@ -202,18 +202,14 @@ class _MeshAggregator:
         _lib.check(_lib.lib().smesh_fuse_view(renderer._h, self._h, ctypes.byref(camera._pod), ctypes.c_void_p(pp), wp, pmem))
         release_to(self.device, streams)
 
-    def fuse_views(self, renderer, cameras, probs_images, weights_images=None):
-        """`fuse_view` for a whole batch, in order (the loop of colorize_cityscapes_mesh.py:54-67 as one call).  With a
-        triangle renderer and device-resident images the library fuses consecutive views two per launch: each accumulator
-        row is read and written once for both.  All images must live in the same memory (host or device)."""
+    def _marshal_views(self, cameras, probs_images, weights_images, what):
+        """ctypes arguments of a batch of views: (pods, n, probs pointers, weights pointers or None, memory kind, keep-alives, streams)."""
         cameras, probs_images = list(cameras), list(probs_images)
         n = len(cameras)
         if len(probs_images) != n or (weights_images is not None and len(weights_images) != n):
-            raise ValueError("fuse_views needs one probs image (and one weights image or None) per camera")
-        if n == 0:
-            return
-        pods = (_lib.CameraPOD * n)()
-        pptr, wptr = (ctypes.c_void_p * n)(), (ctypes.c_void_p * n)()
+            raise ValueError("%s needs one probs image (and one weights image or None) per camera" % what)
+        pods = (_lib.CameraPOD * max(n, 1))()
+        pptr, wptr = (ctypes.c_void_p * max(n, 1))(), (ctypes.c_void_p * max(n, 1))()
         keep, mem, streams = [], None, []
         for i, cam in enumerate(cameras):
             W, H = cam.resolution
@@ -222,11 +218,11 @@ class _MeshAggregator:
             if tuple(pshape) != (W, H, self.classes) or pdt != np.float32:
                 raise ValueError("probs image %d must be float32 (W,H,C) = %s" % (i, (W, H, self.classes)))
             if pstr != (H * self.classes, self.classes, 1):
-                raise ValueError("fuse_views needs contiguous (W,H,C) probs images")
+                raise ValueError("%s needs contiguous (W,H,C) probs images" % what)
             if mem is None:
                 mem = pmem
             if pmem != mem:
-                raise ValueError("fuse_views: all images must live in the same memory (host or device)")
+                raise ValueError("%s: all images must live in the same memory (host or device)" % what)
             pptr[i] = pp
             keep.append(k1)
             w = None if weights_images is None else weights_images[i]
@@ -236,9 +232,56 @@ class _MeshAggregator:
                     raise ValueError("weights image %d must be contiguous float32 (W,H) in the same memory as probs" % i)
                 wptr[i] = wp_
                 keep.append(k2)
-        _lib.check(_lib.lib().smesh_fuse_views(renderer._h, self._h, pods, n, pptr,
-                                               None if weights_images is None else wptr, mem))
+        return pods, n, pptr, (None if weights_images is None else wptr), (mem if mem is not None else _lib.MEM_HOST), keep, streams
+
+    def fuse_views(self, renderer, cameras, probs_images, weights_images=None):
+        """`fuse_view` for a whole batch, in order (the loop of colorize_cityscapes_mesh.py:54-67 as one call).  With a
+        triangle renderer and device-resident images the library rasterises and fuses up to eight views per launch: each
+        accumulator row is read and written once for all of them.  All images must live in the same memory (host or device)."""
+        pods, n, pptr, wptr, mem, keep, streams = self._marshal_views(cameras, probs_images, weights_images, "fuse_views")
+        if n == 0:
+            return
+        _lib.check(_lib.lib().smesh_fuse_views(renderer._h, self._h, pods, n, pptr, wptr, mem))
         release_to(self.device, streams)
+
+    def fuse_views_ranged(self, renderer, cameras, probs_images, weights_images=None, nparts=4, on_rows=None):
+        """`fuse_views` cut by accumulator row range (new functionality; `smesh_fuse_views_begin` / `_continue`): all
+        views (at most 32) are rasterised, then part p = 0 .. nparts-1 fuses, for all of them in order, the triangles whose rows lie
+        in one 64-row-aligned range, and `on_rows(row_lo, row_hi)` is called as soon as that part is queued -- those rows are final,
+        so a sharded job exchanges them (`Communicator.allreduce_rows`) while the next part is fused.  Same sums as `fuse_views`.
+        Where rows are not in triangle order (texel renderers, re-ordered meshes, host images ...) part 0 is the whole job.
+        Returns the list of (row_lo, row_hi)."""
+        pods, n, pptr, wptr, mem, keep, streams = self._marshal_views(cameras, probs_images, weights_images, "fuse_views_ranged")
+        nparts = int(nparts)
+        if n == 0 or nparts < 1:
+            raise ValueError("fuse_views_ranged needs at least one view and nparts >= 1")
+        lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+        ranges = []
+        lib = _lib.lib()
+        _lib.check(lib.smesh_fuse_views_begin(renderer._h, self._h, pods, n, pptr, wptr, mem, nparts, ctypes.byref(lo), ctypes.byref(hi)))
+        for part in range(nparts):
+            if part:
+                _lib.check(lib.smesh_fuse_views_continue(renderer._h, self._h, part, ctypes.byref(lo), ctypes.byref(hi)))
+            ranges.append((int(lo.value), int(hi.value)))
+            if on_rows is not None and hi.value > lo.value:
+                on_rows(int(lo.value), int(hi.value))
+        release_to(self.device, streams)
+        return ranges
+
+    def get_raw_rows(self, row_lo, row_hi, plane=0):
+        """Rows [row_lo, row_hi) of one plane of the raw state (plane 0: the accumulator as stored -- Mul: its hi plane, unfolded;
+        plane 1: Mul's lo plane; a Mul element's value is hi + lo): float32[row_hi - row_lo, C]."""
+        row_lo, row_hi = int(row_lo), int(row_hi)
+        out = np.empty((max(row_hi - row_lo, 0), self.classes), np.float32)
+        _lib.check(_lib.lib().smesh_aggregator_get_raw_rows(self._h, row_lo, row_hi, int(plane), out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
+        return out
+
+    def set_raw_rows(self, row_lo, raw, plane=0):
+        raw = np.ascontiguousarray(raw, dtype=np.float32)
+        if raw.ndim != 2 or raw.shape[1] != self.classes:
+            raise ValueError("raw rows must be float32[n,%d]" % self.classes)
+        _lib.check(_lib.lib().smesh_aggregator_set_raw_rows(self._h, int(row_lo), int(row_lo) + raw.shape[0], int(plane),
+                                                           raw.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
 
 
 class ModelRenderer:

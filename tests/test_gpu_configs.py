@@ -320,7 +320,7 @@ def test_cfg5_full_size_properties(sm):
     keep = hp.sum(axis=1) > 0.5
     want = np.zeros((100_000, C), np.float64)
     np.add.at(want, flat[sel][keep] - first, hp[keep].astype(np.float64))
-    np.testing.assert_allclose(rows, want, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(rows, want, rtol=1e-5, atol=1e-6)
     out = plain.get_device()                                                                     # normalised, stays in HBM
     tail = np.empty((100_000, C), np.float32)
     _lib.check(_lib.lib().smesh_memcpy(tail.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(out.ptr + first * C * 4), tail.nbytes,

@@ -71,7 +71,7 @@ def test_random_soup_against_oracle(sm, oracle, seed):
                 agg.fuse_view(r, cam, probs, weights)
             oagg.add(oidx, probs, weights)
         # Mul: (hi, lo) rows in every triangle-order kernel, a view's terms summed in double (fuse_tri.inc.hpp, "Mul state")
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)
 
@@ -114,7 +114,7 @@ def test_random_texel_soup_against_oracle(sm, oracle, seed):
         if batch:
             from semantic_meshes_amd.device import to_device
             agg.fuse_views(r, cams, [to_device(p) for p in batch])
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)
 
@@ -170,7 +170,7 @@ def test_random_soup_fuse_views_against_oracle(sm, oracle, seed):
         oagg = oracle.OracleAggregator(P, C, kind, iew)
         for v in range(nviews):
             oagg.add(o.render(cams[v])[0], probs[v], weights[v])
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)
 
@@ -212,7 +212,7 @@ def test_random_texel_soup_mul_against_the_float64_oracle(sm, oracle, seed):
         oagg = oracle.OracleAggregator(P, C, "mul", iew)
         for cam, p in zip(cams, probs):
             oagg.add(o.render(cam)[0], p)
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5, atol=1e-6)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)
 
@@ -284,7 +284,7 @@ def test_random_room_against_oracle(sm, oracle, seed):
             images.append(to_device(probs))
         grouped.fuse_views(r, cams, images)
         want = oagg.get()
-        assert_fused_close(agg.get(), want, rtol=2e-5, atol=1e-6)
-        assert_fused_close(grouped.get(), want, rtol=2e-5, atol=1e-6)
+        assert_fused_close(agg.get(), want, rtol=1e-5, atol=1e-6)
+        assert_fused_close(grouped.get(), want, rtol=1e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)

@@ -346,7 +346,7 @@ def test_golden_fixtures_on_gpu(sm):
             a.add(idx, probs)
     for kind, a in aggs.items():
         # the fixture was accumulated in float32 like the reference; tolerance covers the summation order
-        assert_fused_close(a.get(), want_fuse[kind], rtol=2e-5 if kind != "mul" else 2e-4, atol=1e-6)
+        assert_fused_close(a.get(), want_fuse[kind], rtol=1e-5, atol=1e-6)
 
 
 def test_texel_renderer_matches_oracle(sm, oracle):
@@ -519,7 +519,7 @@ def test_fuse_view_mixed_triangle_sizes(sm, oracle, kind):
         # Mul: bit-identical float32 terms on both sides, summed in double by k_fuse_tri / fuse_box ((hi, lo) state);
         # the hi-plane-only kernels behind SMESH_FUSE=strip sum thousands of pixels per primitive in float32
         import os
-        mul_tol = 5e-3 if os.environ.get("SMESH_FUSE") == "strip" else 1e-5
+        mul_tol = 1e-5
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
         oracle.set_accum_double(False)
@@ -552,7 +552,7 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
         if os.environ.get("SMESH_FUSE") != "strip":
             assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
                 "k_fuse_tri_wide" if C >= 128 and os.environ.get("SMESH_FUSE_WIDE") != "0" else "k_fuse_tri_any" if C > 48 else "k_fuse_tri")
-        mul_tol = 5e-3 if os.environ.get("SMESH_FUSE") == "strip" else 1e-5   # (hi, lo) state in every triangle-order kernel; the generic scatter-add adds in float32 on the hi plane
+        mul_tol = 1e-5   # (hi, lo) state in every triangle-order kernel; the generic scatter-add adds in float32 on the hi plane
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
     finally:
         oracle.set_accum_double(False)
@@ -594,7 +594,7 @@ def test_fuse_views_medium_triangles(sm, oracle, kind, C, iew):
         assert (want.sum(axis=1) > 0.5).sum() > P // 2
         # (Mul behind SMESH_FUSE=strip: the generic scatter-add adds in float32 on the hi plane, as in the tests above)
         import os
-        tol = 5e-3 if kind == "mul" and os.environ.get("SMESH_FUSE") == "strip" else 1e-5
+        tol = 1e-5
         assert_fused_close(group.get(), want, rtol=tol)
         assert_fused_close(single.get(), want, rtol=tol)
     finally:
@@ -612,7 +612,7 @@ def test_fuse_view_user_index_images_take_generic_path(sm, oracle):
         probs = random_probs(rng, *cam.resolution, C)
         agg.fuse_view(r, cam, probs)
         oagg.add(o.render(cam)[0], probs)
-    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("cap", [1, 7, 300])
@@ -643,7 +643,7 @@ def test_render_fragment_queue_overflow(sm, oracle, monkeypatch, cap):
         oagg = oracle.OracleAggregator(P, C)
         for cam, p in zip(cams + cams[:1], probs + probs[:1]):
             oagg.add(o.render(cam)[0], p)
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
     monkeypatch.delenv("SMESH_FRAG_CAP")
@@ -764,7 +764,7 @@ def test_fuse_view_texels_big_triangles(sm, oracle, kind):
             probs = random_probs(rng, *cam.resolution, C)
             agg.fuse_view(r, cam, probs)
             oagg.add(o.render(cam)[0], probs)
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
     # the scratch histogram is all zero again: a plain add() (generic path) still gives the right counts
@@ -774,7 +774,7 @@ def test_fuse_view_texels_big_triangles(sm, oracle, kind):
     idx = r.render(cams[0])[0]
     agg.add(idx, probs)
     oagg2.add(np.asarray(idx), probs)
-    assert_fused_close(agg.get(), oagg2.get(), rtol=2e-5)
+    assert_fused_close(agg.get(), oagg2.get(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("content_match", [False, True])
@@ -858,7 +858,7 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle, monkeypatch, con
     agg.add(idx1b, to_device(probs))
     assert last() == fast and path() == matched
     oagg.add(o.render(cams[1])[0], probs)
-    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
 
 
 def test_harness_shaped_loop_takes_triangle_order_path(sm, oracle):
@@ -906,7 +906,7 @@ def test_harness_shaped_loop_takes_triangle_order_path(sm, oracle):
     assert len(kernels) == len(cams)
     if os.environ.get("SMESH_FUSE") != "strip":
         assert kernels == ["k_fuse_tri"] * len(cams), kernels
-    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
 
 
 @pytest.mark.parametrize("C", [5, 19, 40, 7, 150])
@@ -927,7 +927,7 @@ def test_fuse_view_small_and_big_triangles_interleaved(sm, oracle, C):
             probs = random_probs(rng, *cam.resolution, C)
             agg.fuse_view(r, cam, probs)
             oagg.add(o.render(cam)[0], probs)
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
 
@@ -958,7 +958,7 @@ def test_shuffled_face_order_is_reordered_internally(sm, oracle, C):
         assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
             "k_fuse_tri" if C == 19 else "k_fuse_tri_wide" if os.environ.get("SMESH_FUSE_WIDE") != "0" else "k_fuse_tri_any")
         np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
-    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     # render() + add() on the re-ordered renderer, and bigger triangles (cooperative paths) with the id table
     coarse, cams2 = small_scene(60, 30, 640, 480, views=2)
     perm2 = rng.permutation(len(coarse.faces))
@@ -975,7 +975,7 @@ def test_shuffled_face_order_is_reordered_internally(sm, oracle, C):
             np.testing.assert_array_equal(np.asarray(idx), o2.render(cam)[0])
             agg2.add(idx, probs)
             oagg2.add(np.asarray(idx), probs)
-        assert_fused_close(agg2.get(), oagg2.get(), rtol=2e-5)
+        assert_fused_close(agg2.get(), oagg2.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
 
@@ -1021,7 +1021,7 @@ def test_render_and_add_from_two_threads(sm, oracle):
         oagg = oracle.OracleAggregator(P, C)
         for cam, probs in zip(cams, all_probs):
             oagg.add(o.render(cam)[0], probs)
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
 
@@ -1058,7 +1058,7 @@ def test_degenerate_geometry(sm, oracle):
         probs = random_probs(rng, *cam.resolution, C)
         agg.fuse_view(r, cam, probs)
         oagg.add(oidx, probs)
-    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     # duplicates: the lower id wins everywhere (B-4), so the re-appended copies of faces 0..49 never show up
     assert not np.isin(np.asarray(idx), np.arange(P - 50, P)).any()
 
@@ -1086,7 +1086,7 @@ def test_odd_image_sizes(sm, oracle, res):
             probs = random_probs(rng, W, H, C)
             agg.fuse_view(r, cam, probs)
             oagg.add(oidx, probs)
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
 
@@ -1329,7 +1329,7 @@ def test_fuse_views_texels_with_big_triangles(sm, oracle):
             oagg = oracle.OracleAggregator(P, C, kind)
             for k, cam in enumerate(cams):
                 oagg.add(o.render(cam)[0], probs[k])
-            assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+            assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
         finally:
             oracle.set_accum_double(False)
 
@@ -1363,7 +1363,7 @@ def test_fuse_views_wide_rows_mixed_triangle_sizes(sm, oracle, C):
                 oagg = oracle.OracleAggregator(P, C, kind)
                 for k, cam in enumerate(cams):
                     oagg.add(o.render(cam)[0], probs[k], weights[k])
-                assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+                assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
             finally:
                 oracle.set_accum_double(False)
 
@@ -1394,7 +1394,7 @@ def test_fuse_views_mixed_triangle_sizes_and_image_sizes(sm, oracle, kind):
         oagg = oracle.OracleAggregator(P, C, kind)
         for k, cam in enumerate(cams):
             oagg.add(o.render(cam)[0], probs[k])
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
 
@@ -1420,7 +1420,7 @@ def test_fuse_views_shuffled_faces_and_fallbacks(sm, oracle):
             oagg.add(oidx[k], probs[k])
         if os.environ.get("SMESH_FUSE") != "strip":
             np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     # texel renderer
     tmesh, tcams = small_scene(60, 30, 330, 250, views=3)
     tr = sm.render.texels(tmesh, tcams, 0.6)
@@ -1431,7 +1431,7 @@ def test_fuse_views_shuffled_faces_and_fallbacks(sm, oracle):
     agg.fuse_views(tr, tcams, [to_device(p) for p in probs])
     for k, cam in enumerate(tcams):
         oagg.add(to.render(cam)[0], probs[k])
-    assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
+    assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
     # argument checks
     with pytest.raises(ValueError):
         agg.fuse_views(tr, tcams, probs[:2])
@@ -1458,7 +1458,7 @@ def test_fuse_views_sharded_on_the_device(sm, oracle):
         oagg = oracle.OracleAggregator(P, C)
         for k, cam in enumerate(cams):
             oagg.add(o.render(cam)[0], probs[k])
-        assert_fused_close(agg.get(), oagg.get(), rtol=2e-5)
-        assert_fused_close(hagg.get(), oagg.get(), rtol=2e-5)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
+        assert_fused_close(hagg.get(), oagg.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
