@@ -442,6 +442,8 @@ def main():
     # views; bracketing all of them lowered `value` from 14.3 k to 14.0 k views/s).  The library counts the launches and views
     # inside the bracketed regions itself (smesh_profile_read_ex), so the averages below are over exactly the regions that were timed.
     prof_every = int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "3"))
+    if ranged:
+        prof_every = 1      # (the fusion launches of a held group are cut in `parts` regions: time them all or the sums mean nothing)
     _lib.check(_lib.lib().smesh_profile_sample_every(device, prof_every))
     _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
     barrier()
@@ -512,7 +514,7 @@ def main():
         # which launches those were: a call of n views is cut into launches of 8 / 4 / 2 / 1 views, largest first (the library's
         # rule, smesh_fuse_views); cross-checked against the library's own counters
         mix = {}
-        if B > 1 and prof_mask:
+        if B > 1 and prof_mask and not ranged:
             cap = 8     # smesh_aggregator_max_fused_views (Mul with 41 .. 48 classes: 2 -- not a bench workload)
             cap = min(cap, int(os.environ.get("SMESH_FUSE_VIEWS", "8")))
             for call, i in enumerate(range(args.warmup, total_views, B)):
@@ -585,13 +587,15 @@ def main():
                        "rank0": {"compute_ms": round(compute_ms, 3), "exchange_ms": round(exchange_ms, 3),
                                  "exchange_exposed_ms": round(exposed_ms, 3)},
                        "timed_region_ms": round(1e3 * dt, 3),
-                       "host_syncs_in_timed_region": 1 if (comm is not None or dist is None) else 4,
+                       "host_syncs_in_timed_region": 1 if (comm is not None or dist is None) else 3 + (parts if ranged else 1),
                        "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
             # frac_needed first: the fraction by the bytes the kernel HAS to move (visible pixels' class vectors, records, touched
             # rows once per launch); `frac` is SURVEY.md 8(d)'s formula, which also charges the class vectors of background
             # pixels and a row round trip per view that the kernel does not perform -- it flatters
             "roofline": {"frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4),
                          "kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),
+                         "note": ("N > 1 with the exchange under the fusion: the held views' fusion launches are cut in exchange_parts row ranges "
+                                  "(launches_timed counts every piece); the kernel's roofline is the N = 1 line's") if ranged else None,
                          "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -90,6 +90,13 @@ int smesh_stream_wait(int device, void* producer_stream);
  * owner of a DEVICE buffer can overwrite or free it on that stream without a host synchronisation. */
 int smesh_stream_release(int device, void* consumer_stream);
 int smesh_stream_handle(int device, void** stream);
+/* Completion tokens (new): smesh_token_record marks the library's main stream of `device` behind everything queued so far -- no host
+ * wait; smesh_token_done sets *done = 1 once the device has passed the mark (the token is then spent: do not query it again) and 0 while
+ * it has not.  The asynchronous entry points (smesh_fuse_view(s), smesh_aggregator_add_async / _add_rendered / _add_matched) read their
+ * DEVICE images after they return: a host layer that cannot order the owner's stream behind those reads (smesh_stream_release) keeps
+ * the images alive until a token recorded after the call is done.  semantic_meshes_amd/fusion.py does both. */
+int smesh_token_record(int device, uint64_t* token);
+int smesh_token_done(int device, uint64_t token, int* done);
 /* Time stamps on the library's main stream (new; a harness's view of where a job's device time went without a profiler):
  * smesh_stream_mark records mark `id` (0 .. 15) behind everything queued so far -- no host synchronisation;
  * smesh_stream_mark_elapsed waits for mark `to` and returns the device milliseconds between the two marks. */

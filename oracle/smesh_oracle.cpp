@@ -815,6 +815,8 @@ int smesh_aggregator_add_async(smesh_aggregator_t* a, const void* indices, int i
 int smesh_stream_wait(int, void*) { return SMESH_OK; }   // the oracle has no streams: everything is synchronous
 int smesh_stream_release(int, void*) { return SMESH_OK; }
 int smesh_stream_handle(int, void** s) { if (s) *s = nullptr; return SMESH_OK; }
+int smesh_token_record(int, uint64_t* t) { if (t) *t = 0; return SMESH_OK; }
+int smesh_token_done(int, uint64_t, int* d) { if (d) *d = 1; return SMESH_OK; }
 int smesh_stream_mark(int, int) { return SMESH_OK; }
 int smesh_stream_mark_elapsed(int, int, int, double* ms) { if (ms) *ms = 0.0; return SMESH_OK; }
 // multi-GPU exchange: not part of the CPU restatement (tests sum the shards' raw accumulators themselves)

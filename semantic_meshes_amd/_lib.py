@@ -41,6 +41,8 @@ SIGNATURES = {
     "smesh_stream_wait": (c_int, [c_int, c_void_p]),
     "smesh_stream_release": (c_int, [c_int, c_void_p]),
     "smesh_stream_handle": (c_int, [c_int, P(c_void_p)]),
+    "smesh_token_record": (c_int, [c_int, P(c_u64)]),
+    "smesh_token_done": (c_int, [c_int, c_u64, P(c_int)]),
     "smesh_stream_mark": (c_int, [c_int, c_int]),
     "smesh_stream_mark_elapsed": (c_int, [c_int, c_int, c_int, P(ctypes.c_double)]),
     "smesh_renderer_create_triangles": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_int, P(c_void_p)]),
@@ -113,39 +115,64 @@ _lock = threading.Lock()
 
 
 def _elf_dynamic_strings(path):
-    """(SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read from its dynamic section."""
+    """(SONAME or None, [DT_NEEDED ...]) of a little-endian ELF64 shared object, read from its PT_DYNAMIC segment through the program
+    headers (section headers may be stripped).  Raises ValueError on anything that is not such a file, truncated ones included."""
     import struct
     with open(path, "rb") as f:
         data = f.read()
-    if data[:6] != b"\x7fELF\x02\x01":
-        raise ValueError("not a little-endian ELF64 file")
-    shoff, = struct.unpack_from("<Q", data, 0x28)
-    shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
-    dyn = None
-    for k in range(shnum):
-        name, typ, flags, addr, off, size, link, info, align, entsize = struct.unpack_from("<IIQQQQIIQQ", data, shoff + k * shentsize)
-        if typ == 6:      # SHT_DYNAMIC; sh_link = its string table
-            stroff, strsize = struct.unpack_from("<QQ", data, shoff + link * shentsize + 0x18)
-            dyn = (off, size, stroff)
-            break
-    if dyn is None:
-        return None, []
-    off, size, stroff = dyn
+    try:
+        if data[:6] != b"\x7fELF\x02\x01":
+            raise ValueError("not a little-endian ELF64 file")
+        phoff, = struct.unpack_from("<Q", data, 0x20)
+        phentsize, phnum = struct.unpack_from("<HH", data, 0x36)
+        loads, dyn = [], None
+        for k in range(phnum):
+            typ, flags, off, vaddr, paddr, filesz, memsz, align = struct.unpack_from("<IIQQQQQQ", data, phoff + k * phentsize)
+            if typ == 1:
+                loads.append((vaddr, off, filesz))
+            elif typ == 2:
+                dyn = (off, filesz)
+        if dyn is None:
+            return None, []
+        entries = []
+        for e in range(dyn[0], dyn[0] + dyn[1], 16):
+            tag, val = struct.unpack_from("<qQ", data, e)
+            if tag == 0:
+                break
+            entries.append((tag, val))
+        strtab = next((v for t, v in entries if t == 5), None)        # DT_STRTAB: a virtual address
+        if strtab is None:
+            return None, []
+        stroff = next((off + strtab - vaddr for vaddr, off, filesz in loads if vaddr <= strtab < vaddr + filesz), None)
+        if stroff is None:
+            raise ValueError("DT_STRTAB outside every PT_LOAD segment")
 
-    def cstr(o):
-        end = data.index(b"\0", stroff + o)
-        return data[stroff + o:end].decode()
+        def cstr(o):
+            end = data.index(b"\0", stroff + o)
+            return data[stroff + o:end].decode()
 
-    soname, needed = None, []
-    for e in range(off, off + size, 16):
-        tag, val = struct.unpack_from("<qQ", data, e)
-        if tag == 0:
-            break
-        if tag == 1:
-            needed.append(cstr(val))
-        elif tag == 14:
-            soname = cstr(val)
-    return soname, needed
+        soname, needed = None, []
+        for tag, val in entries:
+            if tag == 1:
+                needed.append(cstr(val))
+            elif tag == 14:
+                soname = cstr(val)
+        return soname, needed
+    except (struct.error, IndexError, UnicodeDecodeError) as e:
+        raise ValueError("malformed ELF file %s: %s" % (path, e))
+
+
+def _preload_note(msg):
+    """Why the torch-bundled HIP runtime was NOT mapped first (SMESH_DEBUG=1 prints it; a process that later imports torch against
+    a second runtime sees no GPU there -- this is the first thing to look at)."""
+    global PRELOAD_NOTE
+    PRELOAD_NOTE = msg
+    if os.environ.get("SMESH_DEBUG"):
+        import sys
+        print("semantic_meshes_amd: " + msg, file=sys.stderr)
+
+
+PRELOAD_NOTE = None
 
 
 def _preload_hip_runtime():
@@ -179,9 +206,11 @@ def _preload_hip_runtime():
     try:
         wanted = [n for n in _elf_dynamic_strings(LIB_PATH)[1] if n.startswith("libamdhip64.so")]
         offered = _elf_dynamic_strings(hip)[0]
-    except (OSError, ValueError, IndexError):
+    except (OSError, ValueError) as e:
+        _preload_note("HIP runtime preload skipped: %s" % e)
         return
     if not wanted or offered != wanted[0]:
+        _preload_note("HIP runtime preload skipped: %s offers SONAME %r, libsmesh_hip.so needs %r" % (hip, offered, wanted[:1]))
         return          # another ROCm major: the linker would map the system runtime beside it anyway
     for name in ("libhsa-runtime64.so", "libamdhip64.so"):
         path = os.path.join(libdir, name)

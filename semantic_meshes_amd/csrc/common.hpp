@@ -53,6 +53,7 @@ struct DeviceCtx {
   unsigned profile_every = 1;   // ... every n-th region of the slot (an event pair costs ~4 us of stream time)
   ProfSlot slots[SMESH_PROF_SLOTS];
   hipEvent_t marks[SMESH_STREAM_MARKS] = {};   // smesh_stream_mark
+  std::vector<hipEvent_t> token_pool;          // smesh_token_record / _done: events waiting for their next use
   std::recursive_mutex mu;
 };
 

@@ -222,6 +222,41 @@ int smesh_stream_mark_elapsed(int device, int from, int to, double* ms) {
   return SMESH_OK;
 }
 
+// Completion tokens: an event behind everything queued so far on the library's streams of `device`.  What the asynchronous entry
+// points need from their caller -- "keep the DEVICE images valid until the kernels have read them" -- becomes checkable without a
+// host wait: the Python layer holds its references to the inputs of add() / fuse_view(s)() until their token is done.
+int smesh_token_record(int device, uint64_t* token) {
+  if (!token) return fail(SMESH_ERR_INVALID, "token is NULL");
+  *token = 0;
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  SMESH_HIP(hipSetDevice(device));
+  hipEvent_t ev = nullptr;
+  if (!ctx->token_pool.empty()) { ev = ctx->token_pool.back(); ctx->token_pool.pop_back(); }
+  else SMESH_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  // the main stream also stands for the exchange stream's reads of the accumulator; images are only ever read on the main stream
+  // (and, for content checksums of foreign index images, on the raster stream, which add_matched waits for itself)
+  SMESH_HIP(hipEventRecord(ev, ctx->stream));
+  *token = (uint64_t)reinterpret_cast<uintptr_t>(ev);
+  return SMESH_OK;
+}
+
+int smesh_token_done(int device, uint64_t token, int* done) {
+  if (!done) return fail(SMESH_ERR_INVALID, "done is NULL");
+  *done = 1;
+  if (!token) return SMESH_OK;
+  DeviceCtx* ctx;
+  SMESH_TRY(get_ctx(device, &ctx));
+  std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+  hipEvent_t ev = reinterpret_cast<hipEvent_t>((uintptr_t)token);
+  const hipError_t e = hipEventQuery(ev);
+  if (e == hipErrorNotReady) { (void)hipGetLastError(); *done = 0; return SMESH_OK; }
+  if (e != hipSuccess) return fail_hip(e, "hipEventQuery", __FILE__, __LINE__);
+  ctx->token_pool.push_back(ev);     // done: the token is spent
+  return SMESH_OK;
+}
+
 int smesh_profile_enable(int device, int enabled) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));

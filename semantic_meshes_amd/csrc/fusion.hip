@@ -2120,7 +2120,7 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
   }
 
   // ---- restore the all-zero histogram (the strip kernel does it itself) ---------------------------
-  if (need_hist && !strip_path(C)) {
+  if (need_hist && !(strip_path(C) && !mul)) {
     if (a->P <= 2 * N) {
       SMESH_HIP(hipMemsetAsync(a->count, 0, a->P * 4, st));
     } else {

@@ -56,7 +56,7 @@ def allreduce_raw(aggregator, group=None, comm=None):
         _lib.check(_lib.lib().smesh_stream_wait(flat.device, ctypes.c_void_p(int(torch.cuda.current_stream(flat.device).cuda_stream))))
         return aggregator
     if hasattr(aggregator, "get_raw_rows"):
-        return allreduce_rows_raw(aggregator, 0, aggregator.primitives, group)
+        return allreduce_rows_raw(aggregator, 0, aggregator.primitives, group)     # (host copies; Mul's (hi, lo) pairs as float64)
     raw = np.ascontiguousarray(aggregator.get_raw(), dtype=np.float32)
     t = torch.from_numpy(raw)
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
@@ -75,6 +75,19 @@ def allreduce_rows_raw(aggregator, row_lo, row_hi, group=None, comm=None):
     if not dist.is_available() or not dist.is_initialized() or row_hi <= row_lo:
         return aggregator
     import torch
+    if dist.get_backend(group) == "nccl" and hasattr(aggregator, "raw_device_array"):
+        # in place in HBM on torch's stream (Mul: the pair folded into the float32 hi plane first -- the exact float64 exchange is
+        # the native path's); the library's streams are ordered behind the collective by an event
+        import ctypes
+        from . import _lib
+        flat = aggregator.raw_device_array(padded=True)
+        S = flat.shape[0] // max(aggregator.primitives, 1)
+        t = torch.as_tensor(flat, device="cuda:%d" % flat.device)
+        if t.data_ptr() != flat.ptr:
+            raise RuntimeError("torch copied the accumulator instead of aliasing it")
+        dist.all_reduce(t[row_lo * S:row_hi * S], op=dist.ReduceOp.SUM, group=group)
+        _lib.check(_lib.lib().smesh_stream_wait(flat.device, ctypes.c_void_p(int(torch.cuda.current_stream(flat.device).cuda_stream))))
+        return aggregator
     if getattr(aggregator, "kind", None) == "Mul":
         v = aggregator.get_raw_rows(row_lo, row_hi, 0).astype(np.float64) + aggregator.get_raw_rows(row_lo, row_hi, 1)
         t = torch.from_numpy(v)

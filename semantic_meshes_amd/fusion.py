@@ -31,6 +31,29 @@ class _MeshAggregator:
         _lib.check(_lib.lib().smesh_aggregator_create(self.primitives, self.classes, _lib.AGG_KINDS[kind],
                                                      self.images_equal_weight, self.device, ctypes.byref(h)))
         self._h = h
+        self._inflight = []     # (completion token, [objects]) of asynchronous calls whose device inputs may still be being read
+
+    def _hold(self, keepalives):
+        """The asynchronous entry points read DEVICE images after they return.  `release_to()` orders the stream `describe()` guessed for
+        their owner behind those reads -- but a tensor that is later freed or re-used on ANOTHER stream or thread (or whose producer
+        exported no stream) could be recycled by its caching allocator while the kernels still read it.  So the aggregator keeps its own
+        references to the inputs of other frameworks until a completion token recorded behind the call is done (checked, without waiting,
+        at the next call).  This library's own DeviceArrays are freed behind its streams and need none."""
+        self._drain()
+        foreign = [k for k in keepalives if k is not None and not isinstance(k, DeviceArray)]
+        if not foreign:
+            return
+        tok = ctypes.c_uint64(0)
+        _lib.check(_lib.lib().smesh_token_record(self.device, ctypes.byref(tok)))
+        self._inflight.append((tok.value, foreign))
+
+    def _drain(self):
+        done = ctypes.c_int(0)
+        while self._inflight:
+            _lib.check(_lib.lib().smesh_token_done(self.device, ctypes.c_uint64(self._inflight[0][0]), ctypes.byref(done)))
+            if not done.value:
+                break
+            self._inflight.pop(0)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
@@ -87,6 +110,7 @@ class _MeshAggregator:
                 self._h, rb._h, ctypes.c_void_p(ip), ctypes.c_void_p(pp), _c64(pstr), pmem,
                 None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H))
             release_to(self.device, streams)
+            self._hold([k1 if pmem == _lib.MEM_DEVICE else None, k2 if (wp is not None and wmem == _lib.MEM_DEVICE) else None])
             return
         if idt.itemsize == 4 and tuple(istr) == (H, 1) and self.match_renders and not self._records_from_image():
             # An index image that went through another framework or numpy (DLPack -> TF -> .numpy() -> add in the reference's
@@ -102,6 +126,8 @@ class _MeshAggregator:
                     None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H, ctypes.byref(matched)))
                 if matched.value:
                     release_to(self.device, streams)
+                    self._hold([k0 if imem == _lib.MEM_DEVICE else None, k1 if pmem == _lib.MEM_DEVICE else None,
+                                k2 if (wp is not None and wmem == _lib.MEM_DEVICE) else None])
                     return
         # Host images are consumed before the call returns (Fusion.h:45-47).  Device images are read asynchronously: this library's own
         # DeviceArrays are freed behind its streams, other frameworks' streams are put behind the reads by release_to() -- so the
@@ -111,6 +137,8 @@ class _MeshAggregator:
             ctypes.c_void_p(pp), _c64(pstr), pmem,
             None if wp is None else ctypes.c_void_p(wp), None if wstr is None else _c64(wstr), wmem, W, H))
         release_to(self.device, streams)
+        self._hold([k0 if imem == _lib.MEM_DEVICE else None, k1 if pmem == _lib.MEM_DEVICE else None,
+                    k2 if (wp is not None and wmem == _lib.MEM_DEVICE) else None])
 
     # class-wide switch for the content check above
     match_renders = os.environ.get("SMESH_MATCH_RENDERS", "1") != "0"
@@ -129,12 +157,14 @@ class _MeshAggregator:
 
     def reset(self):
         _lib.check(_lib.lib().smesh_aggregator_reset(self._h))
+        self._drain()
 
     def get(self):
         """Normalised per-primitive class distribution, fresh float32[P,C] numpy array (Fusion.h:72-76)."""
         out = np.empty((self.primitives, self.classes), np.float32)
         if out.size:
             _lib.check(_lib.lib().smesh_aggregator_get(self._h, out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
+        self._drain()     # (get() waited for the stream: every earlier call's reads are over)
         return out
 
     def get_rows(self, row_lo, row_hi):
@@ -201,6 +231,8 @@ class _MeshAggregator:
             wp = ctypes.c_void_p(wp_)
         _lib.check(_lib.lib().smesh_fuse_view(renderer._h, self._h, ctypes.byref(camera._pod), ctypes.c_void_p(pp), wp, pmem))
         release_to(self.device, streams)
+        if pmem == _lib.MEM_DEVICE:
+            self._hold([k1, k2 if weights_image is not None else None])
 
     def _marshal_views(self, cameras, probs_images, weights_images, what):
         """ctypes arguments of a batch of views: (pods, n, probs pointers, weights pointers or None, memory kind, keep-alives, streams)."""
@@ -243,6 +275,8 @@ class _MeshAggregator:
             return
         _lib.check(_lib.lib().smesh_fuse_views(renderer._h, self._h, pods, n, pptr, wptr, mem))
         release_to(self.device, streams)
+        if mem == _lib.MEM_DEVICE:
+            self._hold(keep)
 
     def fuse_views_ranged(self, renderer, cameras, probs_images, weights_images=None, nparts=4, on_rows=None):
         """`fuse_views` cut by accumulator row range (new functionality; `smesh_fuse_views_begin` / `_continue`): all
@@ -266,6 +300,8 @@ class _MeshAggregator:
             if on_rows is not None and hi.value > lo.value:
                 on_rows(int(lo.value), int(hi.value))
         release_to(self.device, streams)
+        if mem == _lib.MEM_DEVICE:
+            self._hold(keep)
         return ranges
 
     def get_raw_rows(self, row_lo, row_hi, plane=0):

@@ -33,10 +33,11 @@ _live_renderers = weakref.WeakSet()   # MeshAggregator.add looks here for the re
 class _Renderer:
     """Common part of PlyRendererTriangles / PlyRendererTexels (Renderer.h:12-43)."""
 
-    def __init__(self, handle, device):
+    def __init__(self, handle, device, capsules=None):
         self._h = handle
         self.device = device
         self._primitives = None
+        self._capsules = capsules     # what render() returns by default: None = this module's RETURN_CAPSULES (per renderer, not per process)
         _live_renderers.add(self)
 
     def __del__(self):
@@ -59,9 +60,9 @@ class _Renderer:
         uint32 (W,H) with background 0xFFFFFFFF and float32 (W,H) with background +inf, device-resident.
 
         By default the two planes are `DeviceArray`s (`__dlpack__`, `__cuda_array_interface__`, `np.asarray`).  With
-        `capsules=True` (or `semantic_meshes.render.RETURN_CAPSULES = True`, or SMESH_RENDER_CAPSULES=1) they are the
-        `"dltensor"` PyCapsules the reference returns (Renderer.h:37-38), which `tf.experimental.dlpack.from_dlpack`
-        (eval-scannet/eval_scannet.py:211-212) requires; `MeshAggregator.add` takes either."""
+        `capsules=True` (or a renderer made by `semantic_meshes.render.triangles / texels` -- the reference's package name --, or
+        SMESH_RENDER_CAPSULES=1) they are the `"dltensor"` PyCapsules the reference returns (Renderer.h:37-38), which
+        `tf.experimental.dlpack.from_dlpack` (eval-scannet/eval_scannet.py:211-212) requires; `MeshAggregator.add` takes either."""
         if not isinstance(camera, Camera):
             raise TypeError("render() expects a semantic_meshes data.Camera")
         W, H = camera.resolution
@@ -80,7 +81,9 @@ class _Renderer:
         indices = DeviceArray(pi.value, (W, H), np.uint32, self.device, owner=self, on_release=rel_i)
         indices._rendered_by = self   # add(indices, ...) can then reuse what this render left on the device
         depth = DeviceArray(pd.value, (W, H), np.float32, self.device, owner=self, on_release=rel_d)
-        if RETURN_CAPSULES if capsules is None else capsules:
+        if capsules is None:
+            capsules = RETURN_CAPSULES if self._capsules is None else self._capsules
+        if capsules:
             return indices.capsule(), depth.capsule()
         return indices, depth
 
@@ -97,19 +100,19 @@ class _Renderer:
 class PlyRendererTriangles(_Renderer):
     """Triangle primitives: id == ordinal of the face in the mesh (TriangleRenderer.h:41-44,57-60)."""
 
-    def __init__(self, mesh, device=0):
+    def __init__(self, mesh, device=0, capsules=None):
         v, f = _mesh_arrays(mesh)
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().smesh_renderer_create_triangles(v.ctypes.data_as(ctypes.c_void_p), len(v),
                                                              f.ctypes.data_as(ctypes.c_void_p), len(f), device, ctypes.byref(h)))
-        super().__init__(h, device)
+        super().__init__(h, device, capsules)
 
 
 class PlyRendererTexels(_Renderer):
     """Texel primitives (TexturedTriangleRenderer.h:87-182)."""
     is_texel = True      # (MeshAggregator.add: copies of a texel render keep going through the content match)
 
-    def __init__(self, mesh, cameras, texels_per_pixel=0.1, device=0):
+    def __init__(self, mesh, cameras, texels_per_pixel=0.1, device=0, capsules=None):
         v, f = _mesh_arrays(mesh)
         cams = list(cameras.getCameras()) if hasattr(cameras, "getCameras") else list(cameras)
         for c in cams:
@@ -121,7 +124,7 @@ class PlyRendererTexels(_Renderer):
                                                           f.ctypes.data_as(ctypes.c_void_p), len(f),
                                                           ctypes.cast(pods, ctypes.c_void_p), len(cams),
                                                           float(texels_per_pixel), device, ctypes.byref(h)))
-        super().__init__(h, device)
+        super().__init__(h, device, capsules)
         self._num_faces = len(f)
 
     def texel_layout(self):
@@ -133,12 +136,13 @@ class PlyRendererTexels(_Renderer):
         return faces, res, first
 
 
-def triangles(mesh, device=0):
-    """`semantic_meshes.render.triangles(mesh)` (Render.cu:24)."""
-    return PlyRendererTriangles(mesh, device=device)
+def triangles(mesh, device=0, capsules=None):
+    """`semantic_meshes.render.triangles(mesh)` (Render.cu:24).  `capsules`: what the renderer's `render()` returns by default
+    (None: DeviceArrays unless SMESH_RENDER_CAPSULES=1; True: the reference's "dltensor" PyCapsules)."""
+    return PlyRendererTriangles(mesh, device=device, capsules=capsules)
 
 
-def texels(mesh, cameras, texels_per_pixel=0.1, device=0):
+def texels(mesh, cameras, texels_per_pixel=0.1, device=0, capsules=None):
     """`semantic_meshes.render.texels(mesh, colmap|[cameras][, texels_per_pixel])` (Render.cu:20-23);
     default texels_per_pixel 0.1 (TexturedTriangleRenderer.h:87)."""
-    return PlyRendererTexels(mesh, cameras, texels_per_pixel, device=device)
+    return PlyRendererTexels(mesh, cameras, texels_per_pixel, device=device, capsules=capsules)

@@ -61,6 +61,18 @@ def main():
             probs = oracle.synth_probs(W * H, C, synth.probs_seed(7, k), 0.05).reshape(W, H, C)
             agg.add(idxs[k], probs)
         fuse[kind] = agg.get()
+    # Mul once more with the float64-accumulating yardstick: the float32 log-domain state of the reference (LogProb<float>,
+    # Fusion.cu:85) is itself ~1e-4 away from the exact product after four views; the HIP path's (hi, lo) state is compared with this
+    oracle.set_accum_double(True)
+    try:
+        agg = oracle.OracleAggregator(P, C, "mul", 0.5)
+        for k, cam in enumerate(cams):
+            W, H = cam.resolution
+            probs = oracle.synth_probs(W * H, C, synth.probs_seed(7, k), 0.05).reshape(W, H, C)
+            agg.add(idxs[k], probs)
+        fuse["mul_float64_state"] = agg.get()
+    finally:
+        oracle.set_accum_double(False)
     np.savez_compressed(os.path.join(HERE, "cfg1_fuse.npz"), **fuse)
     print("wrote", os.listdir(HERE))
 

@@ -345,8 +345,11 @@ def test_golden_fixtures_on_gpu(sm):
         for a in aggs.values():
             a.add(idx, probs)
     for kind, a in aggs.items():
-        # the fixture was accumulated in float32 like the reference; tolerance covers the summation order
-        assert_fused_close(a.get(), want_fuse[kind], rtol=1e-5, atol=1e-6)
+        # Sum / Summax: the fixture was accumulated in float32, single-threaded, like the reference -- and so does the HIP path: equal bits.
+        # Mul: the fixture of the float64-accumulating yardstick (the float32 log-domain state the reference keeps is itself 1e-4 off
+        # after four views: tests/test_oracle.py checks that fixture against this one)
+        # Sum / Summax: the fixture was accumulated in float32 in pixel order; cfg1's thirty-pixel triangles are summed by a wave each (a tree)
+        assert_fused_close(a.get(), want_fuse["mul_float64_state" if kind == "mul" else kind], rtol=1e-5)
 
 
 def test_texel_renderer_matches_oracle(sm, oracle):
@@ -1258,7 +1261,7 @@ def test_fuse_views_wide_rows_equal_single_calls_bit_for_bit(sm, oracle, kind, C
         if kind != "mul":      # (Mul: the hi plane is re-centred once per launch, so the grouping shows in the last bits)
             np.testing.assert_array_equal(batch.get_raw().view(np.uint32), single.get_raw().view(np.uint32))
             np.testing.assert_array_equal(batch.get_raw().view(np.uint32), oraw.view(np.uint32))
-    mul_tol = 1e-3 if os.environ.get("SMESH_FUSE") == "strip" else 1e-5   # Mul: (hi, lo) state, a view's terms summed in double, against the float64 oracle
+    mul_tol = 1e-5   # Mul: (hi, lo) state, a view's terms summed in double (float64 atomics + one fold per row on the generic path), against the float64 oracle
     assert_fused_close(batch.get(), want, rtol=mul_tol if kind == "mul" else 1e-5)
     if kind == "mul":
         assert_fused_close(batch.get(), single.get(), rtol=mul_tol)
@@ -1288,7 +1291,7 @@ def test_fuse_views_texels_equal_single_calls_bit_for_bit(sm, oracle, kind, C, t
     dp, dw = [to_device(p) for p in probs[:4]], [to_device(w) for w in weights]
     dp = dp + dp[:3] + dp
     batch.fuse_views(r, cams, dp, dw)
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() in ("k_fuse_texel", "k_scatter_strip")
+    assert sm._lib.lib().smesh_last_fuse_kernel().decode() in ("k_fuse_texel", "k_scatter_strip", "k_scatter_flat")   # (SMESH_FUSE=strip: Mul takes the float64-atomic flat path)
     oracle.set_accum_double(kind == "mul")
     try:
         oagg = oracle.OracleAggregator(P, C, kind, 0.5)
@@ -1304,7 +1307,7 @@ def test_fuse_views_texels_equal_single_calls_bit_for_bit(sm, oracle, kind, C, t
     if os.environ.get("SMESH_FUSE") != "strip" and kind != "mul":
         np.testing.assert_array_equal(batch.get_raw().view(np.uint32), single.get_raw().view(np.uint32))
         np.testing.assert_array_equal(batch.get_raw().view(np.uint32), oraw.view(np.uint32))
-    mul_tol = 1e-3 if os.environ.get("SMESH_FUSE") == "strip" else 1e-5     # Mul: (hi, lo) rows, every term folded in double, against the float64 oracle
+    mul_tol = 1e-5     # Mul: (hi, lo) rows, every term folded in double, against the float64 oracle
     assert_fused_close(batch.get(), want, rtol=mul_tol if kind == "mul" else 1e-5)
     assert_fused_close(batch.get(), single.get(), rtol=mul_tol if kind == "mul" else 1e-5)
 

@@ -245,7 +245,7 @@ def test_native_allreduce_rows_world_one_is_an_identity(sm):
     leaves the sums what they were: Sum bit-equal to the job without an exchange, Mul equal in get() (the (hi, lo) pairs are re-split)."""
     from semantic_meshes_amd import comm as smcomm, distributed as smdist, synth
     from helpers import small_scene, assert_fused_close
-    mesh, cams = small_scene(60, 30, 320, 240, views=6)
+    mesh, cams = small_scene(170, 81, 320, 240, views=6)     # (two-pixel triangles: no float atomics, the additions have one order)
     P, C = len(mesh.faces), 19
     renderer = sm.render.triangles(mesh)
     probs = [synth.device_probs(320, 240, C, synth.probs_seed(2, k), 0.05, 0) for k in range(len(cams))]

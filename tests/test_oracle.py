@@ -385,6 +385,20 @@ def test_golden_cfg1_fuse(oracle):
             idx = _unrle(g["idx%d_vals" % k], g["idx%d_lens" % k], (W, H))
             agg.add(idx, oracle.synth_probs(W * H, 5, synth.probs_seed(7, k), 0.05).reshape(W, H, 5))
         np.testing.assert_array_equal(agg.get(), want[kind])
+    # the Mul fixture of the float64-accumulating yardstick (what the HIP path's (hi, lo) state is held to, 1e-5): reproduced bit for
+    # bit, and the float32 log-domain state the reference keeps (LogProb<float>, Fusion.cu:85) lies 1.5e-4 from it after four views
+    oracle.set_accum_double(True)
+    try:
+        agg = oracle.OracleAggregator(10000, 5, "mul", 0.5)
+        for k in range(4):
+            W, H = (int(v) for v in g["cam%d_res" % k])
+            idx = _unrle(g["idx%d_vals" % k], g["idx%d_lens" % k], (W, H))
+            agg.add(idx, oracle.synth_probs(W * H, 5, synth.probs_seed(7, k), 0.05).reshape(W, H, 5))
+        np.testing.assert_array_equal(agg.get(), want["mul_float64_state"])
+    finally:
+        oracle.set_accum_double(False)
+    np.testing.assert_allclose(want["mul"], want["mul_float64_state"], rtol=2e-4, atol=1e-6)
+    assert np.abs(want["mul"] - want["mul_float64_state"]).max() > 1e-5
 
 
 def test_strided_and_threaded_add_agree(oracle):
