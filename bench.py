@@ -66,13 +66,14 @@ def pmc_traffic(workload, kernel_prefix, views_per_launch, group_pipeline=False)
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--no-host-path"]
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--no-host-path",
+                   "--no-pmc"]
             if group_pipeline:
                 cmd.append("--group-pipeline")
             env = dict(os.environ, TMPDIR="/tmp")
             env.pop("RANK", None)
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=420)
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
             except subprocess.TimeoutExpired:
                 return None, "rocprofv3 --pmc %s timed out" % counter
             path = None
@@ -148,8 +149,30 @@ def cpu_baseline(workload, budget_s=20.0):
         done2 += 1
     dt2 = time.perf_counter() - t1
     oracle.set_fast_histogram(False)
+    # cfg1 (10 000 triangles, four 640 x 480 views, five classes -- the reference's own CPU-runnable case) in full
+    cfg1 = None
+    try:
+        m1, c1, C1 = synth.scene("cfg1")
+        r1 = oracle.OracleRenderer(m1.vertices, m1.faces)
+        W1, H1 = c1[0].resolution
+        p1 = [oracle.synth_probs(W1 * H1, C1, synth.probs_seed(1, k)).reshape(W1, H1, C1) for k in range(len(c1))]
+        cfg1 = {}
+        for label, nt, fast in (("port", cores, False), ("optimised_cpu", best, True)):
+            oracle.set_threads(nt)
+            oracle.set_fast_histogram(fast)
+            a1 = oracle.OracleAggregator(len(m1.faces), C1)
+            t = time.perf_counter()
+            for k, cam in enumerate(c1):
+                a1.add(r1.render(cam)[0], p1[k])
+            a1.get()
+            d1 = time.perf_counter() - t
+            cfg1[label] = {"views_per_s": round(len(c1) / d1, 2), "seconds": round(d1, 4), "cores": nt}
+        cfg1["what"] = "cfg1 in full: %d views at %dx%d, %d triangles, %d classes (render + add + one get)" % (len(c1), W1, H1, len(m1.faces), C1)
+    except Exception as e:
+        cfg1 = {"error": str(e)[:160]}
+    oracle.set_fast_histogram(False)
     oracle.set_threads(1)
-    return {"value": round(done / dt, 3), "unit": "views/s", "cores": cores, "kind": "port",
+    return {"value": round(done / dt, 3), "unit": "views/s", "cores": cores, "kind": "port", "cfg1_full": cfg1,
             "sample": "%d of the %s views (render + add), %d OpenMP threads, %.1f s" % (done, workload, cores, dt),
             "optimised_cpu": {"value": round(done2 / dt2, 3), "unit": "views/s", "cores": best,
                               "what": "same port with a dense parallel histogram instead of the reference's serial std::map, "
@@ -250,8 +273,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline", action="store_true", help="also for workloads other than cfg2 (slow: the oracle at that size)")
     ap.add_argument("--no-host-path", action="store_true")
-    ap.add_argument("--pmc", action="store_true",
-                    help="measure roofline.traffic in this run: two extra short passes of this script under rocprofv3 --pmc (about a minute)")
+    ap.add_argument("--pmc", action="store_true", default=None,
+                    help="measure roofline.traffic in this run: two extra short passes of this script under rocprofv3 --pmc (about a minute). "
+                         "Default: on for a one-GPU run of a triangle-renderer workload when rocprofv3 is on PATH")
+    ap.add_argument("--no-pmc", dest="pmc", action="store_false", help="take roofline.traffic from the committed PMC summary instead")
     ap.add_argument("--views-per-call", type=int, default=int(os.environ.get("SMESH_BENCH_VIEWS_PER_CALL", "8")),
                     help="views handed to the library per call (fuse_views; 1 = one fuse_view call per view)")
     ap.add_argument("--exchange-parts", type=int, default=int(os.environ.get("SMESH_BENCH_EXCHANGE_PARTS", "4")),
@@ -270,6 +295,10 @@ def main():
     if args.warmup is None:
         args.warmup = {"cfg5": 4}.get(args.workload, 10)
 
+    if args.pmc is None:
+        import shutil
+        args.pmc = (args.gpus == 1 and "RANK" not in os.environ and args.workload in ("cfg2", "cfg1") and shutil.which("rocprofv3") is not None
+                    and not os.environ.get("SMESH_BENCH_NO_PMC"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -444,6 +473,8 @@ def main():
     prof_every = int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "3"))
     if ranged:
         prof_every = 1      # (the fusion launches of a held group are cut in `parts` regions: time them all or the sums mean nothing)
+    elif B > 1 and args.steps <= 40 and "SMESH_BENCH_PROFILE_EVERY" not in os.environ:
+        prof_every = 1      # short runs (the driver's --steps 20: three groups): every group, so that the average is over >= 3 launches
     _lib.check(_lib.lib().smesh_profile_sample_every(device, prof_every))
     _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
     barrier()

@@ -86,6 +86,18 @@ struct Scratch {
 
 inline uint64_t div_up(uint64_t a, uint64_t b) { return (a + b - 1) / b; }
 
+// Development ablations ("what does the kernel cost without its atomics / its stores / its class-vector loads": WRONG results)
+// exist only in builds with -DSMESH_ABLATION (make ABLATION=1, tools/*ablation*.sh).  In the product build SMESH_ABL() is the
+// constant 0 -- the branches are compiled out of the kernels -- and the SMESH_DBG / SMESH_FDBG / SMESH_RDBG / SMESH_REC_DBG
+// environment variables are not read (tests/test_abi.py looks for their names in the shared library).
+#ifdef SMESH_ABLATION
+#define SMESH_ABL(bits) (bits)
+#define SMESH_ABL_ENV(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define SMESH_ABL(bits) 0
+#define SMESH_ABL_ENV(name) 0
+#endif
+
 // Per-triangle record the rasteriser leaves for the triangle-order fusion (smesh_fuse_view):
 //   kind 1 (small): bounding box at (x0, y0) of at most 8 x 8 pixels; bit (dx * 8 + dy) of `mask` is set when
 //                   the triangle emitted a fragment at (x0 + dx, y0 + dy) (it may still have lost the depth test);

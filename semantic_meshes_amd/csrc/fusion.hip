@@ -32,7 +32,9 @@
 #include <cmath>
 #include <cstdlib>
 #include <new>
+#include <cstring>
 #include <string>
+#include <thread>
 #include <type_traits>
 
 using namespace smesh;
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(kWave) void k_hist_strip(ScatterArgs a) {
       q = L.child[q];
     }
   }
-  if (a.dbg & 2) return;
+  if (SMESH_ABL(a.dbg) & 2) return;
   // (sorting the groups by primitive id first, as the scatter kernel does, was measured slower here:
   // 19.1 vs 15.4 us -- the network costs more than the better-coalesced 4-byte atomics save)
   if (r.root) atomicAdd(&a.count[v], n);
@@ -608,7 +610,7 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
     // ---- 5. order the strip's groups by primitive id (bitonic network, key = prim << 6 | root lane):
     // neighbouring primitives then sit on neighbouring lanes and share cache lines in one atomic instruction
     {
-      const bool sortable = a.P <= (1u << 26) && !(a.dbg & 1);
+      const bool sortable = a.P <= (1u << 26) && !(SMESH_ABL(a.dbg) & 1);
       if (rr.root) F.sprim[rr.gidx] = (sortable ? (v << 6) : ((uint32_t)rr.gidx << 6)) | (uint32_t)l;   // compact the keys
       wave_sync();
       uint32_t key = l < rr.G ? F.sprim[l] : 0xFFFFFFFFu;
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(kWave) void k_scatter_strip(ScatterArgs a) {
       }
       pin(v_next);
       pin(pw_next);
-      if (!(a.dbg & 2)) {
+      if (!(SMESH_ABL(a.dbg) & 2)) {
         if (rows_per_pass) {
           // lane -> (row slot, class): 64 / C sorted groups per pass, C consecutive lanes per accumulator row
           if (f_active) {
@@ -1195,7 +1197,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
     S.hi[v][l] = (uint32_t)(win[v] >> 32);
   }
   unsigned long long vis = __ballot(any_win != 0ull);
-  if (vis == 0ull || (a.dbg & 1)) return;
+  if (vis == 0ull || (SMESH_ABL(a.dbg) & 1)) return;
   wave_sync();
 
   // From here on the wave works on a few triangles' rows at a time; a triangle's pixel sets are read from its owner lane's LDS
@@ -1216,7 +1218,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
     }
 #pragma unroll
     for (int b = 0; b < B; b++)
-      if (t[b] >= 0 && !(a.dbg & 4)) load_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
+      if (t[b] >= 0 && !(SMESH_ABL(a.dbg) & 4)) load_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
     // (a software-pipelined variant -- one pixel stream per triangle across the views, the next pixel's class vector requested
     // before the current one is added -- was slower at cfg5: 423 vs 500 views/s, 124 VGPRs instead of 88)
     for (int v = 0; v < nv; v++) {
@@ -1261,7 +1263,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
           if (have[b]) {
             const uint64_t pix = pix_of(org[b], __ffsll((long long)pm[b]) - 1, Hv);
             pm[b] &= pm[b] - 1ull;
-            if (!(a.dbg & 8)) load_wide<NCH>(probs + pix * C, C, l, p[b]);
+            if (!(SMESH_ABL(a.dbg) & 8)) load_wide<NCH>(probs + pix * C, C, l, p[b]);
             if (weights) wt[b] = weights[pix];
           }
         }
@@ -1308,7 +1310,7 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
     }
 #pragma unroll
     for (int b = 0; b < B; b++)
-      if (t[b] >= 0 && !(a.dbg & 2)) store_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
+      if (t[b] >= 0 && !(SMESH_ABL(a.dbg) & 2)) store_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
   }
 }
 
@@ -1872,7 +1874,7 @@ int launch_strip(const ScatterArgs& a0, int num_cus, hipStream_t st) {
   const dim3 grid(waves), block(kWave);
   // class counts of the benchmark configs get compile-time loops; everything else runs the same
   // kernel with a run-time C (the reference needs a rebuild with -DCLASSES_NUMS for each count)
-  if (a.dbg & 32) {
+  if (SMESH_ABL(a.dbg) & 32) {
     switch (a.C) {
       case 19: hipLaunchKernelGGL((k_scatter_strip<19, KIND, true>), grid, block, lds, st, a); break;
       default: hipLaunchKernelGGL((k_scatter_strip<0, KIND, true>), grid, block, lds, st, a); break;
@@ -2064,7 +2066,7 @@ int add_device(smesh_aggregator* a, const void* d_idx, int idx_dtype, const int6
   args.count = need_hist ? a->count : nullptr;
   args.acc = a->acc; args.N = N; args.P = (uint32_t)a->P; args.C = C; args.S = a->S; args.iew = a->iew;
   args.W = (uint32_t)W; args.H = (uint32_t)H;
-  { const char* d = getenv("SMESH_DBG"); args.dbg = d ? atoi(d) : 0; }
+  args.dbg = SMESH_ABL_ENV("SMESH_DBG");
   set_tiling(args);
 
   // ---- F1 histogram (skipped when the weight does not depend on it) -------------------------
@@ -2263,7 +2265,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     x.ps0 = tv.v[0].ps0; x.ps1 = tv.v[0].ps1;
     x.big_capacity = big_capacity;
     x.tri_blocks = (uint32_t)div_up(F, kWave);
-    { static const int fdbg = getenv("SMESH_FDBG") ? atoi(getenv("SMESH_FDBG")) : 0; x.dbg = fdbg; }
+    { static const int fdbg = SMESH_ABL_ENV("SMESH_FDBG"); x.dbg = fdbg; }
     x.tex_first = nullptr; x.tex_res = nullptr; x.count = nullptr; x.acc_d = nullptr;
     x.prim_id = prim_id;
     x.mid = 0;
@@ -2346,7 +2348,8 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     if (specialised) {
       // medium triangles first (their rows are nobody else's: the main waves leave the rows of queued triangles alone, the tail waves
       // skip what t.mid hands to k_fuse_mid); a few waves per SIMD walking the queues, gone at once when the queues are empty
-      static const int mid_mode = getenv("SMESH_FUSE_MID") ? atoi(getenv("SMESH_FUSE_MID")) : 1;   // (2 / 3: development, half of the hand-over each)
+      static const int mid_mode_env = getenv("SMESH_FUSE_MID") ? atoi(getenv("SMESH_FUSE_MID")) : 1;   // 0: the tail waves take the medium triangles too
+      static const int mid_mode = (mid_mode_env == 0 || SMESH_ABL(1)) ? mid_mode_env : 1;               // (2 / 3: half of the hand-over each -- wrong results, ablation builds only)
       bool listed = true;                              // (records rebuilt from a foreign image carry no list of medium primitives)
       for (int v = 0; v < nviews; v++) listed = listed && views[v].mid_queue;
       if (mid_mode && listed && a->kind != SMESH_AGG_MUL) {      // (Mul's (hi, lo) rows cannot take k_fuse_mid's atomics)
@@ -2747,6 +2750,70 @@ static int finalize_into(smesh_aggregator* a, float* d_out, uint64_t row_lo = 0,
   return SMESH_OK;
 }
 
+// Device -> pageable host memory at link speed.  hipMemcpy into pageable memory is staged by the runtime at ~16 GB/s (76 MB of a
+// cfg2 result: 4.7 ms for a 34 us kernel); here the result crosses PCIe by DMA into a ring of page-locked chunks (~55 GB/s) and a
+// few host threads move each chunk on into the caller's array while the next ones are in flight.
+namespace {
+struct PinnedRing {
+  static constexpr int kChunks = 4;
+  static constexpr size_t kChunkBytes = 8u << 20;
+  void* buf[kChunks] = {};
+  hipEvent_t ev[kChunks] = {};
+  bool ok = false;
+  bool init() {
+    if (ok) return true;
+    for (int i = 0; i < kChunks; i++) {
+      if (hipHostMalloc(&buf[i], kChunkBytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
+      if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return false; }
+    }
+    ok = true;
+    return true;
+  }
+};
+void parallel_copy(char* dst, const char* src, size_t n) {
+  constexpr int kThreads = 6;
+  if (n < (1u << 20)) { memcpy(dst, src, n); return; }
+  std::thread th[kThreads];
+  const size_t per = (n / kThreads + 63) & ~(size_t)63;
+  for (int t = 0; t < kThreads; t++) {
+    const size_t lo = std::min(n, per * (size_t)t), hi = std::min(n, per * (size_t)(t + 1));
+    th[t] = std::thread([=] { if (hi > lo) memcpy(dst + lo, src + lo, hi - lo); });
+  }
+  for (auto& x : th) x.join();
+}
+}  // namespace
+
+// `d_src` (device) -> `out` (pageable or page-locked host memory), ordered behind what is queued on the context's stream; returns
+// when the bytes are in `out`.  Serialised by the context lock (one ring per device context).
+static int copy_to_host(DeviceCtx* ctx, void* out, const void* d_src, size_t bytes) {
+  static PinnedRing rings[64];
+  static const bool off = getenv("SMESH_GET_STAGING") && atoi(getenv("SMESH_GET_STAGING")) == 0;
+  PinnedRing& ring = rings[ctx->device & 63];
+  if (off || bytes < (4u << 20) || !ring.init()) {
+    SMESH_HIP(hipMemcpyAsync(out, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SMESH_HIP(hipStreamSynchronize(ctx->stream));
+    return SMESH_OK;
+  }
+  const size_t CB = PinnedRing::kChunkBytes;
+  const size_t nchunks = (bytes + CB - 1) / CB;
+  for (size_t k = 0; k < nchunks + PinnedRing::kChunks - 1; k++) {
+    if (k < nchunks) {     // chunk k: DMA into its ring slot (the slot's previous tenant, chunk k - kChunks, was drained below)
+      const size_t off_b = k * CB, n = std::min(CB, bytes - off_b);
+      SMESH_HIP(hipMemcpyAsync(ring.buf[k % PinnedRing::kChunks], static_cast<const char*>(d_src) + off_b, n, hipMemcpyDeviceToHost, ctx->stream));
+      SMESH_HIP(hipEventRecord(ring.ev[k % PinnedRing::kChunks], ctx->stream));
+    }
+    if (k + 1 >= (size_t)PinnedRing::kChunks) {     // drain chunk j = k - (kChunks - 1)
+      const size_t j = k + 1 - PinnedRing::kChunks;
+      if (j < nchunks) {
+        const size_t off_b = j * CB, n = std::min(CB, bytes - off_b);
+        SMESH_HIP(hipEventSynchronize(ring.ev[j % PinnedRing::kChunks]));
+        parallel_copy(static_cast<char*>(out) + off_b, static_cast<const char*>(ring.buf[j % PinnedRing::kChunks]), n);
+      }
+    }
+  }
+  return SMESH_OK;
+}
+
 int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind) {
   if (!a || !out) return fail(SMESH_ERR_INVALID, "NULL argument");
   std::lock_guard<std::mutex> g(a->mu);
@@ -2764,9 +2831,7 @@ int smesh_aggregator_get(smesh_aggregator_t* a, float* out, int memkind) {
   }
   SMESH_TRY(a->out_tmp.reserve(bytes));
   SMESH_TRY(finalize_into(a, static_cast<float*>(a->out_tmp.ptr)));
-  SMESH_HIP(hipMemcpyAsync(out, a->out_tmp.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
-  SMESH_HIP(hipStreamSynchronize(ctx->stream));
-  return SMESH_OK;
+  return copy_to_host(ctx, out, a->out_tmp.ptr, bytes);
 }
 
 int smesh_aggregator_get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t row_hi, float* out, int memkind) {
@@ -2787,7 +2852,7 @@ int smesh_aggregator_get_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64_t r
     d_out = static_cast<float*>(a->out_tmp.ptr);
   }
   SMESH_TRY(finalize_into(a, d_out, row_lo, row_hi));
-  if (memkind != SMESH_MEM_DEVICE) SMESH_HIP(hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (memkind != SMESH_MEM_DEVICE) return copy_to_host(ctx, out, d_out, bytes);
   SMESH_HIP(hipStreamSynchronize(ctx->stream));
   return SMESH_OK;
 }

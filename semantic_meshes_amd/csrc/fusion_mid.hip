@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void k_fuse_mid(TriFuseArgs a, TriViews<8> vw,
         if ((c & 15) == l16) { if (c < 16) m0 = t; else if (c < 32) m1 = t; else m2 = t; }
       }
     }
-    if (on && ntot && !(a.dbg & 2)) {
+    if (on && ntot && !(SMESH_ABL(a.dbg) & 2)) {
       float* __restrict__ row = a.acc + (uint64_t)pid * C;
       if (l16 < C && m0 != 0.0f) unsafeAtomicAdd(&row[l16], m0);
       if (l16 + 16 < C && m1 != 0.0f) unsafeAtomicAdd(&row[l16 + 16], m1);

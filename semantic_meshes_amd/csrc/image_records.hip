@@ -266,12 +266,12 @@ __global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restric
     const uint32_t n = wm & 127u, scx = (wm >> 7) & 255u, sty = wm >> 15;
     const unsigned long long pk = (unsigned long long)n | ((unsigned long long)(__umul24(n, x0) + scx) << kMomCountBits) |
                                   ((unsigned long long)(__umul24(n, y0) + sty) << (kMomCountBits + kMomSumBits));
-    if (!(dbg & 4)) atomicAdd(&mom[v], pk);
+    if (!(SMESH_ABL(dbg) & 4)) atomicAdd(&mom[v], pk);
   }
   uint32_t rows = (uint32_t)(sm | (sm >> 32));
   rows = (rows | (rows >> 16)) & 0xFFFFu;
   const int ymin = __builtin_ctz(rows), ymax = 31 - __builtin_clz(rows);
-  if (ymax - ymin < 8 && !(dbg & 2)) {
+  if (ymax - ymin < 8 && !(SMESH_ABL(dbg) & 2)) {
     unsigned long long mask = 0ull;               // bit dx * 8 + dy (common.hpp, TriFrag); the chain's columns are cx, cx + 1, ...
 #pragma unroll
     for (int j = 0; j < kSX; j++)
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_rec_resolve(const uint32_t* __restri
   // left by the previous call or written by this call's pass M: a stale record never carries this call's tag.)
   // (Compacting the others -- a sixth of cfg2's primitives, spread over every wave -- through LDS so that one wave of the workgroup
   // repairs them was measured slower: 13.8 -> 15.4 us.)
-  if (((raw.y >> 16) == tag && (uint32_t)__popcll(smask) == n) || (dbg & 1)) return;
+  if (((raw.y >> 16) == tag && (uint32_t)__popcll(smask) == n) || (SMESH_ABL(dbg) & 1)) return;
   uint4 rec = make_uint4(0u, kPadPending << 16, n, 0u);                      // pending: kind 0, the pixel count parked in the mask
   bool queue = true;
   if (n <= 64u) {
@@ -587,7 +587,7 @@ int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, 
   if (r.moments) {
     // frags may hold the last image's records: pass R rewrites whatever differs
     r.clean = false;
-    static const int dbg = getenv("SMESH_REC_DBG") ? atoi(getenv("SMESH_REC_DBG")) : 0;   // development ablation (timing only: wrong results)
+    static const int dbg = SMESH_ABL_ENV("SMESH_REC_DBG");   // development ablation (timing only: wrong results; -DSMESH_ABLATION builds)
     const uint32_t strips_y = (uint32_t)div_up(H, kTY), nstrips = (uint32_t)div_up(W, kSX) * strips_y;
     const uint32_t strips_per_xcd = (uint32_t)div_up(nstrips, 8);
     hipLaunchKernelGGL(k_rec_moments, dim3(strips_per_xcd * 8), dim3(kWave), 0, st, d_idx, (uint32_t)W, (uint32_t)H, (uint32_t)P, strips_y, nstrips,

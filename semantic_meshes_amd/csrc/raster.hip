@@ -477,7 +477,7 @@ __device__ __forceinline__ unsigned long long shade_key(const RasterArgs& a, uin
 __device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri& t, int x, int y) {
   const unsigned long long key = shade_key(a, f, t, x, y);
   if (key == kNullKey) return;
-  if (a.dbg & 1) { if (key == 12345ull) a.keys[0] = key; return; }
+  if (SMESH_ABL(a.dbg) & 1) { if (key == 12345ull) a.keys[0] = key; return; }
   atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
 }
 
@@ -507,14 +507,14 @@ __global__ void k_raster_small(RasterArgs a) {
       push_mid(a, f, bw * bh);
       rec.kind = 2;
       rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
-    } else if (!(a.dbg & 2)) {
+    } else if (!(SMESH_ABL(a.dbg) & 2)) {
       unsigned long long mask = 0ull;
       for (int dx = 0; dx < bw; dx++)
         for (int dy = 0; dy < bh; dy++) {
           const unsigned long long key = shade_key(a, f, t, t.x0 + dx, t.y0 + dy);
           if (key != kNullKey) {
             mask |= 1ull << (dx * 8 + dy);
-            if (!(a.dbg & 1)) atomicMin(&a.keys[key_index((uint32_t)(t.x0 + dx), (uint32_t)(t.y0 + dy), a.H)], key);
+            if (!(SMESH_ABL(a.dbg) & 1)) atomicMin(&a.keys[key_index((uint32_t)(t.x0 + dx), (uint32_t)(t.y0 + dy), a.H)], key);
           }
         }
       rec.kind = mask ? 1 : 0;
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(256) void k_raster_big(RasterArgs a, uint32_t chunk
           const int y = t.y0 + cy + ty;
           if (y > t.y1) continue;
           const unsigned long long key = shade_piece_key(a, f, pc, x, y);
-          if (key != kNullKey && !(a.dbg & 1)) atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
+          if (key != kNullKey && !(SMESH_ABL(a.dbg) & 1)) atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
         }
       }
     }
@@ -631,7 +631,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
         const uint32_t hs = atomicAdd(a.big_count + 2, 1u);
         if (hs < a.big_capacity) a.huge_queue[hs] = (uint32_t)f;
       }
-    } else if (!(a.dbg & 2)) {
+    } else if (!(SMESH_ABL(a.dbg) & 2)) {
       // one flattened loop over the box (trip count bw * bh, not max bw x max bh over the wave's lanes)
       const int area = bw * bh;
       int dx = 0, dy = 0;
@@ -648,7 +648,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
       }
     }
   }
-  if (a.dbg & 4) { if (a.frags && f < a.F) { rec.mask = cover; a.frags[f] = rec; } return; }   // ablation: setup + coverage only
+  if (SMESH_ABL(a.dbg) & 4) { if (a.frags && f < a.F) { rec.mask = cover; a.frags[f] = rec; } return; }   // ablation: setup + coverage only
   // split the box at the tile borders: columns dx < bx / rows dy < by belong to tile (tx0, ty0)
   const uint32_t tx0 = (uint32_t)t.x0 / kQW, ty0 = (uint32_t)t.y0 / kQH;
   const int bx = (int)(tx0 + 1) * kQW - t.x0, by = (int)(ty0 + 1) * kQH - t.y0;
@@ -662,7 +662,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   const Claim4 c = wave_claim_prepare4(T0, n0 | (n1 << 16), n2 | (n3 << 16));
   const uint32_t tot0 = c.tot01 & 0xFFFFu, tot1 = c.tot01 >> 16, tot2 = c.tot23 & 0xFFFFu, tot3 = c.tot23 >> 16;
   uint32_t g0 = 0u, g1 = 0u, g2 = 0u, g3 = 0u;
-  if (!(a.dbg & 16) && cover != 0ull && lane == c.leader) {   // (ablation bit 16: grouping without the reservations)
+  if (!(SMESH_ABL(a.dbg) & 16) && cover != 0ull && lane == c.leader) {   // (ablation bit 16: grouping without the reservations)
     if (tot0) g0 = atomicAdd(&a.q.count[T0 * kQSub + sub], tot0);
     if (tot1) g1 = atomicAdd(&a.q.count[(T0 + a.q.tiles_y) * kQSub + sub], tot1);
     if (tot2) g2 = atomicAdd(&a.q.count[(T0 + 1u) * kQSub + sub], tot2);
@@ -676,7 +676,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   uint32_t e2 = sq2 + (uint32_t)__shfl((int)g2, c.leader) + (c.pre23 & 0xFFFFu);
   uint32_t e3 = sq3 + (uint32_t)__shfl((int)g3, c.leader) + (c.pre23 >> 16);
   unsigned long long mask = 0ull;
-  if (a.dbg & 8) cover = 0ull;   // ablation: setup + coverage + slot reservation, no depth / stores
+  if (SMESH_ABL(a.dbg) & 8) cover = 0ull;   // ablation: setup + coverage + slot reservation, no depth / stores
   for (unsigned long long m = cover; m; m &= m - 1ull) {
     const int bit = __ffsll((long long)m) - 1;
     const int dx = bit >> 3, dy = bit & 7;
@@ -700,7 +700,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
     const uint32_t e = hy ? (hx ? e3 : e2) : (hx ? e1 : e0);
     const uint32_t lim = (hy ? (hx ? sq3 : sq2) : (hx ? sq1 : sq0)) + a.q.cap;
     e0 += (!hx && !hy) ? 1u : 0u; e1 += (hx && !hy) ? 1u : 0u; e2 += (!hx && hy) ? 1u : 0u; e3 += (hx && hy) ? 1u : 0u;
-    if (a.dbg & 1) continue;
+    if (SMESH_ABL(a.dbg) & 1) continue;
     // pixel inside its tile: (x mod 32) * 64 + (y mod 64)
     const uint16_t pin = (uint16_t)((((uint32_t)x & (kQW - 1)) * kQH) | ((uint32_t)y & (kQH - 1)));
     if (e < lim) {
@@ -721,7 +721,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   // the sub-rectangle) and samples the triangle does not cover store the null key -- no per-fragment bookkeeping.
   // All reservations of the wave are issued first, by the owner lanes: one memory round trip, not one per triangle.
   uint32_t rb0 = 0u, rb1 = 0u, rb2 = 0u, rb3 = 0u, rb4 = 0u, rb5 = 0u;   // queue bases of this lane's (<= 3 x 2) sub-rectangles
-  if (medium && !(a.dbg & 1)) {
+  if (medium && !(SMESH_ABL(a.dbg) & 1)) {
     const int tX0 = t.x0 / kQW, tY0 = t.y0 / kQH;
     const int ntx = t.x1 / kQW - tX0 + 1, nty = t.y1 / kQH - tY0 + 1;
     auto reserve = [&](int j) -> uint32_t {
@@ -778,7 +778,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
       const uint32_t tb = jt == 0 ? sb0 : jt == 1 ? sb1 : jt == 2 ? sb2 : jt == 3 ? sb3 : jt == 4 ? sb4 : sb5;
       const uint32_t slot = tb + (uint32_t)((x - xlo) * hy + (y - ylo));
       const uint32_t tile = (uint32_t)jx * a.q.tiles_y + (uint32_t)jy;
-      if (!in_box || (a.dbg & 1)) continue;
+      if (!in_box || (SMESH_ABL(a.dbg) & 1)) continue;
       if (slot < a.q.cap) {
         const uint64_t e = ((uint64_t)tile * kQSub + sub) * a.q.cap + slot;
         a.q.key[e] = key;
@@ -1246,7 +1246,7 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
   a.huge_queue = vs.huge_queue;
   a.frags = r->side[side].frags;
-  { static const int rdbg = getenv("SMESH_RDBG") ? atoi(getenv("SMESH_RDBG")) : 0; a.dbg = rdbg; }
+  { static const int rdbg = SMESH_ABL_ENV("SMESH_RDBG"); a.dbg = rdbg; }
   a.q = FragQueues();
   a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~kMinWaves waves
   static const uint64_t min_waves = getenv("SMESH_RASTER_MIN_WAVES") ? (uint64_t)std::max(1, atoi(getenv("SMESH_RASTER_MIN_WAVES"))) : 2048u;

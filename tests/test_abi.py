@@ -48,6 +48,15 @@ def test_oracle_library_exports_every_declared_symbol(oracle):
     assert lib.smesh_backend() == b"oracle-cpu"
 
 
+def test_product_library_has_no_wrong_result_switches(hip_lib):
+    """The development ablations (kernels without their atomics / stores / loads: wrong results, timing only) are compiled out of the
+    product build and their environment variables are not read: the names do not even occur in the shared library (VERDICT r3 #8)."""
+    from semantic_meshes_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for name in (b"SMESH_DBG", b"SMESH_FDBG", b"SMESH_RDBG", b"SMESH_REC_DBG"):
+        assert name + b"\0" not in blob and name not in blob, name
+
+
 def test_python_signature_table_matches_header():
     from semantic_meshes_amd import _lib
     assert sorted(_lib.SIGNATURES) == declared_symbols()

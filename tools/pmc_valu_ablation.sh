@@ -1,3 +1,4 @@
+# NEEDS an ablation build of the library: make -C semantic_meshes_amd/csrc clean && make -C semantic_meshes_amd/csrc -j8 ABLATION=1
 # VALU instructions per wave of k_raster_frag_group under the SMESH_RDBG ablation bits (instruction counts add up; times do not).
 tag=$1; out=gpurun_out/$tag; mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for d in 0 2 4 24 8 1; do

@@ -1,3 +1,4 @@
+# NEEDS an ablation build of the library: make -C semantic_meshes_amd/csrc clean && make -C semantic_meshes_amd/csrc -j8 ABLATION=1
 # k_raster_frag_group under the SMESH_RDBG ablation bits (development; results are wrong by design when a bit is set).
 # usage: bash tools/raster_ablation.sh <tag>
 tag=$1; out=gpurun_out/$tag; mkdir -p $out; cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
