@@ -465,6 +465,11 @@ def main():
     prof_mask = 0xFF if os.environ.get("SMESH_BENCH_PROFILE_ALL") else ((1 << _lib.PROF_FUSE_SCATTER) | (1 << _lib.PROF_EXCHANGE))
     if os.environ.get("SMESH_BENCH_NO_PROFILE"):   # experiment: what do the HIP events around the kernel cost?
         prof_mask = 0
+    if ranged and not os.environ.get("SMESH_BENCH_PROFILE_ALL"):
+        # N > 1 with the exchange under the fusion: the held views' fusion is cut in `parts` x groups launches, and an event pair around
+        # each of them keeps the stream idle ~10 us (measured: 12 pairs = 0.1 ms of a 1.7 ms region).  Only the collectives are timed here;
+        # the kernel's roofline is the N = 1 line's.
+        prof_mask = 1 << _lib.PROF_EXCHANGE
     # HIP events on the library's stream around every 8th launch of the dominant kernel when every view is its own call (an event
     # pair costs ~4 us of stream time = 5 % of a cfg2 view); with fuse_views around the fusion launches of every THIRD group, the
     # first one included (measured: the two events of a group keep the stream idle for 2 x 6 us = 2 % of a group of eight cfg2
@@ -509,12 +514,16 @@ def main():
 
     t1 = time.perf_counter()
     fused = agg.get() if exchange == "allreduce" else agg.get_rows(*owned)
-    get_ms = 1e3 * (time.perf_counter() - t1)
+    get_first_ms = 1e3 * (time.perf_counter() - t1)     # (the first get() of the process also allocates its page-locked landing buffer)
     annotated = int((fused.sum(axis=1) > 0.9).sum())
     if os.environ.get("SMESH_BENCH_DUMP") and rank == 0 and exchange == "allreduce":
         # (tests: a sample of the fused rows, to be compared with a single-process fusion of the same views)
         sample_rows = np.unique(np.linspace(0, max(P - 1, 0), 4096).astype(np.int64))
         np.savez(os.environ["SMESH_BENCH_DUMP"], rows=sample_rows, fused=fused[sample_rows])
+    del fused
+    t1 = time.perf_counter()
+    fused = agg.get() if exchange == "allreduce" else agg.get_rows(*owned)     # ... which the next result of that size recycles
+    get_ms = 1e3 * (time.perf_counter() - t1)
     del fused
     nranks_reported = world
     if comm is not None:
@@ -619,14 +628,15 @@ def main():
                                  "exchange_exposed_ms": round(exposed_ms, 3)},
                        "timed_region_ms": round(1e3 * dt, 3),
                        "host_syncs_in_timed_region": 1 if (comm is not None or dist is None) else 3 + (parts if ranged else 1),
-                       "get_ms": round(get_ms, 2), "annotated_primitives": annotated},
+                       "get_ms": round(get_ms, 2), "get_first_ms": round(get_first_ms, 2), "annotated_primitives": annotated},
             # frac_needed first: the fraction by the bytes the kernel HAS to move (visible pixels' class vectors, records, touched
             # rows once per launch); `frac` is SURVEY.md 8(d)'s formula, which also charges the class vectors of background
             # pixels and a row round trip per view that the kernel does not perform -- it flatters
             "roofline": {"frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4),
                          "kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),
-                         "note": ("N > 1 with the exchange under the fusion: the held views' fusion launches are cut in exchange_parts row ranges "
-                                  "(launches_timed counts every piece); the kernel's roofline is the N = 1 line's") if ranged else None,
+                         "note": ("N > 1 with the exchange under the fusion: the fusion launches are not bracketed with events here (an event pair "
+                                  "around each of exchange_parts x groups launches costs what the overlap saves); the kernel's roofline is the "
+                                  "N = 1 line's") if ranged else None,
                          "bound": "hbm",
                          "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,

@@ -34,6 +34,7 @@
 #include <new>
 #include <cstring>
 #include <string>
+#include <sys/mman.h>
 #include <thread>
 #include <type_traits>
 
@@ -1955,6 +1956,7 @@ struct smesh_aggregator {
 int smesh_aggregator_join_exchange(smesh_aggregator* a);
 int smesh_aggregator_refuse_scattered(smesh_aggregator* a, const char* what);
 static int ensure_acc_d(smesh_aggregator* a);
+static void copy_ring_prepare(DeviceCtx* ctx);
 
 bool smesh_aggregator_can_fuse_triangles(smesh_aggregator* a, uint64_t F);
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
@@ -2301,7 +2303,9 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     t.tri_blocks = (uint32_t)div_up(f_hi - f_lo, tpb);
   }
   static const uint32_t big_per_cu = getenv("SMESH_BIG_WAVES") ? (uint32_t)std::max(1, atoi(getenv("SMESH_BIG_WAVES"))) : 16u;
-  const uint32_t big_waves = big_per_cu * (uint32_t)std::max(1, ctx->num_cus);    // one wave per queued big triangle at a time; they exit at once if the queue is empty
+  // one wave per queued big triangle at a time; they exit at once if the queue is empty.  A launch over one of `nparts` triangle
+  // ranges takes its share of them (every one of its waves still walks the whole queue and keeps the triangles of its range).
+  const uint32_t big_waves = std::max((uint32_t)std::max(1, ctx->num_cus), big_per_cu * (uint32_t)std::max(1, ctx->num_cus) / (uint32_t)nparts);
   const dim3 grid(t.tri_blocks + big_waves), block(kWave);
   const dim3 tgrid(t.tri_blocks), bgrid(big_waves);                        // any-C paths: big triangles in a second launch
   if (!specialised && part == 0) SMESH_TRY(mul_recentre(a));   // (a pass over ALL rows: never beside the exchange of a finished range)
@@ -2612,6 +2616,7 @@ int smesh_aggregator_create(uint64_t P, uint32_t C, int kind, float iew, int dev
     delete a;
     return fail_hip(e, "aggregator allocation", __FILE__, __LINE__);
   }
+  if (acc_bytes >= (4u << 20)) copy_ring_prepare(ctx);
   *out = a;
   return SMESH_OK;
 }
@@ -2785,11 +2790,27 @@ void parallel_copy(char* dst, const char* src, size_t n) {
 
 // `d_src` (device) -> `out` (pageable or page-locked host memory), ordered behind what is queued on the context's stream; returns
 // when the bytes are in `out`.  Serialised by the context lock (one ring per device context).
+static PinnedRing g_rings[64];
+// (called when an aggregator with a result of 4 MB and more is created: the ring is not allocated inside somebody's first get())
+static void copy_ring_prepare(DeviceCtx* ctx) { (void)g_rings[ctx->device & 63].init(); }
+
 static int copy_to_host(DeviceCtx* ctx, void* out, const void* d_src, size_t bytes) {
-  static PinnedRing rings[64];
   static const bool off = getenv("SMESH_GET_STAGING") && atoi(getenv("SMESH_GET_STAGING")) == 0;
-  PinnedRing& ring = rings[ctx->device & 63];
-  if (off || bytes < (4u << 20) || !ring.init()) {
+  PinnedRing& ring = g_rings[ctx->device & 63];
+  if (!off && bytes >= (4u << 20)) {
+    // a fresh numpy array is untouched memory: 19 000 first-touch page faults for a cfg2 result cost more than the transfer.  Ask
+    // for transparent huge pages on its page-aligned interior (a no-op where THP is off or the range is already populated).
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(out) + (2u << 20) - 1) & ~(uintptr_t)((2u << 20) - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(out) + bytes) & ~(uintptr_t)((2u << 20) - 1);
+    if (hi > lo) (void)madvise(reinterpret_cast<void*>(lo), hi - lo, MADV_HUGEPAGE);
+  }
+  bool pinned = false;     // page-locked destination (semantic_meshes_amd/device.py: result_empty): DMA straight into it
+  {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, out) == hipSuccess) pinned = attr.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();
+  }
+  if (off || pinned || bytes < (4u << 20) || !ring.init()) {
     SMESH_HIP(hipMemcpyAsync(out, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SMESH_HIP(hipStreamSynchronize(ctx->stream));
     return SMESH_OK;

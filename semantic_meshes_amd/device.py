@@ -7,6 +7,7 @@ memory that exposes `__cuda_array_interface__` (the protocol ROCm builds of torc
 and converts to numpy on request.
 """
 import ctypes
+import os
 
 import numpy as np
 
@@ -183,6 +184,52 @@ def pinned_empty(shape, dtype=np.float32):
     _lib.check(_lib.lib().smesh_host_malloc(max(n, 1), ctypes.byref(p)))
     buf = (ctypes.c_uint8 * max(n, 1)).from_address(p.value)   # numpy keeps `buf` alive as the base of every view
     weakref.finalize(buf, _free_pinned, p.value)
+    return np.frombuffer(buf, dtype=dtype, count=n // dtype.itemsize).reshape(shape)
+
+
+# Results (get(), get_rows(), get_raw()) land in page-locked host memory that is RECYCLED: a fresh pageable array of a cfg2 result
+# (76 MB) costs 3.8 ms of first-touch page faults before a byte has crossed PCIe, a page-locked one is written by DMA at link speed
+# (1.4 ms) -- but allocating page-locked memory is slow (tens of ms), so a buffer goes back to a free list when the array that was
+# handed out (and every view of it) is gone, and the next result of that size takes it.  The caller still owns a fresh array each time.
+_result_free = {}            # nbytes -> [pointers of free buffers]
+_result_live = [0]           # page-locked bytes handed out or parked
+_RESULT_MIN = 4 << 20
+_RESULT_LIMIT = int(os.environ.get("SMESH_RESULT_POOL_MB", "4096")) << 20
+_RESULT_KEEP = 2             # free buffers kept per size
+
+
+def _recycle_result(n, ptr):
+    free = _result_free.setdefault(n, [])
+    if len(free) < _RESULT_KEEP:
+        free.append(ptr)
+    else:
+        _result_live[0] -= n
+        _free_pinned(ptr)
+
+
+def result_empty(shape, dtype=np.float32):
+    """An uninitialised numpy array for a result that is about to be copied out of HBM: page-locked and recycled when it is large
+    (see above), plain `np.empty` otherwise or when SMESH_RESULT_POOL_MB worth of such arrays are alive."""
+    import weakref
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if n < _RESULT_MIN or _RESULT_LIMIT <= 0:
+        return np.empty(shape, dtype)
+    free = _result_free.get(n)
+    if free:
+        ptr = free.pop()
+    else:
+        if _result_live[0] + n > _RESULT_LIMIT:
+            return np.empty(shape, dtype)
+        p = ctypes.c_void_p()
+        try:
+            _lib.check(_lib.lib().smesh_host_malloc(n, ctypes.byref(p)))
+        except RuntimeError:
+            return np.empty(shape, dtype)
+        ptr = p.value
+        _result_live[0] += n
+    buf = (ctypes.c_uint8 * n).from_address(ptr)
+    weakref.finalize(buf, _recycle_result, n, ptr)
     return np.frombuffer(buf, dtype=dtype, count=n // dtype.itemsize).reshape(shape)
 
 

@@ -9,7 +9,7 @@ import ctypes
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray, describe, release_to
+from .device import DeviceArray, describe, release_to, result_empty
 
 import os
 
@@ -161,7 +161,7 @@ class _MeshAggregator:
 
     def get(self):
         """Normalised per-primitive class distribution, fresh float32[P,C] numpy array (Fusion.h:72-76)."""
-        out = np.empty((self.primitives, self.classes), np.float32)
+        out = result_empty((self.primitives, self.classes), np.float32)
         if out.size:
             _lib.check(_lib.lib().smesh_aggregator_get(self._h, out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
         self._drain()     # (get() waited for the stream: every earlier call's reads are over)
@@ -171,7 +171,7 @@ class _MeshAggregator:
         """`get()` for the rows [row_lo, row_hi) only (row_lo a multiple of 4): what a rank owns after
         `Communicator.reduce_scatter` (new functionality)."""
         row_lo, row_hi = int(row_lo), int(row_hi)
-        out = np.empty((max(row_hi - row_lo, 0), self.classes), np.float32)
+        out = result_empty((max(row_hi - row_lo, 0), self.classes), np.float32)
         _lib.check(_lib.lib().smesh_aggregator_get_rows(self._h, row_lo, row_hi, out.ctypes.data_as(ctypes.c_void_p), _lib.MEM_HOST))
         return out
 

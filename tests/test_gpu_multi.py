@@ -288,8 +288,7 @@ def test_bench_under_the_drivers_launcher_world_one(variant):
     assert rr[0][0] == 0 and rr[-1][1] == 10000 and all(a[1] == b[0] for a, b in zip(rr, rr[1:]))
     assert cfg["compute_ms"] > 0 and cfg["exchange_exposed_ms"] >= 0 and cfg["exchange_ms"] >= 0
     assert cfg["compute_ms"] + cfg["exchange_exposed_ms"] <= cfg["timed_region_ms"] * 1.05
-    assert out["roofline"]["regions_in_timed_loop"] == 8 and out["roofline"]["regions_timed"] == 8 and out["roofline"]["views_timed"] == 16
-    assert 0 < out["roofline"]["frac"] < 1.5
+    assert out["roofline"]["regions_timed"] == 0 and out["roofline"]["note"]      # (no event pairs around the cut fusion launches: see the note)
 
 
 @pytest.mark.parametrize("C,res", [(19, (320, 240)), (19, (333, 257)), (5, (37, 29)), (40, (320, 240)), (150, (320, 240))])
