@@ -315,6 +315,14 @@ const char* smesh_last_fuse_kernel(void);
  * "scatter" (atomic scatter-add: what the triangle-order kernels do not take), "none".  For reporting. */
 const char* smesh_last_add_path(void);
 
+/* Diagnostics of the rasteriser's size classes (new, no reference counterpart; TriangleRenderer.h:92 leaves every triangle to one
+ * DeviceMutexRasterizer).  `huge_stage_needed`: 0 if the library can PROVE from the mesh's bounding box and longest edge that, seen
+ * from `camera`, no triangle crosses the near plane or has a screen box beyond 64 pixels a side -- it then leaves out the launch
+ * that rasterises such triangles; 1 otherwise.  `queue_lengths` (may be NULL): after r's last smesh_renderer_render /
+ * _render_device (waits for it), [0] triangles with a box over 8 x 8 pixels, [1] nonzero if fragment queues overflowed, [2] of
+ * [0], those beyond 64 pixels a side or clipped at the near plane, [3] of [0], those of at most 256 box pixels. */
+int smesh_renderer_render_stats(smesh_renderer_t* r, const smesh_camera_t* camera, int* huge_stage_needed, uint32_t queue_lengths[4]);
+
 /* ---- timing hooks (tracing) -------------------------------------------- */
 /* `slot_mask` is a bitmask of SMESH_PROF_* slots (bit s = slot s; 0 = off, 0xFF = all).
  * For every enabled slot the library brackets the kernels with HIP events on its own stream.

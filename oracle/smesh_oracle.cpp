@@ -799,6 +799,11 @@ int smesh_aggregator_add_matched(smesh_aggregator_t*, smesh_renderer_t*, const v
   return SMESH_OK;
 }
 int smesh_renderer_seal_render(smesh_renderer_t*, const uint32_t*) { return SMESH_OK; }
+int smesh_renderer_render_stats(smesh_renderer_t*, const smesh_camera_t*, int* needed, uint32_t q[4]) {   // (the oracle has one loop for every triangle)
+  if (needed) *needed = 1;
+  if (q) q[0] = q[1] = q[2] = q[3] = 0u;
+  return SMESH_OK;
+}
 const char* smesh_last_fuse_kernel(void) { return "oracle"; }
 const char* smesh_last_add_path(void) { return "oracle"; }
 int smesh_aggregator_add_rendered(smesh_aggregator_t* a, smesh_renderer_t*, const uint32_t* idx, const float* probs,

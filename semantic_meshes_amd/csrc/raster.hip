@@ -1074,6 +1074,9 @@ struct smesh_renderer {
   uint64_t V = 0, F = 0, num_primitives = 0;
   float* verts = nullptr;          // float32[V*3]
   int32_t* faces = nullptr;        // int32[F*3]
+  // Host-side summary of the mesh (create_common): the box of its vertices and its longest edge -- what no_huge_possible() needs to
+  // prove, per camera, that the queue of k_raster_huge stays empty.  valid = every vertex finite, at least one usable face.
+  struct Bounds { bool valid = false; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, max_edge = 0; } bounds;
   uint32_t* prim_id = nullptr;     // [F] primitive id per triangle position, when the triangles were re-ordered (else null)
   // What a render in flight needs besides the per-triangle records, per view slot: smesh_fuse_views rasterises up to
   // kMaxGroup views in the same launches (slots beyond 0 are allocated on first use); every other entry point uses slot 0.
@@ -1132,6 +1135,7 @@ struct smesh_renderer {
   unsigned long long* d_hash = nullptr;
   hipEvent_t hash_ev[kRecordSides] = {};   // recorded on the main stream behind the kernel that writes d_hash[s]
   Scratch match_stage;             // device copy of a host index image that is being looked up
+  int last_render_side = 0;        // the side render_into() filled last (smesh_renderer_render_stats)
   bool raster_pending = false;     // work queued on the raster stream since the last synchronisation
   bool main_pending = false;       // renderer state (keys, scratch) used on the main stream since then
   std::mutex mu;
@@ -1167,6 +1171,8 @@ int plane_checksum(DeviceCtx* ctx, hipStream_t st, const uint32_t* d_img, uint64
 }  // namespace
 
 namespace {
+bool no_huge_possible(const smesh_renderer* r, const smesh_camera_t* cam);
+void mesh_bounds(const float* v, uint64_t V, const int32_t* f, uint64_t F, smesh_renderer::Bounds& b);
 
 int ensure_keys(smesh_renderer::ViewScratch& vs, uint64_t W, uint64_t H, hipStream_t st) {
   const uint64_t N = div_up(W, 4) * div_up(H, 4) * 16;   // 4 x 4 blocked layout, padded
@@ -1269,6 +1275,7 @@ uint32_t frag_groups(uint64_t F, int views, uint32_t tpw) {
 int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, float* d_depth, hipStream_t st = nullptr,
                 int side = 0) {
   DeviceCtx* ctx = r->ctx;
+  r->last_render_side = side;
   if (!st) {
     // plain render()/render_device(): main stream, after whatever smesh_fuse_view left on the raster stream
     st = ctx->stream;
@@ -1300,7 +1307,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
       hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(div_up(r->F, a.tpw), 4)), dim3(256), 0, st, a);
       SMESH_HIP(hipGetLastError());
       const uint32_t ntiles = (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
-      hipLaunchKernelGGL(k_raster_huge, dim3(std::min<uint32_t>(ntiles, 2u * (uint32_t)ctx->num_cus)), dim3(256), 0, st, a, ntiles);
+      if (!no_huge_possible(r, cam)) hipLaunchKernelGGL(k_raster_huge, dim3(std::min<uint32_t>(ntiles, 2u * (uint32_t)ctx->num_cus)), dim3(256), 0, st, a, ntiles);
       SMESH_HIP(hipGetLastError());
       hipLaunchKernelGGL(k_tile_resolve, dim3((uint32_t)(div_up(W, kQW) * div_up(H, kQH))), dim3(256), 0, st, a, d_idx, d_depth);
       SMESH_HIP(hipGetLastError());
@@ -1408,7 +1415,9 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   SMESH_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_raster_frag_group, dim3((uint32_t)n * rg.blocks_per_view), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_raster_huge_group, dim3(std::min<uint32_t>(tiles, 4u * (uint32_t)ctx->num_cus)), dim3(256), 0, st, rg);
+  bool huge_needed = false;   // (no_huge_possible: a proof that the queue of every view of the group stays empty)
+  for (int v = 0; v < n; v++) huge_needed = huge_needed || !no_huge_possible(r, &cams[v]);
+  if (huge_needed) hipLaunchKernelGGL(k_raster_huge_group, dim3(std::min<uint32_t>(tiles, 4u * (uint32_t)ctx->num_cus)), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
   hipLaunchKernelGGL(k_tile_resolve_group, dim3(tiles), dim3(256), 0, st, rg);
   SMESH_HIP(hipGetLastError());
@@ -1459,6 +1468,78 @@ hipError_t alloc_side(smesh_renderer* r, int i) {
   return e;
 }
 
+// Box of the vertices and longest edge of the faces, on the host, once per renderer (a few ms per million faces).
+void mesh_bounds(const float* v, uint64_t V, const int32_t* f, uint64_t F, smesh_renderer::Bounds& b) {
+  b.valid = false;
+  if (!V || !F) return;
+  float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+  bool finite = true;
+  for (uint64_t i = 0; i < V; i++)
+    for (int d = 0; d < 3; d++) {
+      const float x = v[3 * i + d];
+      finite = finite && std::isfinite(x);
+      lo[d] = std::min(lo[d], x); hi[d] = std::max(hi[d], x);
+    }
+  if (!finite) return;
+  double m2 = 0.0;
+  for (uint64_t i = 0; i < F; i++) {
+    const int32_t a = f[3 * i], c = f[3 * i + 1], e = f[3 * i + 2];
+    if (a < 0 || c < 0 || e < 0 || (uint64_t)a >= V || (uint64_t)c >= V || (uint64_t)e >= V) continue;   // (load_tri drops such faces)
+    const float* p[3] = {v + 3 * (uint64_t)a, v + 3 * (uint64_t)c, v + 3 * (uint64_t)e};
+    for (int k = 0; k < 3; k++) {
+      const float* q = p[k]; const float* w = p[(k + 1) % 3];
+      const double dx = (double)q[0] - w[0], dy = (double)q[1] - w[1], dz = (double)q[2] - w[2];
+      m2 = std::max(m2, dx * dx + dy * dy + dz * dz);
+    }
+  }
+  for (int d = 0; d < 3; d++) { b.lo[d] = lo[d]; b.hi[d] = hi[d]; }
+  b.max_edge = std::sqrt(m2);
+  b.valid = std::isfinite(b.max_edge);
+}
+
+// True only if NO triangle of the mesh can land in the queue of k_raster_huge for this camera -- none crosses the near plane and
+// none has a screen box of more than kMedium pixels a side -- so that the launch can be left out (at cfg2 an empty k_raster_huge_group
+// cost 7 us of kernel time plus a launch gap per group of eight views).  A PROOF from the mesh's box and its longest
+// edge, never a guess: false whenever the bound does not hold (a camera inside or near the mesh, coarse triangles), and then the kernel
+// is launched as before.  With z_lo the smallest camera-space depth of the box (float32 rounding of the vertex stage subtracted) and
+// L the longest edge as the vertex stage sees it, r = L / z_lo: two vertices P, Q of one triangle project
+//   |u_P - u_Q| = |fx| |x_P / z_P - x_Q / z_Q| <= (|fx| |x_P - x_Q| + |u_Q - cx| |z_P - z_Q|) / z_P <= (|fx| + |u_Q - cx|) r,
+// and a triangle that reaches the image has its leftmost vertex Q at -D - 1 <= u_Q <= W + 1 (D: its extent), so
+//   D <= (|fx| + max(|cx|, |W - cx|) + 1) r / (1 - r); likewise in v.  A box of n pixel centres needs an extent of at least n - 1.
+bool no_huge_possible(const smesh_renderer* r, const smesh_camera_t* cam) {
+  static const bool off = getenv("SMESH_HUGE_ALWAYS") && atoi(getenv("SMESH_HUGE_ALWAYS")) != 0;
+  const smesh_renderer::Bounds& b = r->bounds;
+  if (off || !b.valid) return false;
+  const double W = (double)cam->width, H = (double)cam->height;
+  double zmin = INFINITY, mag = 0.0, frob2 = 0.0;
+  for (int row = 0; row < 3; row++) {
+    double m = std::fabs((double)cam->translation[row]);
+    for (int d = 0; d < 3; d++) {
+      const double R = cam->rotation[3 * row + d];
+      m += std::fabs(R) * std::max(std::fabs(b.lo[d]), std::fabs(b.hi[d]));
+      frob2 += R * R;
+    }
+    mag = std::max(mag, m);
+  }
+  for (int c = 0; c < 8; c++) {
+    double z = cam->translation[2];
+    for (int d = 0; d < 3; d++) z += (double)cam->rotation[6 + d] * ((c >> d) & 1 ? b.hi[d] : b.lo[d]);
+    zmin = std::min(zmin, z);
+  }
+  const double eps = 32.0 * 5.9604644775390625e-08 * mag;            // float32 evaluation of R X + t (project_point): < 4 ulp of `mag`
+  const double z_lo = zmin - eps;
+  const double L = std::sqrt(frob2) * b.max_edge + 4.0 * eps;       // |R (P - Q)| <= ||R||_F |P - Q|, plus the rounding of both points
+  if (!(z_lo > 1e-3) || !std::isfinite(mag) || !std::isfinite(L)) return false;   // (kNear = 1e-6: nothing behind or on the near plane)
+  const double ratio = L / z_lo;
+  if (!(ratio < 0.25)) return false;
+  const double fx = std::fabs(cam->focal[0]), fy = std::fabs(cam->focal[1]);
+  const double ax = std::max(std::fabs(cam->principal[0]), std::fabs(W - cam->principal[0])) + 1.0;
+  const double ay = std::max(std::fabs(cam->principal[1]), std::fabs(H - cam->principal[1])) + 1.0;
+  const double du = (fx + ax) * ratio / (1.0 - ratio), dv = (fy + ay) * ratio / (1.0 - ratio);
+  const double limit = (double)kMedium - 4.0;                          // (the box of an extent D holds at most D + 1 pixel centres)
+  return std::isfinite(du) && std::isfinite(dv) && du <= limit && dv <= limit;
+}
+
 int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F, int device,
                   smesh_renderer** out) {
   if (!out) return fail(SMESH_ERR_INVALID, "out is NULL");
@@ -1472,6 +1553,7 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   if (!r) return fail(SMESH_ERR_RUNTIME, "out of memory");
   r->ctx = ctx; r->V = V; r->F = F; r->num_primitives = F;
   r->big_capacity = (uint32_t)std::max<uint64_t>(F, 1);
+  mesh_bounds(vertices, V, faces, F, r->bounds);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->verts), std::max<uint64_t>(V * 12, 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->faces), std::max<uint64_t>(F * 12, 16));
   if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->vs[0].sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
@@ -2257,6 +2339,22 @@ int smesh_renderer_seal_render(smesh_renderer_t* r, const uint32_t* indices_dev)
     if (!r->hash_ev[sd]) SMESH_HIP(hipEventCreateWithFlags(&r->hash_ev[sd], hipEventDisableTiming));
     SMESH_HIP(hipEventRecord(r->hash_ev[sd], ctx->stream));
     r->hash_valid[sd] = true;
+  }
+  return SMESH_OK;
+}
+
+int smesh_renderer_render_stats(smesh_renderer_t* r, const smesh_camera_t* cam, int* huge_stage_needed, uint32_t queue_lengths[4]) {
+  if (!r || !cam) return fail(SMESH_ERR_INVALID, "NULL argument");
+  SMESH_TRY(check_camera(cam));
+  std::lock_guard<std::mutex> g(r->mu);
+  if (huge_stage_needed) *huge_stage_needed = no_huge_possible(r, cam) ? 0 : 1;
+  if (queue_lengths) {
+    DeviceCtx* ctx = r->ctx;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    SMESH_HIP(hipSetDevice(ctx->device));
+    SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
+    SMESH_HIP(hipMemcpyAsync(queue_lengths, r->side[r->last_render_side].big_count, 16, hipMemcpyDeviceToHost, ctx->stream));
+    SMESH_HIP(hipStreamSynchronize(ctx->stream));
   }
   return SMESH_OK;
 }

@@ -87,6 +87,17 @@ class _Renderer:
             return indices.capsule(), depth.capsule()
         return indices, depth
 
+    def render_stats(self, camera, queues=True):
+        """Diagnostics (`smesh_renderer_render_stats`): `(huge_stage_needed, queue_lengths)` -- whether the launch for triangles that
+        cross the near plane or span more than 64 pixels is needed for `camera` (False: the library proved from the mesh's bounding
+        box and longest edge that there is none), and after the last `render()` / `render_numpy()` the four queue lengths
+        `[boxes over 8 x 8, queue overflow flag, of those huge or clipped, of those at most 256 box pixels]`."""
+        needed = ctypes.c_int()
+        q = (ctypes.c_uint32 * 4)()
+        _lib.check(_lib.lib().smesh_renderer_render_stats(self._h, ctypes.byref(camera._pod), ctypes.byref(needed),
+                                                         ctypes.cast(q, ctypes.c_void_p) if queues else None))
+        return bool(needed.value), [int(x) for x in q]
+
     def render_numpy(self, camera):
         """Host variant: one call, results copied into fresh numpy arrays."""
         W, H = camera.resolution

@@ -1465,3 +1465,38 @@ def test_fuse_views_sharded_on_the_device(sm, oracle):
         assert_fused_close(hagg.get(), oagg.get(), rtol=1e-5)
     finally:
         oracle.set_accum_double(False)
+
+
+def test_huge_stage_is_left_out_only_where_it_is_provably_empty(sm, oracle):
+    """The launch for near-plane-crossing / over-64-pixel triangles is skipped when the library can prove its queue empty from the
+    mesh's bounding box and longest edge (raster.hip no_huge_possible).  A camera approaching a coarse grid from far away, head on
+    and obliquely, crosses that proof's boundary: wherever the launch is declared unnecessary the queue really is empty, the
+    declaration is used on both sides of the boundary, and the render is bit-equal to the oracle throughout."""
+    from semantic_meshes_amd import synth
+    mesh = synth.grid_mesh(24, 18, extent=10.0, relief=0.6)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    skipped = needed = 0
+    for k, (dist, elev, off) in enumerate([(d, e, s) for d in (400.0, 120.0, 60.0, 30.0, 14.0, 7.0, 3.0)
+                                           for e in (80.0, 35.0, 8.0) for s in (0.0, 4.5)]):
+        th = 0.7 * k
+        el = np.radians(elev)
+        eye = (off + dist * np.cos(th) * np.cos(el), dist * np.sin(th) * np.cos(el), dist * np.sin(el))
+        R, t = synth.look_at(eye, (off, 0.0, 0.0))
+        W, H = (320, 240) if k % 2 else (640, 400)
+        cam = sm.data.Camera(R, t, np.asarray([W, H]), np.asarray([0.9 * W, 0.8 * W]), np.asarray([W / 2.0 - 7.0, H / 2.0 + 3.0]))
+        idx, depth = r.render_numpy(cam)
+        need, q = r.render_stats(cam)
+        if need:
+            needed += 1
+        else:
+            skipped += 1
+            assert q[2] == 0, (dist, elev, off, q)
+        oidx, odepth = o.render(cam)
+        np.testing.assert_array_equal(idx, oidx)
+        np.testing.assert_array_equal(depth.view(np.uint32), odepth.view(np.uint32))
+    assert skipped >= 8 and needed >= 8, (skipped, needed)
+    # cfg2's cameras: provably no such triangle (the headline workload does not pay for the launch)
+    mesh2, cams2, _ = synth.scene("cfg2")
+    r2 = sm.render.triangles(mesh2)
+    assert not any(r2.render_stats(c, queues=False)[0] for c in cams2[::17])
