@@ -125,7 +125,8 @@ struct TriFuseArgs {
   const uint32_t* big_queue;
   const uint32_t* big_len;    // queue length of this render (emptied by the next render's vertex kernel)
   uint32_t big_capacity;
-  uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the rest the big-triangle queue
+  uint32_t tri_blocks;        // blocks 0 .. tri_blocks-1 walk the triangles, the next big_blocks the big-triangle queue, the rest (k_fuse_tri with `mid`) the lists of medium triangles
+  uint32_t big_blocks;
   int dbg;                    // development ablation (SMESH_FDBG): 1 stop after pass 1, 2 no stores, 4 no row loads, 8 no probs loads
   const uint32_t* prim_id;    // [F] primitive id of triangle f when the renderer re-ordered its triangles (null: id == f)
   // texel primitives (k_fuse_texel) only
@@ -133,7 +134,7 @@ struct TriFuseArgs {
   const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
   uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
   double* acc_d;              // Mul + texel primitives: [P][C] sums of ONE view's terms, all zero between launches (big triangles only)
-  int mid;                    // k_fuse_tri: nonzero = k_fuse_mid takes the queued triangles with at most kMidBox pixels per view (the tail waves skip them)
+  int mid;                    // k_fuse_tri: nonzero = the launch's last workgroups (fuse_mid_entries) take the queued triangles with at most kMidBox pixels per view (the tail waves skip them)
   uint32_t ps0, ps1;          // k_fuse_tri / fuse_box only: element strides of x and y of the class-vector image (dense: H * C and C); the class stride is 1
   // Fusion by triangle RANGE (smesh_fuse_views_begin / _continue: the rows of a finished range are exchanged between GPUs while the
   // next range is fused).  Main block b of the launch takes the triangles of block blk_first + b; the waves that walk the queues of
@@ -172,7 +173,7 @@ struct RenderedView {
 };
 
 // Medium triangles: a bounding box over 8 x 8 pixels of at most kMidBox pixels (16 x 16: beyond that a whole wave per triangle --
-// fuse_box -- is faster than sixteen lanes, tools/mesh_density_sweep.py).  The rasteriser lists them (push_mid), k_fuse_mid fuses them.
+// fuse_box -- is faster than sixteen lanes, tools/mesh_density_sweep.py).  The rasteriser lists them (push_mid), the last workgroups of the k_fuse_tri launch fuse them (fuse_mid.inc.hpp).
 constexpr int kMidBox = 256;
 
 // Per-primitive records built from an arbitrary index image (image_records.hip): what lets MeshAggregator::add() run the

@@ -1,35 +1,28 @@
-// fusion_mid.hip -- k_fuse_mid: the triangle-order fusion of MEDIUM triangles (a bounding box over 8 x 8 pixels, of at most kMidBox
-// pixels): sixteen lanes per (triangle, view), four of them per wave, float atomics on the accumulator row.
+// fuse_mid.inc.hpp -- the triangle-order fusion of MEDIUM triangles (a bounding box over 8 x 8 pixels, of at most kMidBox pixels):
+// sixteen lanes per (triangle, view), four of them per wave, float atomics on the accumulator row.  Included INSIDE the anonymous
+// namespace of the translation units that instantiate k_fuse_tri, after fuse_tri.inc.hpp's helpers: since round 4 the medium
+// triangles are fused by extra one-wave workgroups at the END OF THE k_fuse_tri LAUNCH (fuse_mid_entries) instead of a launch of
+// their own ahead of it (k_fuse_mid, round 3) -- at cfg2, where no triangle is medium, that launch cost 5.6 us of kernel time plus a
+// launch gap per group of eight views, and on meshes that do have medium triangles the two kernels now share
+// the chip instead of running one after the other.
 //
-// Why: a mesh of 90 000 triangles at 1080p (~23 pixels per triangle, boxes just over 8 x 8 -- a decimated
-// indoor scan, eval-scannet/simplify_scannet_meshes.py) spent 115 us per view in the tail blocks of k_fuse_tri, where ONE WAVE takes
-// one queued triangle at a time through all the views of the launch (fuse_box): a chain of dependent memory round trips (queue
-// entry -> records -> index plane -> class vectors -> row) with a quarter of the lanes busy, at the three waves per SIMD that the
-// 149 registers of the eight-view k_fuse_tri allow -- and seven queue entries out of eight are looked up only to be dropped (a
-// triangle sits in the queue of every view in which it is big).  Here the unit of work is the queue ENTRY: one (triangle, view).
-// It gets one 16-lane DPP row: the box is scanned by sixteen lanes (all index loads of a lane in flight together), each lane adds
-// up the weighted class vectors of its own hits, the row-wide sums are an all-reduce by row rotations (`row_ror` 8, 4, 2, 1) and
-// lane l adds classes l, l + 16, l + 32 to the accumulator row with float atomics -- the views of a triangle meet in its row in
-// any order, so no entry has to know about the others.  Four entries in flight per wave, at twice the waves per SIMD.
+// Why sixteen lanes per entry: a mesh of 90 000 triangles at 1080p (~23 pixels per triangle, boxes
+// just over 8 x 8 -- a decimated indoor scan, eval-scannet/simplify_scannet_meshes.py) spent 115 us per view in the tail blocks of
+// k_fuse_tri, where ONE WAVE takes one queued triangle at a time through all the views of the launch (fuse_box): a chain of dependent
+// memory round trips (queue entry -> records -> index plane -> class vectors -> row) with a quarter of the lanes busy -- and seven
+// queue entries out of eight are looked up only to be dropped (a triangle sits in the queue of every view in which it is big).
+// Here the unit of work is the queue ENTRY: one (triangle, view).  It gets one 16-lane DPP row: the box is scanned by sixteen lanes
+// (all index loads of a lane in flight together), each lane adds up the weighted class vectors of its own hits, the row-wide sums
+// are an all-reduce by row rotations (`row_ror` 8, 4, 2, 1) and lane l adds classes l, l + 16, l + 32 to the accumulator row with
+// float atomics -- the views of a triangle meet in its row in any order, so no entry has to know about the others.
 // Sum and Summax only (Mul's (hi, lo) rows cannot take atomics: those aggregators keep the one-wave-per-triangle tail).
 // The arithmetic is Mesh.h:94-106 term for term; the ORDER of the additions is a tree per view and arbitrary across views:
 // 1e-5 like every path that is not one-lane-per-row, and not run-to-run deterministic to the last bit.
 //
-// Work split (TriFuseArgs::mid != 0): a view in which the triangle's box holds at most kMidBox pixels (mid_box(), fuse_tri.inc.hpp) is
-// fused here; k_fuse_tri's main waves own the rows of triangles that are LARGE in no view of the launch (and skip their
-// medium views); its tail waves take the triangles that are large somewhere, minus their medium views.
-#include <hip/hip_runtime.h>
-
-#include "common.hpp"
-
-#include <cmath>
-#include <type_traits>
-
-using namespace smesh;
-
-namespace {
-
-#include "fuse_tri.inc.hpp"
+// Work split (TriFuseArgs::mid != 0): a view in which the triangle's box holds at most kMidBox pixels (mid_box()) is fused here;
+// k_fuse_tri's main waves leave every row alone whose triangle has a box over 8 x 8 in some view of the launch (these waves add to
+// it at the same time); its tail waves take such a triangle's large views and its small views, and likewise add with atomics
+// (fuse_box, a.mid).
 
 constexpr int kMidHits = 256;     // compacted hits per 16-lane row = kMidBox: every box fits (LDS: 16 rows x 256 x 2 bytes per workgroup)
 constexpr int kRowRor1 = 0x121, kRowRor2 = 0x122, kRowRor4 = 0x124, kRowRor8 = 0x128;
@@ -67,33 +60,45 @@ __device__ __forceinline__ double row16_sum_d(double v) {
   return v;
 }
 
-// CT: register slots of a class vector (C <= CT, run-time C).  256 threads = 16 entries in flight per workgroup.
-template <int CT, int KIND>
-__global__ __launch_bounds__(256) void k_fuse_mid(TriFuseArgs a, TriViews<8> vw, int nv) {
-  static_assert(KIND != SMESH_AGG_MUL, "k_fuse_mid adds with float atomics: Sum and Summax only");
+// CT: register slots of a class vector (C <= CT, run-time C).  One WAVE = four entries in flight; `worker` of `nworkers` such waves
+// (the last workgroups of a k_fuse_tri launch).  `hit_lds`: 4 x kMidHits uint16 of this wave's LDS.
+typedef __attribute__((address_space(3))) uint16_t lds_u16;
+template <int CT, int KIND, int NV>
+__device__ __forceinline__ void fuse_mid_entries(const TriFuseArgs& a, const TriViews<NV>& vw, const uint32_t worker, const uint32_t nworkers,
+                                                 lds_u16* __restrict__ hit_lds) {
+  static_assert(KIND != SMESH_AGG_MUL, "fuse_mid_entries adds with float atomics: Sum and Summax only");
   const int C = (int)a.C;
   const int l16 = (int)(threadIdx.x & 15u);
-  const uint32_t slot = (blockIdx.x * 256u + threadIdx.x) >> 4, nslots = gridDim.x * 16u;
-  uint32_t len[8], total = 0u;
+  const uint32_t slot = worker * 4u + (threadIdx.x >> 4), nslots = nworkers * 4u;
+  uint32_t len[NV], total = 0u;
 #pragma unroll
-  for (int v = 0; v < 8; v++) { len[v] = v < nv ? min(vw.v[v].big_len[3], a.big_capacity) : 0u; total += len[v]; }   // the rasteriser's lists of medium triangles (push_mid)
+  for (int v = 0; v < NV; v++) { len[v] = min(vw.v[v].big_len[3], a.big_capacity); total += len[v]; }   // the rasteriser's lists of medium triangles (push_mid)
   if (total == 0u) return;             // no medium triangle in any view: every BASELINE config
-  __shared__ uint16_t s_hit[16][kMidHits];   // per 16-lane row: the box pixels that hold the triangle, compacted (pass 2 takes one per lane and round)
-  uint16_t* __restrict__ my_hits = s_hit[(threadIdx.x >> 4) & 15u];
+  lds_u16* __restrict__ my_hits = hit_lds + ((threadIdx.x >> 4) & 3u) * kMidHits;   // per 16-lane row: the box pixels that hold the triangle, compacted (pass 2 takes one per lane and round)
   // what a queue entry is: the view it belongs to, the triangle, the triangle's record in that view
   struct Entry { uint32_t fi; int view; TriFrag rec; };
   auto fetch = [&](const uint32_t q) -> Entry {
     Entry e;
     e.fi = 0u; e.view = -1;
     e.rec.x0 = 0; e.rec.y0 = 0; e.rec.kind = 0; e.rec.pad = 0; e.rec.mask = 0ull;
+    // which view's list entry q falls into: arithmetic on the eight lengths; the view's pointers are then read from the kernel-argument
+    // segment at a run-time index (chains of selects over all views held every pointer of every view in scalar registers, and the
+    // spilled ones cost the whole kernel -- main path included -- six vector registers: one wave per SIMD at C = 19 / Summax)
     uint32_t qq = q;
+    int jsel = -1;
     bool located = q >= total;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
+    for (int j = 0; j < NV; j++) {
       if (!located) {
-        if (qq < len[j]) { e.fi = vw.v[j].big_queue[(uint64_t)a.big_capacity + qq]; e.rec = vw.v[j].frags[e.fi]; e.view = j; located = true; }
+        if (qq < len[j]) { jsel = j; located = true; }
         else qq -= len[j];
       }
+    }
+    if (jsel >= 0) {
+      const TriView& w = vw.v[jsel];
+      e.fi = w.big_queue[(uint64_t)a.big_capacity + qq];
+      e.rec = w.frags[e.fi];
+      e.view = jsel;
     }
     return e;
   };
@@ -105,13 +110,11 @@ __global__ __launch_bounds__(256) void k_fuse_mid(TriFuseArgs a, TriViews<8> vw,
     next = fetch(q + nslots);
     const uint32_t fi = cur.fi;
     const TriFrag rec = cur.rec;
-    const uint32_t* __restrict__ idx = vw.v[0].idx;
-    const float* __restrict__ probs = vw.v[0].probs;
-    const float* __restrict__ weights = vw.v[0].weights;
-    uint32_t vH = vw.v[0].H, ps0 = vw.v[0].ps0, ps1 = vw.v[0].ps1;
-#pragma unroll
-    for (int j = 1; j < 8; j++)
-      if (cur.view == j) { idx = vw.v[j].idx; probs = vw.v[j].probs; weights = vw.v[j].weights; vH = vw.v[j].H; ps0 = vw.v[j].ps0; ps1 = vw.v[j].ps1; }
+    const TriView& cw = vw.v[cur.view >= 0 ? cur.view : 0];
+    const uint32_t* __restrict__ idx = cw.idx;
+    const float* __restrict__ probs = cw.probs;
+    const float* __restrict__ weights = cw.weights;
+    const uint32_t vH = cw.H, ps0 = cw.ps0, ps1 = cw.ps1;
     const bool on = cur.view >= 0 && rec.kind == 2 && mid_box(rec, 0u, 0u);   // (larger boxes: k_fuse_tri's tail waves)
     if (__ballot(on) == 0ull) continue;
     const uint32_t pid = (a.prim_id && on) ? a.prim_id[fi] : fi;   // value in the index image = accumulator row
@@ -218,23 +221,4 @@ __global__ __launch_bounds__(256) void k_fuse_mid(TriFuseArgs a, TriViews<8> vw,
   }
 }
 
-}  // namespace
 
-// `slots`: class-vector register slots (8 / 16 / 24 / 32 / 40 / 48 >= C).  One launch for all `nviews` views of `tv`.
-void smesh_launch_fuse_mid(int kind, int slots, int nviews, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv) {
-  const dim3 block(256);
-#define SMESH_FM(K)                                                                              \
-  switch (slots) {                                                                               \
-    case 8:  hipLaunchKernelGGL((k_fuse_mid<8, K>), grid, block, 0, st, t, tv, nviews); break;    \
-    case 16: hipLaunchKernelGGL((k_fuse_mid<16, K>), grid, block, 0, st, t, tv, nviews); break;   \
-    case 24: hipLaunchKernelGGL((k_fuse_mid<24, K>), grid, block, 0, st, t, tv, nviews); break;   \
-    case 32: hipLaunchKernelGGL((k_fuse_mid<32, K>), grid, block, 0, st, t, tv, nviews); break;   \
-    case 40: hipLaunchKernelGGL((k_fuse_mid<40, K>), grid, block, 0, st, t, tv, nviews); break;   \
-    default: hipLaunchKernelGGL((k_fuse_mid<48, K>), grid, block, 0, st, t, tv, nviews); break;   \
-  }
-  switch (kind) {
-    case SMESH_AGG_SUM: SMESH_FM(SMESH_AGG_SUM); break;
-    default: SMESH_FM(SMESH_AGG_SUMMAX); break;      // (never Mul: smesh_aggregator_fuse_triangles keeps those on the tail waves)
-  }
-#undef SMESH_FM
-}

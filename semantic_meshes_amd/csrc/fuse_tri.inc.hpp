@@ -209,8 +209,11 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
     const uint32_t x = (uint32_t)pix / a.H, y = (uint32_t)pix - x * a.H;
     return a.probs + ((uint64_t)x * a.ps0 + (uint64_t)y * a.ps1);
   };
-  // this wave owns the row: its current value is requested now and written back at the end (plain read-modify-write)
-  float row_value = (l < C) ? a.acc[(uint64_t)f * C + l] : 0.0f;
+  // this wave owns the row: its current value is requested now and written back at the end (plain read-modify-write) -- unless the
+  // launch also fuses medium views (a.mid: fuse_mid_entries adds to the rows of such triangles with float atomics at the same time),
+  // then this wave adds its totals with atomics as well
+  const bool shared_row = KIND != SMESH_AGG_MUL && a.mid != 0;
+  float row_value = (l < C && !shared_row) ? a.acc[(uint64_t)f * C + l] : 0.0f;
   const bool one_step = npx <= (long long)kWave * U;   // the whole box in one round of index loads
   uint32_t mine_n = 0, hits = 0;                        // this lane's pixels of the triangle (bit u of `hits`: slot u of the one round)
   for (long long base = 0; base < npx; base += (long long)kWave * U) {
@@ -243,6 +246,8 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
       mul_fold(hi, lo, centre, (double)total);
       a.acc[(uint64_t)f * C + l] = hi;
       a.acc_lo[(uint64_t)f * C + l] = lo;
+    } else if (shared_row) {
+      if ((float)total != 0.0f) unsafeAtomicAdd(&a.acc[(uint64_t)f * C + l], (float)total);
     } else {
       a.acc[(uint64_t)f * C + l] = row_value + (float)total;
     }
@@ -338,7 +343,7 @@ __device__ __forceinline__ TriFuseArgs with_view(const TriFuseArgs& a, const Tri
   return x;
 }
 
-// Medium triangles -- a box of at most kMidBox pixels in every view of the launch -- are fused by k_fuse_mid (fusion_mid.hip: sixteen
+// Medium triangles -- a box of at most kMidBox pixels in every view of the launch -- are fused by fuse_mid_entries (fuse_mid.inc.hpp: sixteen
 // lanes per triangle, four triangles per wave) when TriFuseArgs::mid is set; the tail waves below then leave them alone.
 __device__ __forceinline__ bool mid_box(const TriFrag& rec, uint32_t W, uint32_t H) {
   (void)W; (void)H;
@@ -360,8 +365,9 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const T
   // rejected -- a triangle sits in the queue of every view in which it is big and is taken from the first.)  The chunk grows
   // with the queues -- one entry per step while there are fewer entries than tail waves, so that a few expensive triangles
   // still spread over all of them, 64 when there are many.
-  // With a.mid the MEDIUM views are k_fuse_mid's: an entry counts only if its triangle is LARGE (over kMidBox pixels) in the
-  // entry's view, and is taken from the first view in which it is large.
+  // With a.mid the MEDIUM views (boxes of at most kMidBox pixels) are fuse_mid_entries', whose waves run in the same launch and add with
+  // float atomics: an entry counts only if its triangle is LARGE (over kMidBox pixels) in the entry's view, and is taken from the first
+  // view in which it is large; the wave then adds with atomics too (fuse_box, a.mid).
   // A step's `chunk` entries are spread over the whole concatenation of the queues (lane l takes entry l * steps + step): the entries of
   // the first view's queue are all taken, the later views' mostly are duplicates, so consecutive entries would hand a few waves all
   // the work.
@@ -405,7 +411,7 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const T
 #pragma unroll
       for (int j = 0; j < NV; j++) {
         const TriFrag rec = vw.v[j].frags[fq];
-        if (rec.kind == 0 || (a.mid && rec.kind == 2 && mid_box(rec, 0u, 0u))) continue;   // (a medium view: k_fuse_mid's)
+        if (rec.kind == 0 || (a.mid && rec.kind == 2 && mid_box(rec, 0u, 0u))) continue;   // (a medium view: fuse_mid_entries')
         const TriFuseArgs x = with_view(a, vw.v[j]);
         int x1, y1;
         if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
@@ -416,19 +422,36 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const T
   }
 }
 
+#include "fuse_mid.inc.hpp"
+
 // NV views (1, 2, 4 or 8) of the same mesh into the same accumulator in ONE launch, in order: the wave's 64-row block makes one
 // round trip for all of them (the accumulator traffic is 15 us of a two-view launch's 83 at cfg2), and the additions happen in the
 // order NV launches would have made them.  `a`: what the views share (accumulator, mesh, class count ...); `vw`: the views.
+// (Register budget: the instruction scheduler trades registers for latency hiding in steps of whole waves per SIMD, and the eight-view
+// Summax instance for 19 classes sits at 167 of the 168 registers that three waves allow -- any addition to the kernel, however far
+// from its hot loop, dropped it to two waves at 183-185.  The budget of the instances for 19 .. 21 classes is therefore stated
+// (20 and 21 classes / Summax gain their third wave that way: 169 / 175 registers without it); every other instance is left to the scheduler.)
+constexpr int fuse_tri_min_waves(int ct, int kind, int nv) { return (ct >= 19 && ct <= 21 && kind != SMESH_AGG_MUL && (nv != 2 || ct == 19)) ? 3 : 1; }   // (two views, 20 / 21 classes, Summax: would spill)
 template <int CT, int KIND, bool EXACT, int NV>
-__global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> vw) {
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(fuse_tri_min_waves(CT, KIND, NV)))) void k_fuse_tri(TriFuseArgs a, TriViews<NV> vw) {
   const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
   constexpr int PB = CT <= 24 ? 2 : 1;        // pixels whose class vectors are in flight together (3 or 4: no difference, round 2)
   constexpr int KV = (kWave * CT / 4 + kWave - 1) / kWave;   // float4 per lane of the 64-row block
-  __shared__ __attribute__((aligned(16))) float srow[kWave * CT + 4];   // the wave's 64 accumulator rows
+  constexpr int kSrow = (kWave * CT + 4) > (4 * kMidHits / 2) ? (kWave * CT + 4) : (4 * kMidHits / 2);   // (the medium-triangle waves: 4 x kMidHits uint16)
+  __shared__ __attribute__((aligned(16))) float srow[kSrow];   // the wave's 64 accumulator rows
   const int l = threadIdx.x;
-  if (blockIdx.x >= a.tri_blocks) {   // tail blocks: the queued big triangles
-    uint32_t* lds_list = reinterpret_cast<uint32_t*>(srow);   // the tail waves have no use for the row block: >= 64 entries
-    fuse_big_triangles<CT, KIND, EXACT, NV>(a, vw, blockIdx.x - a.tri_blocks, gridDim.x - a.tri_blocks, lds_list);
+  // The launch's workgroups: a.tri_blocks main waves, one per 64 triangles; then a.big_blocks waves on the queued big triangles; then
+  // (a.mid) the waves of the medium triangles, gone at once where the lists are empty.  (The medium-triangle waves FIRST, so that they
+  // start beside the main waves: measured, no faster -- 90 000 triangles 0.105 vs 0.108 ms per view -- and 20 bytes of scratch.)
+  if (blockIdx.x >= a.tri_blocks) {
+    const uint32_t tail = blockIdx.x - a.tri_blocks;
+    if (tail < a.big_blocks) {
+      uint32_t* lds_list = reinterpret_cast<uint32_t*>(srow);   // the tail waves have no use for the row block: >= 64 entries
+      fuse_big_triangles<CT, KIND, EXACT, NV>(a, vw, tail, a.big_blocks, lds_list);
+    } else if constexpr (KIND != SMESH_AGG_MUL) {
+      constexpr int MCT = (CT + 7) / 8 * 8;                     // class-vector register slots of the medium-triangle code: 8, 16 .. 48
+      fuse_mid_entries<MCT, KIND, NV>(a, vw, tail - a.big_blocks, gridDim.x - a.tri_blocks - a.big_blocks, (lds_u16*)srow);
+    }
     return;
   }
   const uint64_t f0 = ((uint64_t)a.blk_first + blockIdx.x) * kWave;   // (blk_first: fusion by triangle range; 0 otherwise)
@@ -436,7 +459,11 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> 
   // per view: box origin (x0 | y0 << 16) and the mask of this triangle's VISIBLE pixels inside its <= 8 x 8 box
   uint32_t org[NV];
   unsigned long long msk[NV];
-  bool big = false;   // a box over 8 x 8 in any view: this row belongs to a tail wave
+  // `big`: a box over 8 x 8 in some view -- other waves of this launch add to the row (the tail waves of the big triangles, the
+  // medium-triangle waves with float atomics), so it is never stored from here.  `large`: a view for the tail waves (every such view
+  // without a.mid; with it, the ones over kMidBox pixels): the tail wave then takes the triangle's small views as well.  A triangle
+  // that is only MEDIUM somewhere keeps its small views in this lane, whose share goes to the row by float atomics at the end.
+  bool big = false, large = false;
 #pragma unroll
   for (int v = 0; v < NV; v++) { org[v] = 0u; msk[v] = 0ull; }
   if (f < a.F) {
@@ -445,10 +472,11 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> 
       const TriFrag rec = vw.v[v].frags[f];
       org[v] = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
       msk[v] = rec.kind == 1 ? rec.mask : 0ull;
-      big = big || (rec.kind == 2 && !(a.mid && mid_box(rec, 0u, 0u)));   // (a.mid: medium views are k_fuse_mid's, the row stays this lane's)
+      big = big || rec.kind == 2;
+      large = large || (rec.kind == 2 && !(KIND != SMESH_AGG_MUL && a.mid && mid_box(rec, 0u, 0u)));
     }
   }
-  if (big) {
+  if (large) {
 #pragma unroll
     for (int v = 0; v < NV; v++) msk[v] = 0ull;
   }
@@ -541,6 +569,10 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> 
       }
       if (!rows_loaded && scattered) {
         if (any_win) load_row<CT, EXACT>(a.acc + (uint64_t)pid * C, C, accr);
+        if (KIND != SMESH_AGG_MUL && big) {   // (a row that takes atomics meanwhile: this lane sums its share from zero, see the end)
+#pragma unroll
+          for (int c = 0; c < CT; c++) accr[c] = 0.0f;
+        }
         rows_loaded = true;
       }
       if (!rows_loaded) {
@@ -554,6 +586,10 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> 
           for (int q = l; q < nrows * C; q += kWave) srow[q] = blk[q];
         }
         wave_sync();
+        if (KIND != SMESH_AGG_MUL && big) {   // (a row that takes atomics meanwhile: this lane sums its share from zero, see the end;
+                                              // zeroed in LDS rather than by a select per register, which cost the Summax instances a wave per SIMD)
+          for (int c = 0; c < C; c++) srow[l * C + c] = 0.0f;
+        }
 #pragma unroll
         for (int c = 0; c < CT; c++) if (EXACT || c < C) accr[c] = srow[l * C + c];
         rows_loaded = true;
@@ -595,25 +631,33 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri(TriFuseArgs a, TriViews<NV> 
       for (int c = 0; c < PT; c++) if (EXACT || c < C) lo_row[c] = lo[c];
     }
   }
-  if (scattered) {
+  if (scattered && __ballot(big && any_win) == 0ull) {
     if (any_win) {
 #pragma unroll
       for (int c = 0; c < CT; c++) if (EXACT || c < C) a.acc[(uint64_t)pid * C + c] = accr[c];
     }
     return;
   }
-  if (__ballot(big) != 0ull) {
-    // Some of these 64 rows belong to big triangles, which the tail blocks of this launch update concurrently:
-    // writing the whole block back would overwrite their sums.  Every other lane stores its own row.
-    if (!big && f < a.F) {
-#pragma unroll
-      for (int c = 0; c < CT; c++) if (EXACT || c < C) blk[l * C + c] = accr[c];
-    }
-    return;
-  }
+  // every other way out goes through LDS: each lane parks its row ...
 #pragma unroll
   for (int c = 0; c < CT; c++) if (EXACT || c < C) srow[l * C + c] = accr[c];
   wave_sync();
+  if (scattered || __ballot(big) != 0ull) {
+    // Some of these 64 rows belong to big or medium triangles, which the tail blocks of this launch update concurrently: writing the
+    // whole block back would overwrite their sums.  Every other lane stores its own row; the lane of a triangle that is medium in some
+    // views (the medium-triangle waves are adding to its row with float atomics) and small in others adds what its small views came
+    // to -- summed from zero, see above -- with atomics too.  Rolled loops over the parked row: unrolled over the register array, the
+    // atomics cost the Summax instances for 19 .. 21 classes their third wave per SIMD (167 -> 183 VGPRs).
+    float* __restrict__ row = a.acc + (uint64_t)pid * C;
+    const float* __restrict__ mine = srow + l * C;
+    if (KIND != SMESH_AGG_MUL && big) {
+      if (any_win)
+        for (int c = 0; c < C; c++) { const float d = mine[c]; if (d != 0.0f) unsafeAtomicAdd(&row[c], d); }
+    } else if (!big && f < a.F && (any_win || !scattered)) {
+      for (int c = 0; c < C; c++) row[c] = mine[c];
+    }
+    return;
+  }
   if (nrows == kWave) {
     f4* b4 = reinterpret_cast<f4*>(blk);
     const f4* s4 = reinterpret_cast<const f4*>(srow);

@@ -40,8 +40,6 @@
 
 using namespace smesh;
 
-// fusion_mid.hip: k_fuse_mid, the queued triangles of at most kMidBox pixels per view, sixteen lanes each
-void smesh_launch_fuse_mid(int kind, int slots, int nviews, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv);
 // fusion_pair.hip: k_fuse_tri<CT, KIND, EXACT, 2> for the class-count slot `tri_ct` chosen below
 void smesh_launch_fuse_tri_multi(int kind, int tri_ct, int nviews, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv);
 
@@ -2234,7 +2232,7 @@ void smesh_fuse_part_rows(uint64_t F, int part, int nparts, uint64_t* f_lo, uint
 }
 
 // `nviews` = 1, 2, 4 or 8 (smesh_aggregator_max_fused_views): views[0], views[1] ... of the same renderer in one launch.
-// `part` / `nparts`: only the triangles of smesh_fuse_part_rows(F, part, nparts) -- the queued medium triangles (k_fuse_mid, float
+// `part` / `nparts`: only the triangles of smesh_fuse_part_rows(F, part, nparts) -- the queued medium triangles (fuse_mid_entries, float
 // atomics) all go with part 0, the queued big ones with the part their position falls into.
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews, int part, int nparts) {
@@ -2306,7 +2304,23 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   // one wave per queued big triangle at a time; they exit at once if the queue is empty.  A launch over one of `nparts` triangle
   // ranges takes its share of them (every one of its waves still walks the whole queue and keeps the triangles of its range).
   const uint32_t big_waves = std::max((uint32_t)std::max(1, ctx->num_cus), big_per_cu * (uint32_t)std::max(1, ctx->num_cus) / (uint32_t)nparts);
-  const dim3 grid(t.tri_blocks + big_waves), block(kWave);
+  // Medium triangles (a box over 8 x 8 of at most kMidBox pixels; k_fuse_tri's class counts, Sum / Summax -- Mul's (hi, lo) rows cannot
+  // take atomics): their queue entries go to further one-wave workgroups at the end of the SAME launch (fuse_mid_entries; a launch of
+  // its own until round 4), gone at once when the lists are empty.  They add with float atomics, so the main waves leave the rows of
+  // such triangles alone (`mixed` lanes) and the tail waves skip what t.mid hands over.  With fusion by triangle range all of them go
+  // with part 0.
+  uint32_t mid_waves = 0;
+  if (specialised) {
+    static const int mid_mode = getenv("SMESH_FUSE_MID") ? atoi(getenv("SMESH_FUSE_MID")) : 1;   // 0: the tail waves take the medium triangles too
+    bool listed = true;                              // (records rebuilt from a foreign image carry no list of medium primitives)
+    for (int v = 0; v < nviews; v++) listed = listed && views[v].mid_queue;
+    if (mid_mode && listed && a->kind != SMESH_AGG_MUL) {
+      t.mid = 1;
+      if (part == 0) mid_waves = 16u * (uint32_t)std::max(1, ctx->num_cus);
+    }
+  }
+  t.big_blocks = big_waves;
+  const dim3 grid(t.tri_blocks + big_waves + mid_waves), block(kWave);
   const dim3 tgrid(t.tri_blocks), bgrid(big_waves);                        // any-C paths: big triangles in a second launch
   if (!specialised && part == 0) SMESH_TRY(mul_recentre(a));   // (a pass over ALL rows: never beside the exchange of a finished range)
   {
@@ -2349,19 +2363,6 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     }
     TriViews<1> tv1;
     tv1.v[0] = tv.v[0];
-    if (specialised) {
-      // medium triangles first (their rows are nobody else's: the main waves leave the rows of queued triangles alone, the tail waves
-      // skip what t.mid hands to k_fuse_mid); a few waves per SIMD walking the queues, gone at once when the queues are empty
-      static const int mid_mode_env = getenv("SMESH_FUSE_MID") ? atoi(getenv("SMESH_FUSE_MID")) : 1;   // 0: the tail waves take the medium triangles too
-      static const int mid_mode = (mid_mode_env == 0 || SMESH_ABL(1)) ? mid_mode_env : 1;               // (2 / 3: half of the hand-over each -- wrong results, ablation builds only)
-      bool listed = true;                              // (records rebuilt from a foreign image carry no list of medium primitives)
-      for (int v = 0; v < nviews; v++) listed = listed && views[v].mid_queue;
-      if (mid_mode && listed && a->kind != SMESH_AGG_MUL) {      // (Mul's (hi, lo) rows cannot take k_fuse_mid's atomics)
-        t.mid = mid_mode == 2 ? 0 : 1;
-        const int slots = a->C <= 8 ? 8 : a->C <= 16 ? 16 : a->C <= 24 ? 24 : a->C <= 32 ? 32 : a->C <= 40 ? 40 : 48;
-        if (mid_mode != 3 && part == 0) smesh_launch_fuse_mid(a->kind, slots, nviews, dim3(6u * (uint32_t)std::max(1, ctx->num_cus)), st, t, tv);
-      }
-    }
     if (nviews >= 2 && specialised) {   // the several-view instances of k_fuse_tri live in fusion_pair.hip / fusion_multi*.hip
       smesh_launch_fuse_tri_multi(a->kind, tri_ct, nviews, grid, st, t, tv);
     } else
@@ -2402,6 +2403,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   t.frags = frags; t.idx = d_idx; t.probs = d_probs; t.weights = d_w; t.acc = a->acc; t.acc_lo = a->acc_lo; t.F = F; t.C = a->C;
   t.H = (uint32_t)H; t.iew = a->iew; t.big_queue = big_queue; t.big_len = big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
+  t.big_blocks = 0;
   t.blk_first = 0u; t.f_lo = 0u; t.f_hi = (uint32_t)F;
   t.dbg = 0; t.prim_id = nullptr;
   SMESH_TRY(ensure_acc_d(a));
@@ -2448,6 +2450,7 @@ int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const ui
   t.acc = a->acc; t.acc_lo = a->acc_lo; t.F = F; t.C = a->C; t.W = (uint32_t)views[0].W; t.H = (uint32_t)views[0].H; t.iew = a->iew;
   t.big_queue = views[0].big_queue; t.big_len = views[0].big_len; t.big_capacity = big_capacity;
   t.tri_blocks = (uint32_t)div_up(F, kWave);
+  t.big_blocks = 0;
   t.blk_first = 0u; t.f_lo = 0u; t.f_hi = (uint32_t)F;
   t.dbg = 0; t.prim_id = nullptr;
   SMESH_TRY(ensure_acc_d(a));

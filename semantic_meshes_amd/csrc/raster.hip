@@ -482,7 +482,7 @@ __device__ __forceinline__ void emit(const RasterArgs& a, uint64_t f, const Tri&
 }
 
 // Medium triangles (a box over 8 x 8 of at most kMidBox pixels) are listed a second time, in the upper half of the big-triangle queue
-// (entries big_capacity ..., count in big_count[3]): k_fuse_mid (fusion_mid.hip) walks that list and nothing else.
+// (entries big_capacity ..., count in big_count[3]): fuse_mid_entries (fuse_mid.inc.hpp, the last workgroups of a k_fuse_tri launch) walks that list and nothing else.
 __device__ __forceinline__ void push_mid(const RasterArgs& a, const uint64_t f, const int box_pixels) {
   if (box_pixels > kMidBox) return;
   const uint32_t slot = atomicAdd(a.big_count + 3, 1u);

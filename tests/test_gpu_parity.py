@@ -564,7 +564,7 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
 @pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
 @pytest.mark.parametrize("C,iew", [(5, 0.5), (19, 0.0), (19, 1.0), (33, 0.5), (48, 0.5)])
 def test_fuse_views_medium_triangles(sm, oracle, kind, C, iew):
-    """Meshes of MEDIUM triangles (boxes over 8 x 8, up to ~30 x 30 pixels: k_fuse_mid, sixteen lanes per (triangle, view), float
+    """Meshes of MEDIUM triangles (boxes over 8 x 8, up to ~30 x 30 pixels: fuse_mid_entries in the k_fuse_tri launch, sixteen lanes per (triangle, view), float
     atomics; Mul: the tail waves of k_fuse_tri) through fuse_views with per-pixel weights, plus one triangle too large for sixteen
     lanes (tail wave) whose other views are medium, against the float64 oracle; the views of a group in one call and one by one."""
     from semantic_meshes_amd.device import to_device
