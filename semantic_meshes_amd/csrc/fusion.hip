@@ -1403,7 +1403,11 @@ __global__ __launch_bounds__(kWave) void k_fuse_texel_big(TriFuseArgs a) { fuse_
 // the only pixel of their texel in this view: nobody else touches that row) and then deals them out one per lane: the rows move
 // with full waves.  Pixels that share their texel with another pixel of the triangle stay with the triangle's own lane, in image
 // order, as before (the reference's order of additions; a row with a single contribution has no order to keep).
-constexpr int kTexelBlock = 512;
+// 256 lanes (round 4; 512 until then): k_fuse_texel_multi takes 136 registers, i.e. three waves per SIMD -- of an eight-wave workgroup
+// only ONE fits a CU (two waves per SIMD), of a four-wave one three.  cfg4 / cfg4t, us per view in the kernel, same box:
+// 512 lanes 112.5 / 150.0, 256 lanes 103.5 / 143.0, 128 lanes 103.7 / 144.1, 64 lanes 107.0 / 148.4; a stated budget of four waves per SIMD
+// (128 registers, 14 spilled) 106.3 / 149.6 at 512 lanes and 102.0 / 146.5 at 256 (profiles/r04_texel_block_sweep.txt).
+constexpr int kTexelBlock = 256;
 
 // Mul ("Mul state", fuse_tri.inc.hpp): a texel receives a pixel or two per view, so every term is folded into the (hi, lo) row on its
 // own, in double, the row re-centred on its largest finite element.
