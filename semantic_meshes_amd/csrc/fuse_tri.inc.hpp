@@ -430,7 +430,8 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const T
 // (Register budget: the instruction scheduler trades registers for latency hiding in steps of whole waves per SIMD, and the eight-view
 // Summax instance for 19 classes sits at 167 of the 168 registers that three waves allow -- any addition to the kernel, however far
 // from its hot loop, dropped it to two waves at 183-185.  The budget of the instances for 19 .. 21 classes is therefore stated
-// (20 and 21 classes / Summax gain their third wave that way: 169 / 175 registers without it); every other instance is left to the scheduler.)
+// (20 and 21 classes / Summax gain their third wave that way: 169 / 175 registers without it); every other instance is left to the scheduler.  A budget of FOUR waves for the headline instance
+// (19 classes, Sum, eight views: 128 registers, 64 spilled) measured slower: 41.3 vs 37.6 us per view.)
 constexpr int fuse_tri_min_waves(int ct, int kind, int nv) { return (ct >= 19 && ct <= 21 && kind != SMESH_AGG_MUL && (nv != 2 || ct == 19)) ? 3 : 1; }   // (two views, 20 / 21 classes, Summax: would spill)
 template <int CT, int KIND, bool EXACT, int NV>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(fuse_tri_min_waves(CT, KIND, NV)))) void k_fuse_tri(TriFuseArgs a, TriViews<NV> vw) {
