@@ -316,9 +316,10 @@ const char* smesh_last_fuse_kernel(void);
 const char* smesh_last_add_path(void);
 
 /* Diagnostics of the rasteriser's size classes (new, no reference counterpart; TriangleRenderer.h:92 leaves every triangle to one
- * DeviceMutexRasterizer).  `huge_stage_needed`: 0 if the library can PROVE from the mesh's bounding box and longest edge that, seen
- * from `camera`, no triangle crosses the near plane or has a screen box beyond 64 pixels a side -- it then leaves out the launch
- * that rasterises such triangles; 1 otherwise.  `queue_lengths` (may be NULL): after r's last smesh_renderer_render /
+ * DeviceMutexRasterizer).  `huge_stage_needed`: bit 0 clear if the library can PROVE from the mesh's bounding box and longest edge
+ * that, seen from `camera`, no triangle crosses the near plane or has a screen box beyond 64 pixels a side -- it then leaves out the
+ * launch that rasterises such triangles; bit 1 clear if it can prove that no box exceeds 8 x 8 pixels -- smesh_fuse_views then leaves
+ * out the waves / launches that fuse such triangles; 3 without either proof.  `queue_lengths` (may be NULL): after r's last smesh_renderer_render /
  * _render_device (waits for it), [0] triangles with a box over 8 x 8 pixels, [1] nonzero if fragment queues overflowed, [2] of
  * [0], those beyond 64 pixels a side or clipped at the near plane, [3] of [0], those of at most 256 box pixels. */
 int smesh_renderer_render_stats(smesh_renderer_t* r, const smesh_camera_t* camera, int* huge_stage_needed, uint32_t queue_lengths[4]);

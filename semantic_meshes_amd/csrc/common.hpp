@@ -170,6 +170,7 @@ struct RenderedView {
   uint64_t W, H;
   int64_t ps0 = 0, ps1 = 0;     // element strides of x and y of `probs` when it is not the dense (W,H,C) image (class stride 1); 0, 0: dense
   bool mid_queue = false;       // big_queue[big_capacity ...] lists the medium triangles of this view, big_len[3] of them (the rasteriser's renders)
+  bool no_big = false;          // PROVEN on the host (raster.hip no_big_possible): no triangle of this view has a box over 8 x 8 pixels -- big_queue is empty
 };
 
 // Medium triangles: a bounding box over 8 x 8 pixels of at most kMidBox pixels (16 x 16: beyond that a whole wave per triangle --

@@ -2307,7 +2307,9 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   static const uint32_t big_per_cu = getenv("SMESH_BIG_WAVES") ? (uint32_t)std::max(1, atoi(getenv("SMESH_BIG_WAVES"))) : 16u;
   // one wave per queued big triangle at a time; they exit at once if the queue is empty.  A launch over one of `nparts` triangle
   // ranges takes its share of them (every one of its waves still walks the whole queue and keeps the triangles of its range).
-  const uint32_t big_waves = std::max((uint32_t)std::max(1, ctx->num_cus), big_per_cu * (uint32_t)std::max(1, ctx->num_cus) / (uint32_t)nparts);
+  bool no_big = true;     // every view of the launch PROVEN free of triangles with a box over 8 x 8 (RenderedView::no_big): no tail waves at all
+  for (int v = 0; v < nviews; v++) no_big = no_big && views[v].no_big;
+  const uint32_t big_waves = no_big ? 0u : std::max((uint32_t)std::max(1, ctx->num_cus), big_per_cu * (uint32_t)std::max(1, ctx->num_cus) / (uint32_t)nparts);
   // Medium triangles (a box over 8 x 8 of at most kMidBox pixels; k_fuse_tri's class counts, Sum / Summax -- Mul's (hi, lo) rows cannot
   // take atomics): their queue entries go to further one-wave workgroups at the end of the SAME launch (fuse_mid_entries; a launch of
   // its own until round 4), gone at once when the lists are empty.  They add with float atomics, so the main waves leave the rows of
@@ -2321,7 +2323,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     if (mid_mode && listed && a->kind != SMESH_AGG_MUL) {
       t.mid = 1;
       static const uint32_t mid_per_cu = getenv("SMESH_MID_WAVES") ? (uint32_t)std::max(1, atoi(getenv("SMESH_MID_WAVES"))) : 32u;   // (90 000 triangles at 1080p, ms per view: 8 -> 0.111, 16 -> 0.108, 32 -> 0.104, 64 -> 0.103; cfg2 0.062 throughout)
-      if (part == 0) mid_waves = mid_per_cu * (uint32_t)std::max(1, ctx->num_cus);
+      if (part == 0 && !no_big) mid_waves = mid_per_cu * (uint32_t)std::max(1, ctx->num_cus);
     }
   }
   t.big_blocks = big_waves;
@@ -2363,7 +2365,7 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
       case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
       default:                                                                                \
         if (!t.tri_blocks) { } else if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }   \
-        hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, tv, nviews, pw, amax, scratch_stride);             \
+        if (!no_big) hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, tv, nviews, pw, amax, scratch_stride); \
         break;                                                                                \
     }
     TriViews<1> tv1;
@@ -2471,6 +2473,7 @@ int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const ui
       default:               hipLaunchKernelGGL((k_fuse_texel_multi<SMESH_AGG_MUL>), tgrid, tblock, 0, st, t, tv, nviews); break;
     }
     for (int v = 0; v < nviews; v++) {
+      if (views[v].no_big) continue;   // (proven on the host: this view's queue of big triangles is empty -- eight empty launches per cfg4 group)
       TriFuseArgs x = t;
       x.frags = views[v].frags; x.idx = views[v].idx; x.probs = views[v].probs; x.weights = views[v].weights;
       x.W = (uint32_t)views[v].W; x.H = (uint32_t)views[v].H; x.big_queue = views[v].big_queue; x.big_len = views[v].big_len;

@@ -1172,6 +1172,7 @@ int plane_checksum(DeviceCtx* ctx, hipStream_t st, const uint32_t* d_img, uint64
 
 namespace {
 bool no_huge_possible(const smesh_renderer* r, const smesh_camera_t* cam);
+bool no_big_possible(const smesh_renderer* r, const smesh_camera_t* cam);
 void mesh_bounds(const float* v, uint64_t V, const int32_t* f, uint64_t F, smesh_renderer::Bounds& b);
 
 int ensure_keys(smesh_renderer::ViewScratch& vs, uint64_t W, uint64_t H, hipStream_t st) {
@@ -1497,19 +1498,20 @@ void mesh_bounds(const float* v, uint64_t V, const int32_t* f, uint64_t F, smesh
   b.valid = std::isfinite(b.max_edge);
 }
 
-// True only if NO triangle of the mesh can land in the queue of k_raster_huge for this camera -- none crosses the near plane and
-// none has a screen box of more than kMedium pixels a side -- so that the launch can be left out (at cfg2 an empty k_raster_huge_group
-// cost 7 us of kernel time plus a launch gap per group of eight views).  A PROOF from the mesh's box and its longest
-// edge, never a guess: false whenever the bound does not hold (a camera inside or near the mesh, coarse triangles), and then the kernel
-// is launched as before.  With z_lo the smallest camera-space depth of the box (float32 rounding of the vertex stage subtracted) and
-// L the longest edge as the vertex stage sees it, r = L / z_lo: two vertices P, Q of one triangle project
+// An upper bound, PROVEN from the mesh's box and its longest edge, on the screen extent (pixels, either axis) of every triangle that
+// reaches the image of this camera -- or +inf when there is no proof (a vertex at or behind the near plane is possible, coarse
+// triangles, no valid summary).  It lets the host leave out launches whose work lists are then empty by construction (at cfg2 an
+// empty k_raster_huge_group cost 7 us of kernel time plus a launch gap per group of eight views).  Never a guess:
+// whenever the bound does not hold the launches happen as before.  With z_lo the smallest camera-space depth of the box (float32
+// rounding of the vertex stage subtracted) and L the longest edge as the vertex stage sees it, r = L / z_lo: two vertices P, Q of one
+// triangle project
 //   |u_P - u_Q| = |fx| |x_P / z_P - x_Q / z_Q| <= (|fx| |x_P - x_Q| + |u_Q - cx| |z_P - z_Q|) / z_P <= (|fx| + |u_Q - cx|) r,
 // and a triangle that reaches the image has its leftmost vertex Q at -D - 1 <= u_Q <= W + 1 (D: its extent), so
-//   D <= (|fx| + max(|cx|, |W - cx|) + 1) r / (1 - r); likewise in v.  A box of n pixel centres needs an extent of at least n - 1.
-bool no_huge_possible(const smesh_renderer* r, const smesh_camera_t* cam) {
+//   D <= (|fx| + max(|cx|, |W - cx|) + 1) r / (1 - r); likewise in v.
+double box_extent_bound(const smesh_renderer* r, const smesh_camera_t* cam) {
   static const bool off = getenv("SMESH_HUGE_ALWAYS") && atoi(getenv("SMESH_HUGE_ALWAYS")) != 0;
   const smesh_renderer::Bounds& b = r->bounds;
-  if (off || !b.valid) return false;
+  if (off || !b.valid) return INFINITY;
   const double W = (double)cam->width, H = (double)cam->height;
   double zmin = INFINITY, mag = 0.0, frob2 = 0.0;
   for (int row = 0; row < 3; row++) {
@@ -1529,16 +1531,22 @@ bool no_huge_possible(const smesh_renderer* r, const smesh_camera_t* cam) {
   const double eps = 32.0 * 5.9604644775390625e-08 * mag;            // float32 evaluation of R X + t (project_point): < 4 ulp of `mag`
   const double z_lo = zmin - eps;
   const double L = std::sqrt(frob2) * b.max_edge + 4.0 * eps;       // |R (P - Q)| <= ||R||_F |P - Q|, plus the rounding of both points
-  if (!(z_lo > 1e-3) || !std::isfinite(mag) || !std::isfinite(L)) return false;   // (kNear = 1e-6: nothing behind or on the near plane)
+  if (!(z_lo > 1e-3) || !std::isfinite(mag) || !std::isfinite(L)) return INFINITY;   // (kNear = 1e-6: nothing behind or on the near plane)
   const double ratio = L / z_lo;
-  if (!(ratio < 0.25)) return false;
+  if (!(ratio < 0.25)) return INFINITY;
   const double fx = std::fabs(cam->focal[0]), fy = std::fabs(cam->focal[1]);
   const double ax = std::max(std::fabs(cam->principal[0]), std::fabs(W - cam->principal[0])) + 1.0;
   const double ay = std::max(std::fabs(cam->principal[1]), std::fabs(H - cam->principal[1])) + 1.0;
   const double du = (fx + ax) * ratio / (1.0 - ratio), dv = (fy + ay) * ratio / (1.0 - ratio);
-  const double limit = (double)kMedium - 4.0;                          // (the box of an extent D holds at most D + 1 pixel centres)
-  return std::isfinite(du) && std::isfinite(dv) && du <= limit && dv <= limit;
+  if (!std::isfinite(du) || !std::isfinite(dv)) return INFINITY;
+  return std::max(du, dv);
 }
+// A box of n pixel centres needs an extent of at least n - 1: no triangle crosses the near plane or has a box of more than kMedium
+// pixels a side (the queue of k_raster_huge stays empty) ...
+bool no_huge_possible(const smesh_renderer* r, const smesh_camera_t* cam) { return box_extent_bound(r, cam) <= (double)kMedium - 4.0; }
+// ... or of more than 8 pixels a side: the big-triangle queue of the view (and with it the list of medium triangles) stays empty -- a
+// mesh of millions of triangles seen from outside (cfg4: 3.5 pixels, cfg5: 5.6; not cfg2: 13 - 24 against boxes that do stay under 8).
+bool no_big_possible(const smesh_renderer* r, const smesh_camera_t* cam) { return box_extent_bound(r, cam) <= 6.5; }
 
 int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F, int device,
                   smesh_renderer** out) {
@@ -2057,6 +2065,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
         const uint64_t k = i + (uint64_t)j;
         rv[j] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[base + j].ptr), probs[k],
                              weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
+        rv[j].no_big = no_big_possible(r, &cams[k]);
       }
       SMESH_TRY(smesh_aggregator_fuse_texels_multi(a, r->F, r->tex_first, r->tex_res, r->big_capacity, rv, gn));
       smesh_note_fuse("k_fuse_texel", "render-records");
@@ -2081,6 +2090,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
           const uint64_t k = i + (uint64_t)(j + v);
           rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[base + j + v].ptr), probs[k],
                                weights ? weights[k] : nullptr, cams[k].width, cams[k].height, 0, 0, true};
+          rv[v].no_big = no_big_possible(r, &cams[k]);
         }
         SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
         j += nv;
@@ -2347,7 +2357,7 @@ int smesh_renderer_render_stats(smesh_renderer_t* r, const smesh_camera_t* cam, 
   if (!r || !cam) return fail(SMESH_ERR_INVALID, "NULL argument");
   SMESH_TRY(check_camera(cam));
   std::lock_guard<std::mutex> g(r->mu);
-  if (huge_stage_needed) *huge_stage_needed = no_huge_possible(r, cam) ? 0 : 1;
+  if (huge_stage_needed) *huge_stage_needed = (no_huge_possible(r, cam) ? 0 : 1) | (no_big_possible(r, cam) ? 0 : 2);
   if (queue_lengths) {
     DeviceCtx* ctx = r->ctx;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);

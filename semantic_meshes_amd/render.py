@@ -91,12 +91,14 @@ class _Renderer:
         """Diagnostics (`smesh_renderer_render_stats`): `(huge_stage_needed, queue_lengths)` -- whether the launch for triangles that
         cross the near plane or span more than 64 pixels is needed for `camera` (False: the library proved from the mesh's bounding
         box and longest edge that there is none), and after the last `render()` / `render_numpy()` the four queue lengths
-        `[boxes over 8 x 8, queue overflow flag, of those huge or clipped, of those at most 256 box pixels]`."""
+        `[boxes over 8 x 8, queue overflow flag, of those huge or clipped, of those at most 256 box pixels]`.
+        `self.last_big_stage_needed`: likewise for boxes over 8 x 8 pixels (what `fuse_views` leaves out where it is False)."""
         needed = ctypes.c_int()
         q = (ctypes.c_uint32 * 4)()
         _lib.check(_lib.lib().smesh_renderer_render_stats(self._h, ctypes.byref(camera._pod), ctypes.byref(needed),
                                                          ctypes.cast(q, ctypes.c_void_p) if queues else None))
-        return bool(needed.value), [int(x) for x in q]
+        self.last_big_stage_needed = bool(needed.value & 2)
+        return bool(needed.value & 1), [int(x) for x in q]
 
     def render_numpy(self, camera):
         """Host variant: one call, results copied into fresh numpy arrays."""

@@ -1476,7 +1476,7 @@ def test_huge_stage_is_left_out_only_where_it_is_provably_empty(sm, oracle):
     mesh = synth.grid_mesh(24, 18, extent=10.0, relief=0.6)
     r = sm.render.triangles(mesh)
     o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
-    skipped = needed = 0
+    skipped = needed = no_big = 0
     for k, (dist, elev, off) in enumerate([(d, e, s) for d in (400.0, 120.0, 60.0, 30.0, 14.0, 7.0, 3.0)
                                            for e in (80.0, 35.0, 8.0) for s in (0.0, 4.5)]):
         th = 0.7 * k
@@ -1492,10 +1492,13 @@ def test_huge_stage_is_left_out_only_where_it_is_provably_empty(sm, oracle):
         else:
             skipped += 1
             assert q[2] == 0, (dist, elev, off, q)
+        if not r.last_big_stage_needed:                 # proven: no box over 8 x 8 pixels -> nothing queued at all
+            no_big += 1
+            assert q[0] == 0 and q[3] == 0 and not need, (dist, elev, off, q)
         oidx, odepth = o.render(cam)
         np.testing.assert_array_equal(idx, oidx)
         np.testing.assert_array_equal(depth.view(np.uint32), odepth.view(np.uint32))
-    assert skipped >= 8 and needed >= 8, (skipped, needed)
+    assert skipped >= 8 and needed >= 8 and no_big >= 4, (skipped, needed, no_big)
     # cfg2's cameras: provably no such triangle (the headline workload does not pay for the launch)
     mesh2, cams2, _ = synth.scene("cfg2")
     r2 = sm.render.triangles(mesh2)
