@@ -569,6 +569,7 @@ def main():
                     left -= nv
             if sum(mix.values()) != k_launches or sum(k * v for k, v in mix.items()) != k_views:
                 mix = {}
+        timed = k_launches > 0 and k_ms > 0     # (N > 1 with the exchange under the fusion: the fusion launches are not bracketed)
         achieved = bytes_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         achieved_needed = needed_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic, traffic_source = None, None
@@ -632,22 +633,23 @@ def main():
             # frac_needed first: the fraction by the bytes the kernel HAS to move (visible pixels' class vectors, records, touched
             # rows once per launch); `frac` is SURVEY.md 8(d)'s formula, which also charges the class vectors of background
             # pixels and a row round trip per view that the kernel does not perform -- it flatters
-            "roofline": {"frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4),
+            "roofline": {"frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4) if timed else None,
                          "kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),
                          "note": ("N > 1 with the exchange under the fusion: the fusion launches are not bracketed with events here (an event pair "
                                   "around each of exchange_parts x groups launches costs what the overlap saves); the kernel's roofline is the "
                                   "N = 1 line's") if ranged else None,
                          "bound": "hbm",
-                         "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "frac_traffic": (round(traffic / max(t_launch, 1e-12) / 1e9 / HBM_PEAK_GBS, 4) if traffic else None),
+                         "achieved": round(achieved, 1) if timed else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if timed else None, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_traffic": (round(traffic / t_launch / 1e9 / HBM_PEAK_GBS, 4) if (traffic and timed) else None),
                          "algorithmic_bytes_per_view": int(bytes_per_view),
                          "algorithmic_bytes_per_launch": int(bytes_per_view * views_per_launch),
                          "needed_bytes_per_view": int(needed_per_view),
                          "views_per_launch": (int(views_per_launch) if views_per_launch == int(views_per_launch)
                                               else round(views_per_launch, 3)),
                          "launches_by_views": {str(k): v for k, v in sorted(mix.items(), reverse=True)} or None,
-                         "avg_launch_us": round(1e6 * t_launch, 2), "us_per_view": round(1e3 * k_ms / max(k_views, 1), 3),
+                         "avg_launch_us": round(1e6 * t_launch, 2) if timed else None,
+                         "us_per_view": round(1e3 * k_ms / max(k_views, 1), 3) if timed else None,
                          "launches_timed": k_launches, "views_timed": k_views, "regions_timed": k_regions,
                          "regions_in_timed_loop": k_entered,
                          "distinct_primitives_per_view": int(T_mean), "visible_pixels_per_view": int(NV_mean),
