@@ -323,6 +323,12 @@ const char* smesh_last_add_path(void);
  * _render_device (waits for it), [0] triangles with a box over 8 x 8 pixels, [1] nonzero if fragment queues overflowed, [2] of
  * [0], those beyond 64 pixels a side or clipped at the near plane, [3] of [0], those of at most 256 box pixels. */
 int smesh_renderer_render_stats(smesh_renderer_t* r, const smesh_camera_t* camera, int* huge_stage_needed, uint32_t queue_lengths[4]);
+/* The bound those proofs rest on, as plain host arithmetic (no device needed; tests/test_host.py checks it against brute force): an
+ * upper bound on the screen extent, in pixels along either axis, of every triangle of the mesh that reaches `camera`'s image and has
+ * no vertex at or behind the near plane -- +inf when nothing can be proven (a vertex may lie behind the camera, coarse triangles,
+ * non-finite vertices).  <= 60: no triangle is huge or clipped; <= 6.5: no box exceeds 8 x 8 pixels. */
+int smesh_box_extent_bound(const float* vertices, uint64_t num_vertices, const int32_t* faces, uint64_t num_faces,
+                           const smesh_camera_t* camera, double* bound);
 
 /* ---- timing hooks (tracing) -------------------------------------------- */
 /* `slot_mask` is a bitmask of SMESH_PROF_* slots (bit s = slot s; 0 = off, 0xFF = all).

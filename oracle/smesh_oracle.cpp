@@ -799,6 +799,10 @@ int smesh_aggregator_add_matched(smesh_aggregator_t*, smesh_renderer_t*, const v
   return SMESH_OK;
 }
 int smesh_renderer_seal_render(smesh_renderer_t*, const uint32_t*) { return SMESH_OK; }
+int smesh_box_extent_bound(const float*, uint64_t, const int32_t*, uint64_t, const smesh_camera_t*, double* bound) {   // (no proofs on the oracle's side)
+  if (bound) *bound = INFINITY;
+  return SMESH_OK;
+}
 int smesh_renderer_render_stats(smesh_renderer_t*, const smesh_camera_t*, int* needed, uint32_t q[4]) {   // (the oracle has one loop for every triangle)
   if (needed) *needed = 1;
   if (q) q[0] = q[1] = q[2] = q[3] = 0u;

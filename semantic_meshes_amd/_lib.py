@@ -95,6 +95,7 @@ SIGNATURES = {
                                              c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64, P(c_int)]),
     "smesh_renderer_seal_render": (c_int, [c_void_p, c_void_p]),
     "smesh_renderer_render_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "smesh_box_extent_bound": (c_int, [c_void_p, c_u64, c_void_p, c_u64, c_void_p, c_void_p]),
     "smesh_last_fuse_kernel": (ctypes.c_char_p, []),
     "smesh_last_add_path": (ctypes.c_char_p, []),
     "smesh_profile_enable": (c_int, [c_int, c_int]),

@@ -1508,10 +1508,8 @@ void mesh_bounds(const float* v, uint64_t V, const int32_t* f, uint64_t F, smesh
 //   |u_P - u_Q| = |fx| |x_P / z_P - x_Q / z_Q| <= (|fx| |x_P - x_Q| + |u_Q - cx| |z_P - z_Q|) / z_P <= (|fx| + |u_Q - cx|) r,
 // and a triangle that reaches the image has its leftmost vertex Q at -D - 1 <= u_Q <= W + 1 (D: its extent), so
 //   D <= (|fx| + max(|cx|, |W - cx|) + 1) r / (1 - r); likewise in v.
-double box_extent_bound(const smesh_renderer* r, const smesh_camera_t* cam) {
-  static const bool off = getenv("SMESH_HUGE_ALWAYS") && atoi(getenv("SMESH_HUGE_ALWAYS")) != 0;
-  const smesh_renderer::Bounds& b = r->bounds;
-  if (off || !b.valid) return INFINITY;
+double box_extent_bound(const smesh_renderer::Bounds& b, const smesh_camera_t* cam) {
+  if (!b.valid) return INFINITY;
   const double W = (double)cam->width, H = (double)cam->height;
   double zmin = INFINITY, mag = 0.0, frob2 = 0.0;
   for (int row = 0; row < 3; row++) {
@@ -1543,6 +1541,10 @@ double box_extent_bound(const smesh_renderer* r, const smesh_camera_t* cam) {
 }
 // A box of n pixel centres needs an extent of at least n - 1: no triangle crosses the near plane or has a box of more than kMedium
 // pixels a side (the queue of k_raster_huge stays empty) ...
+double box_extent_bound(const smesh_renderer* r, const smesh_camera_t* cam) {
+  static const bool off = getenv("SMESH_HUGE_ALWAYS") && atoi(getenv("SMESH_HUGE_ALWAYS")) != 0;
+  return off ? INFINITY : box_extent_bound(r->bounds, cam);
+}
 bool no_huge_possible(const smesh_renderer* r, const smesh_camera_t* cam) { return box_extent_bound(r, cam) <= (double)kMedium - 4.0; }
 // ... or of more than 8 pixels a side: the big-triangle queue of the view (and with it the list of medium triangles) stays empty -- a
 // mesh of millions of triangles seen from outside (cfg4: 3.5 pixels, cfg5: 5.6; not cfg2: 13 - 24 against boxes that do stay under 8).
@@ -2350,6 +2352,14 @@ int smesh_renderer_seal_render(smesh_renderer_t* r, const uint32_t* indices_dev)
     SMESH_HIP(hipEventRecord(r->hash_ev[sd], ctx->stream));
     r->hash_valid[sd] = true;
   }
+  return SMESH_OK;
+}
+
+int smesh_box_extent_bound(const float* vertices, uint64_t V, const int32_t* faces, uint64_t F, const smesh_camera_t* cam, double* bound) {
+  if (!cam || !bound || (V && !vertices) || (F && !faces)) return fail(SMESH_ERR_INVALID, "NULL argument");
+  smesh_renderer::Bounds b;
+  mesh_bounds(vertices, V, faces, F, b);
+  *bound = box_extent_bound(b, cam);
   return SMESH_OK;
 }
 

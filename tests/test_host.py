@@ -200,3 +200,67 @@ def test_hip_runtime_preload_checks_the_soname(tmp_path):
                              capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, out.stderr
         assert out.stdout.strip() == ("LEFT" if tag == "other" else "MAPPED"), (tag, out.stdout, out.stderr)
+
+
+def test_box_extent_bound_is_a_bound():
+    """smesh_box_extent_bound (raster.hip box_extent_bound: what lets the library leave out the launches for huge / clipped / big
+    triangles) is plain host arithmetic in the HIP library: checked here, without a GPU, against brute force -- random soups and grids,
+    random cameras outside, oblique, near and inside the mesh: wherever the function returns a finite bound, no vertex lies at or
+    behind the near plane (as the float32 vertex stage computes it) and no triangle that reaches the image has a larger screen extent."""
+    import ctypes
+    from semantic_meshes_amd import _lib, synth, data
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip("libsmesh_hip.so not built")
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    L.smesh_box_extent_bound.restype = ctypes.c_int
+    rng = np.random.default_rng(2024)
+    finite = tight = 0
+    for trial in range(300):
+        if trial % 3 == 0:
+            mesh = synth.grid_mesh(int(rng.integers(4, 60)), int(rng.integers(4, 60)), extent=float(rng.uniform(1, 30)), relief=float(rng.uniform(0, 1)))
+            V, F = np.asarray(mesh.vertices, np.float32), np.asarray(mesh.faces, np.int32)
+        else:
+            nv, nf = int(rng.integers(3, 200)), int(rng.integers(1, 300))
+            centre = rng.uniform(-5, 5, 3)
+            V = (centre + rng.normal(0, rng.uniform(0.05, 3.0), (nv, 3))).astype(np.float32)
+            F = rng.integers(0, nv, (nf, 3)).astype(np.int32)
+            if trial % 7 == 0:
+                F[0, 1] = -1                                   # an out-of-range index: the face is ignored (load_tri)
+        W, H = int(rng.integers(16, 2000)), int(rng.integers(16, 1200))
+        dist = float(10 ** rng.uniform(-0.5, 3.0))
+        d = rng.normal(size=3); d /= np.linalg.norm(d)
+        target = V.mean(0) + rng.normal(0, 0.5, 3)
+        R, t = synth.look_at(target + d * dist, target, up=(0.3, 0.2, 1.0))
+        if trial % 5 == 0:
+            R = (R * np.float32(rng.uniform(0.5, 2.0))).astype(np.float32)      # not orthonormal: the caller's business
+        fx, fy = float(rng.uniform(0.3, 3.0) * W), float(rng.uniform(0.3, 3.0) * W)
+        cx, cy = float(rng.uniform(-0.2, 1.2) * W), float(rng.uniform(-0.2, 1.2) * H)
+        cam = data.Camera(R, t, np.asarray([W, H]), np.asarray([fx, fy]), np.asarray([cx, cy]))
+        bound = ctypes.c_double()
+        assert L.smesh_box_extent_bound(V.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(V)), F.ctypes.data_as(ctypes.c_void_p),
+                                        ctypes.c_uint64(len(F)), ctypes.byref(cam._pod), ctypes.byref(bound)) == 0
+        if not np.isfinite(bound.value):
+            continue
+        finite += 1
+        # the vertex stage: float32 rigid transform in the library's order of operations, double projection (raster.hip project_point)
+        Rf, tf = np.asarray(cam._pod.rotation, np.float32).reshape(3, 3), np.asarray(cam._pod.translation, np.float32)
+        Xc = np.empty_like(V)
+        for r in range(3):
+            Xc[:, r] = ((Rf[r, 0] * V[:, 0] + Rf[r, 1] * V[:, 1]) + Rf[r, 2] * V[:, 2]) + tf[r]
+        assert (Xc[:, 2] > 1e-6).all(), "a finite bound although a vertex lies behind the near plane"
+        z = Xc[:, 2].astype(np.float64)
+        u = fx * (Xc[:, 0].astype(np.float64) / z) + cx
+        v = fy * (Xc[:, 1].astype(np.float64) / z) + cy
+        ok = (F >= 0).all(1) & (F < len(V)).all(1)
+        Fi = F[ok]
+        tu, tv = u[Fi], v[Fi]
+        x0, x1 = np.maximum(np.ceil(tu.min(1) - 0.5), 0), np.minimum(np.floor(tu.max(1) - 0.5), W - 1)
+        y0, y1 = np.maximum(np.ceil(tv.min(1) - 0.5), 0), np.minimum(np.floor(tv.max(1) - 0.5), H - 1)
+        reach = (x0 <= x1) & (y0 <= y1)
+        if reach.any():
+            ext = max((tu.max(1) - tu.min(1))[reach].max(), (tv.max(1) - tv.min(1))[reach].max())
+            assert ext <= bound.value, (trial, ext, bound.value)
+            boxes = max((x1 - x0 + 1)[reach].max(), (y1 - y0 + 1)[reach].max())
+            assert boxes <= bound.value + 1
+            tight += ext > 0.05 * bound.value
+    assert finite >= 60 and tight >= 20, (finite, tight)
