@@ -364,6 +364,12 @@ int smesh_synth_probs(float* out, uint64_t num_pixels, uint32_t num_classes, uin
 /* Raw device memory for benchmark inputs that must be resident in HBM before timing starts. */
 int smesh_device_malloc(int device, uint64_t bytes, void** out);
 int smesh_device_free(int device, void* ptr);
+/* Device blocks released by the library's handles and by smesh_device_free stay mapped in a per-process cache and are handed out
+ * again for requests of their size class: memory that hipMalloc has only just mapped is where, on a GPU shared by several
+ * processes, kernel writes were seen to go missing (csrc/context.cpp, tools/alloc_churn_repro.hip).  smesh_device_trim unmaps what
+ * the cache holds on `device` (-1: all devices) and reports how many bytes that was (`cached_bytes` may be NULL).
+ * SMESH_ALLOC_CACHE_MB caps the cache (default: a quarter of the device's memory, at most 64 GiB; 0 = no cache). */
+int smesh_device_trim(int device, uint64_t* cached_bytes);
 /* Page-locked host memory (hipHostMalloc): HOST images passed to add() / fuse_view() from such a buffer cross PCIe by DMA. */
 int smesh_host_malloc(uint64_t bytes, void** out);
 int smesh_host_free(void* ptr);

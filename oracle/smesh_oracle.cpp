@@ -915,6 +915,7 @@ int smesh_host_malloc(uint64_t bytes, void** out) { if (!out) return fail(SMESH_
 int smesh_host_free(void* p) { free(p); return SMESH_OK; }
 int smesh_device_malloc(int, uint64_t, void**) { return fail(SMESH_ERR_NODEVICE, "oracle has no device memory"); }
 int smesh_device_free(int, void*) { return SMESH_OK; }
+int smesh_device_trim(int, uint64_t* cached_bytes) { if (cached_bytes) *cached_bytes = 0; return SMESH_OK; }
 int smesh_memcpy(void* dst, const void* src, uint64_t bytes, int dk, int sk, int) {
   if (dk != SMESH_MEM_HOST || sk != SMESH_MEM_HOST) return fail(SMESH_ERR_NODEVICE, "oracle has no device memory");
   std::memmove(dst, src, bytes);

@@ -107,6 +107,7 @@ SIGNATURES = {
     "smesh_synth_probs": (c_int, [c_void_p, c_u64, c_u32, c_u64, c_float, c_int, c_int]),
     "smesh_device_malloc": (c_int, [c_int, c_u64, P(c_void_p)]),
     "smesh_device_free": (c_int, [c_int, c_void_p]),
+    "smesh_device_trim": (c_int, [c_int, P(c_u64)]),
     "smesh_host_malloc": (c_int, [c_u64, P(c_void_p)]),
     "smesh_host_free": (c_int, [c_void_p]),
     "smesh_memcpy": (c_int, [c_void_p, c_void_p, c_u64, c_int, c_int, c_int]),

@@ -134,7 +134,7 @@ static int finish_comm(DeviceCtx* ctx, ncclComm_t c, int nranks, int rank, smesh
   if (!m) return fail(SMESH_ERR_RUNTIME, "out of memory");
   m->ctx = ctx; m->comm = c; m->nranks = nranks; m->rank = rank;
   SMESH_HIP(hipSetDevice(ctx->device));
-  SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&m->d_small), smesh_comm::kSmall * sizeof(double)));
+  SMESH_HIP(dev_malloc(reinterpret_cast<void**>(&m->d_small), smesh_comm::kSmall * sizeof(double)));
   *out = m;
   return SMESH_OK;
 }
@@ -174,7 +174,7 @@ int smesh_comm_destroy(smesh_comm_t* c) {
   (void)hipSetDevice(c->ctx->device);
   (void)hipStreamSynchronize(c->ctx->stream);
   if (c->comm && r->CommDestroy) (void)r->CommDestroy(c->comm);
-  if (c->d_small) (void)hipFree(c->d_small);
+  if (c->d_small) (void)dev_free(c->d_small);
   delete c;
   return SMESH_OK;
 }
@@ -200,6 +200,7 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
   }
   if (n > 1) SMESH_RCCL(r, r->GroupStart());
   int status = SMESH_OK;
+  std::vector<char> reduced((size_t)n, 0);   // the collective of pair i was issued: its epilogue (Mul: float64 image -> (hi, lo) pairs) is due
   for (int i = 0; i < n && status == SMESH_OK; i++) {
     std::lock_guard<std::mutex> g(smesh_aggregator_mutex(aggs[i]));
     DeviceCtx* ctx = comms[i]->ctx;
@@ -219,11 +220,22 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
     ProfScope prof(ctx, SMESH_PROF_EXCHANGE);
     const ncclResult_t e = r->AllReduce(buf, buf, (size_t)count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, comms[i]->comm, ctx->stream);
     if (e != ncclSuccess) status = fail_rccl(r, e, "ncclAllReduce");
-    else status = smesh_aggregator_exchange_end(aggs[i], 0, P, ctx->stream);
+    else reduced[(size_t)i] = 1;
   }
   if (n > 1) {
     const ncclResult_t e = r->GroupEnd();
     if (e != ncclSuccess && status == SMESH_OK) status = fail_rccl(r, e, "ncclGroupEnd");
+  }
+  // The epilogues go on the streams only now: inside a group a collective is put on its stream by ncclGroupEnd, so an epilogue
+  // launched beside its ncclAllReduce call would run AHEAD of the reduction and write this device's own partial sums back
+  // (a grouped Mul all-reduce returned unreduced data without an error).
+  for (int i = 0; i < n && status == SMESH_OK; i++) {
+    if (!reduced[(size_t)i]) continue;
+    std::lock_guard<std::mutex> g(smesh_aggregator_mutex(aggs[i]));
+    DeviceCtx* ctx = comms[i]->ctx;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    if (hipSetDevice(ctx->device) != hipSuccess) { status = fail(SMESH_ERR_RUNTIME, "hipSetDevice failed"); break; }
+    status = smesh_aggregator_exchange_end(aggs[i], 0, smesh_aggregator_primitives(aggs[i]), ctx->stream);
   }
   return status;
 }

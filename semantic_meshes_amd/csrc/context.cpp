@@ -5,7 +5,9 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <unordered_map>
 
 namespace smesh {
 
@@ -97,19 +99,133 @@ ProfScope::~ProfScope() {
   ctx->slots[slot].pending.emplace_back(start, stop);
 }
 
+// ---- device memory: blocks are kept mapped and handed out again ------------------------------------------------------------
+// Why the library does not hipFree what it may need again (round 5; tests/flake_hunt.py, tools/alloc_churn_repro.hip,
+// profiles/r05_lost_writes_*): on a GPU shared by several processes with a few busy streams each, a kernel's writes into a buffer
+// that hipMalloc has JUST mapped are, about once in 20 000 allocations, missing for every workgroup that ran on one of the eight
+// XCDs -- the buffer keeps the zeros it came with, no error is raised; a stand-alone HIP program shows it (no libsmesh involved),
+// one process alone never does, and memory that stays mapped never does.  That was round 4's "unexplained failure": an eighth of a
+// class-vector image read as don't-care pixels.  So device blocks freed by the library's handles and by smesh_device_free go to a
+// per-process cache (still mapped) and are handed out again for requests of the same size class; smesh_device_trim() or the cap
+// (SMESH_ALLOC_CACHE_MB, default a quarter of the device's memory, at most 64 GiB; 0 = plain hipMalloc / hipFree) unmaps them.
+// dev_free keeps hipFree's ordering contract: it returns when the device is idle, so nothing queued still uses the block.
+namespace {
+struct DevBlock { int device; size_t bytes; };
+struct CachedBlock { void* ptr; int device; unsigned long long stamp; };
+std::mutex g_alloc_mu;
+std::unordered_map<void*, DevBlock> g_live;                 // handed out: size class of the block
+std::multimap<size_t, CachedBlock> g_cached;                // free, still mapped: size class -> block
+size_t g_cached_bytes = 0;
+unsigned long long g_alloc_stamp = 0;
+
+size_t size_class(size_t n) {
+  if (n == 0) n = 1;
+  const size_t g = n <= (1u << 20) ? (size_t)4096 : (size_t)2 << 20;
+  return (n + g - 1) / g * g;
+}
+size_t cache_cap() {
+  static const size_t cap = [] {
+    if (const char* e = getenv("SMESH_ALLOC_CACHE_MB")) return (size_t)std::max(0ll, atoll(e)) << 20;
+    size_t free_b = 0, total = 0;
+    if (hipMemGetInfo(&free_b, &total) != hipSuccess) { (void)hipGetLastError(); total = (size_t)64 << 30; }
+    return std::min<size_t>(total / 4, (size_t)64 << 30);
+  }();
+  return cap;
+}
+// (g_alloc_mu held) really frees cached blocks, oldest first, until `need` more bytes fit under `cap`
+void evict_locked(size_t need, size_t cap) {
+  while (!g_cached.empty() && g_cached_bytes + need > cap) {
+    auto oldest = g_cached.begin();
+    for (auto it = g_cached.begin(); it != g_cached.end(); ++it)
+      if (it->second.stamp < oldest->second.stamp) oldest = it;
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != oldest->second.device) (void)hipSetDevice(oldest->second.device);
+    (void)hipFree(oldest->second.ptr);
+    if (cur != oldest->second.device) (void)hipSetDevice(cur);
+    g_cached_bytes -= oldest->first;
+    g_cached.erase(oldest);
+  }
+}
+}  // namespace
+
+hipError_t dev_malloc(void** out, size_t bytes) {
+  *out = nullptr;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  const size_t sz = size_class(bytes);
+  std::lock_guard<std::mutex> lock(g_alloc_mu);
+  for (auto it = g_cached.lower_bound(sz); it != g_cached.end() && it->first <= sz + sz / 8; ++it) {
+    if (it->second.device != dev) continue;
+    *out = it->second.ptr;
+    g_live[*out] = DevBlock{dev, it->first};
+    g_cached_bytes -= it->first;
+    g_cached.erase(it);
+    return hipSuccess;
+  }
+  e = hipMalloc(out, sz);
+  if (e != hipSuccess) {      // out of memory: give back what the cache holds and try once more
+    (void)hipGetLastError();
+    evict_locked(0, 0);
+    e = hipMalloc(out, sz);
+  }
+  if (e == hipSuccess) g_live[*out] = DevBlock{dev, sz};
+  return e;
+}
+
+hipError_t dev_free(void* p) {
+  if (!p) return hipSuccess;
+  // hipFree's contract, kept: when this returns nothing queued on the device uses the block any more
+  hipError_t e = hipDeviceSynchronize();
+  if (e != hipSuccess) (void)hipGetLastError();
+  std::lock_guard<std::mutex> lock(g_alloc_mu);
+  auto it = g_live.find(p);
+  if (it == g_live.end()) return hipFree(p);      // (not one of ours)
+  const DevBlock b = it->second;
+  g_live.erase(it);
+  const size_t cap = cache_cap();
+  if (b.bytes > cap) return hipFree(p);
+  evict_locked(b.bytes, cap);
+  g_cached.emplace(b.bytes, CachedBlock{p, b.device, g_alloc_stamp++});
+  g_cached_bytes += b.bytes;
+  return hipSuccess;
+}
+
+void dev_trim(int device) {
+  std::lock_guard<std::mutex> lock(g_alloc_mu);
+  for (auto it = g_cached.begin(); it != g_cached.end();) {
+    if (device >= 0 && it->second.device != device) { ++it; continue; }
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (cur != it->second.device) (void)hipSetDevice(it->second.device);
+    (void)hipFree(it->second.ptr);
+    if (cur != it->second.device) (void)hipSetDevice(cur);
+    g_cached_bytes -= it->first;
+    it = g_cached.erase(it);
+  }
+}
+
+void dev_cache_stats(uint64_t* live_blocks, uint64_t* cached_blocks, uint64_t* cached_bytes) {
+  std::lock_guard<std::mutex> lock(g_alloc_mu);
+  if (live_blocks) *live_blocks = g_live.size();
+  if (cached_blocks) *cached_blocks = g_cached.size();
+  if (cached_bytes) *cached_bytes = g_cached_bytes;
+}
+
 int Scratch::reserve(size_t need) {
   if (need <= bytes) return SMESH_OK;
-  if (ptr) SMESH_HIP(hipFree(ptr));
+  if (ptr) SMESH_HIP(dev_free(ptr));
   ptr = nullptr;
   bytes = 0;
   size_t want = need + need / 8 + 256;  // slack so that slowly growing images do not reallocate every call
-  SMESH_HIP(hipMalloc(&ptr, want));
+  SMESH_HIP(dev_malloc(&ptr, want));
   bytes = want;
   return SMESH_OK;
 }
 
 void Scratch::release() {
-  if (ptr) (void)hipFree(ptr);
+  if (ptr) (void)dev_free(ptr);
   ptr = nullptr;
   bytes = 0;
 }
@@ -346,7 +462,7 @@ int smesh_device_malloc(int device, uint64_t bytes, void** out) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));
   SMESH_HIP(hipSetDevice(device));
-  SMESH_HIP(hipMalloc(out, bytes ? bytes : 1));
+  SMESH_HIP(dev_malloc(out, bytes ? bytes : 1));
   return SMESH_OK;
 }
 
@@ -355,8 +471,23 @@ int smesh_device_free(int device, void* ptr) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));
   SMESH_HIP(hipSetDevice(device));
-  SMESH_HIP(hipStreamSynchronize(ctx->stream));
-  SMESH_HIP(hipFree(ptr));
+  SMESH_HIP(dev_free(ptr));      // (waits for the device, like hipFree; the block stays mapped for the next request of its size)
+  return SMESH_OK;
+}
+
+// Unmaps the device blocks the library keeps for reuse on `device` (-1: every device).  `cached_bytes` (may be NULL) receives what
+// was being held.  Nothing else changes: live handles keep their memory.
+int smesh_device_trim(int device, uint64_t* cached_bytes) {
+  uint64_t held = 0;
+  dev_cache_stats(nullptr, nullptr, &held);
+  if (cached_bytes) *cached_bytes = held;
+  if (device >= 0) {
+    DeviceCtx* ctx;
+    SMESH_TRY(get_ctx(device, &ctx));
+    SMESH_HIP(hipSetDevice(device));
+  }
+  (void)hipDeviceSynchronize();
+  dev_trim(device);
   return SMESH_OK;
 }
 

@@ -2395,7 +2395,7 @@ bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P) {
 static int ensure_acc_d(smesh_aggregator* a) {
   if (a->kind != SMESH_AGG_MUL || a->acc_d) return SMESH_OK;
   const size_t bytes = (size_t)a->P * a->C * sizeof(double);
-  SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&a->acc_d), bytes ? bytes : 16));
+  SMESH_HIP(dev_malloc(reinterpret_cast<void**>(&a->acc_d), bytes ? bytes : 16));
   SMESH_HIP(hipMemsetAsync(a->acc_d, 0, bytes, a->ctx->stream));
   return SMESH_OK;
 }
@@ -2614,16 +2614,16 @@ int smesh_aggregator_create(uint64_t P, uint32_t C, int kind, float iew, int dev
   if (!a) return fail(SMESH_ERR_RUNTIME, "out of memory");
   a->ctx = ctx; a->P = P; a->C = C; a->S = row_stride(C); a->kind = kind; a->iew = iew;
   const size_t acc_bytes = (size_t)P * a->S * 4;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&a->acc), acc_bytes ? acc_bytes : 16);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&a->count), P ? P * 4 : 16);
+  hipError_t e = dev_malloc(reinterpret_cast<void**>(&a->acc), acc_bytes ? acc_bytes : 16);
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&a->count), P ? P * 4 : 16);
   if (e == hipSuccess) e = hipMemsetAsync(a->acc, 0, acc_bytes, ctx->stream);   // Sum/Summax: 0; Mul: log 1 = 0
-  if (e == hipSuccess && kind == SMESH_AGG_MUL) e = hipMalloc(reinterpret_cast<void**>(&a->acc_lo), acc_bytes ? acc_bytes : 16);
+  if (e == hipSuccess && kind == SMESH_AGG_MUL) e = dev_malloc(reinterpret_cast<void**>(&a->acc_lo), acc_bytes ? acc_bytes : 16);
   if (e == hipSuccess && kind == SMESH_AGG_MUL) e = hipMemsetAsync(a->acc_lo, 0, acc_bytes, ctx->stream);
   if (e == hipSuccess) e = hipMemsetAsync(a->count, 0, P * 4, ctx->stream);
   if (e != hipSuccess) {
-    if (a->acc) (void)hipFree(a->acc);
-    if (a->acc_lo) (void)hipFree(a->acc_lo);
-    if (a->count) (void)hipFree(a->count);
+    if (a->acc) (void)dev_free(a->acc);
+    if (a->acc_lo) (void)dev_free(a->acc_lo);
+    if (a->count) (void)dev_free(a->count);
     delete a;
     return fail_hip(e, "aggregator allocation", __FILE__, __LINE__);
   }
@@ -2635,13 +2635,13 @@ int smesh_aggregator_create(uint64_t P, uint32_t C, int kind, float iew, int dev
 int smesh_aggregator_destroy(smesh_aggregator_t* a) {
   if (!a) return SMESH_OK;
   (void)hipSetDevice(a->ctx->device);
+  (void)hipStreamSynchronize(a->ctx->exchange_stream);   // (a row exchange may still be reading or writing the accumulator)
   (void)hipStreamSynchronize(a->ctx->stream);
-  (void)hipFree(a->acc);
-  if (a->acc_lo) (void)hipFree(a->acc_lo);
-  if (a->acc_d) (void)hipFree(a->acc_d);
-  (void)hipFree(a->count);
+  (void)dev_free(a->acc);
+  if (a->acc_lo) (void)dev_free(a->acc_lo);
+  if (a->acc_d) (void)dev_free(a->acc_d);
+  (void)dev_free(a->count);
   if (a->ev_staged) (void)hipEventDestroy(a->ev_staged);
-  (void)hipStreamSynchronize(a->ctx->exchange_stream);
   if (a->ev_part) (void)hipEventDestroy(a->ev_part);
   if (a->ev_xchg) (void)hipEventDestroy(a->ev_xchg);
   a->xchg_stage.release();
@@ -2959,6 +2959,8 @@ int smesh_aggregator_set_raw_rows(smesh_aggregator_t* a, uint64_t row_lo, uint64
 int smesh_aggregator_raw_pointer(smesh_aggregator_t* a, void** ptr, uint64_t* n) {
   if (!a || !ptr) return fail(SMESH_ERR_INVALID, "NULL argument");
   // callers (the RCCL all-reduce) use this from another stream: make sure our work is done first
+  std::lock_guard<std::mutex> g(a->mu);
+  std::lock_guard<std::recursive_mutex> lock(a->ctx->mu);
   SMESH_HIP(hipSetDevice(a->ctx->device));
   SMESH_TRY(smesh_aggregator_join_exchange(a));
   SMESH_TRY(mul_normalise(a, true));
@@ -3004,12 +3006,12 @@ int smesh_aggregator_renderer(smesh_aggregator_t* a, smesh_annotation_renderer_t
   if (!r) return fail(SMESH_ERR_RUNTIME, "out of memory");
   r->ctx = ctx; r->P = a->P; r->C = a->C;
   const size_t bytes = (size_t)a->P * a->C * 4;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->ann), bytes ? bytes : 16);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->bg), (size_t)a->C * 4);
-  if (e != hipSuccess) { if (r->ann) (void)hipFree(r->ann); delete r; return fail_hip(e, "annotation renderer allocation", __FILE__, __LINE__); }
+  hipError_t e = dev_malloc(reinterpret_cast<void**>(&r->ann), bytes ? bytes : 16);
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&r->bg), (size_t)a->C * 4);
+  if (e != hipSuccess) { if (r->ann) (void)dev_free(r->ann); delete r; return fail_hip(e, "annotation renderer allocation", __FILE__, __LINE__); }
   int st = bytes ? finalize_into(a, r->ann) : SMESH_OK;   // m_annotations = elwise(get)  (Mesh.h:127)
   if (st == SMESH_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = fail(SMESH_ERR_RUNTIME, "stream sync failed");
-  if (st) { (void)hipFree(r->ann); (void)hipFree(r->bg); delete r; return st; }
+  if (st) { (void)dev_free(r->ann); (void)dev_free(r->bg); delete r; return st; }
   *out = r;
   return SMESH_OK;
 }
@@ -3050,8 +3052,8 @@ int smesh_annotation_renderer_destroy(smesh_annotation_renderer_t* r) {
   if (!r) return SMESH_OK;
   (void)hipSetDevice(r->ctx->device);
   (void)hipStreamSynchronize(r->ctx->stream);
-  (void)hipFree(r->ann);
-  (void)hipFree(r->bg);
+  (void)dev_free(r->ann);
+  (void)dev_free(r->bg);
   r->st_idx.release(); r->nm_idx.release(); r->out_tmp.release();
   delete r;
   return SMESH_OK;

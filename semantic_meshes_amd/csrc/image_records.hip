@@ -549,7 +549,7 @@ namespace smesh {
 static size_t block_bytes(uint64_t P) { return (((size_t)P * (sizeof(TriFrag) + 4) + 16) + 15) & ~(size_t)15; }
 
 void ImageRecords::release() {
-  if (frags) (void)hipFree(frags);
+  if (frags) (void)dev_free(frags);
   frags = nullptr; cand = nullptr; big4 = nullptr; big_queue = nullptr; big_count = nullptr; mom = nullptr;
   P = 0; clean = false;
 }
@@ -570,7 +570,7 @@ int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, 
     const size_t n = (size_t)(P ? P : 1);
     char* base = nullptr;
     const size_t total = block_bytes(n) + n * (sizeof(uint4) + 8 + 4);
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&base), total);
+    hipError_t e = dev_malloc(reinterpret_cast<void**>(&base), total);
     if (e != hipSuccess) return fail_hip(e, "image records allocation", __FILE__, __LINE__);
     r.frags = reinterpret_cast<TriFrag*>(base);
     r.cand = reinterpret_cast<uint32_t*>(base + n * sizeof(TriFrag));

@@ -1178,10 +1178,10 @@ void mesh_bounds(const float* v, uint64_t V, const int32_t* f, uint64_t F, smesh
 int ensure_keys(smesh_renderer::ViewScratch& vs, uint64_t W, uint64_t H, hipStream_t st) {
   const uint64_t N = div_up(W, 4) * div_up(H, 4) * 16;   // 4 x 4 blocked layout, padded
   if (N <= vs.keys_pixels) return SMESH_OK;
-  if (vs.keys) SMESH_HIP(hipFree(vs.keys));
+  if (vs.keys) SMESH_HIP(dev_free(vs.keys));
   vs.keys = nullptr;
   vs.keys_pixels = 0;
-  SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&vs.keys), N * 8));
+  SMESH_HIP(dev_malloc(reinterpret_cast<void**>(&vs.keys), N * 8));
   vs.keys_pixels = N;
   hipLaunchKernelGGL(k_fill_keys, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, vs.keys, N);
   SMESH_HIP(hipGetLastError());
@@ -1218,13 +1218,13 @@ bool ensure_queues(smesh_renderer* r, smesh_renderer::ViewScratch& vs, uint64_t 
     (void)hipStreamSynchronize(r->ctx->stream);
     (void)hipStreamSynchronize(r->ctx->raster_stream);
     for (void* p : {(void*)vs.fq.key, (void*)vs.fq.pix, (void*)vs.fq.count, (void*)vs.fq.flag})
-      if (p) (void)hipFree(p);
+      if (p) (void)dev_free(p);
     vs.fq = FragQueues();
     vs.fq_tiles = 0;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&vs.fq.key), ntiles * kQSub * cap * 8);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&vs.fq.pix), ntiles * kQSub * cap * 2);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&vs.fq.count), ntiles * kQSub * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&vs.fq.flag), ntiles * 4);
+    hipError_t e = dev_malloc(reinterpret_cast<void**>(&vs.fq.key), ntiles * kQSub * cap * 8);
+    if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&vs.fq.pix), ntiles * kQSub * cap * 2);
+    if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&vs.fq.count), ntiles * kQSub * 4);
+    if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&vs.fq.flag), ntiles * 4);
     if (e == hipSuccess) e = hipMemsetAsync(vs.fq.count, 0, ntiles * kQSub * 4, st);
     if (e == hipSuccess) e = hipMemsetAsync(vs.fq.flag, 0, ntiles * 4, st);
     if (e != hipSuccess) { *status = fail_hip(e, "fragment queue allocation", __FILE__, __LINE__); return false; }
@@ -1333,8 +1333,8 @@ hipError_t alloc_side(smesh_renderer* r, int i);
 hipError_t alloc_scratch(smesh_renderer* r, int i) {
   smesh_renderer::ViewScratch& vs = r->vs[i];
   hipError_t e = hipSuccess;
-  if (!vs.sv) e = hipMalloc(reinterpret_cast<void**>(&vs.sv), std::max<uint64_t>(r->V * sizeof(ScreenVertex), 16));
-  if (e == hipSuccess && !vs.huge_queue) e = hipMalloc(reinterpret_cast<void**>(&vs.huge_queue), (size_t)r->big_capacity * 4);
+  if (!vs.sv) e = dev_malloc(reinterpret_cast<void**>(&vs.sv), std::max<uint64_t>(r->V * sizeof(ScreenVertex), 16));
+  if (e == hipSuccess && !vs.huge_queue) e = dev_malloc(reinterpret_cast<void**>(&vs.huge_queue), (size_t)r->big_capacity * 4);
   return e;
 }
 
@@ -1433,17 +1433,17 @@ int acquire_image(smesh_renderer* r, uint64_t N, ImagePair** out) {
     ImagePair& im = r->images[i];
     if (!im.idx_out && !im.depth_out) {
       SMESH_HIP(hipStreamSynchronize(r->ctx->stream));
-      (void)hipFree(im.idx);
-      (void)hipFree(im.depth);
+      (void)dev_free(im.idx);
+      (void)dev_free(im.depth);
       r->images.erase(r->images.begin() + i);
     } else {
       i++;
     }
   }
   ImagePair im{nullptr, nullptr, N, false, false};
-  SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&im.idx), N * 4));
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&im.depth), N * 4);
-  if (e != hipSuccess) { (void)hipFree(im.idx); return fail_hip(e, "hipMalloc depth plane", __FILE__, __LINE__); }
+  SMESH_HIP(dev_malloc(reinterpret_cast<void**>(&im.idx), N * 4));
+  hipError_t e = dev_malloc(reinterpret_cast<void**>(&im.depth), N * 4);
+  if (e != hipSuccess) { (void)dev_free(im.idx); return fail_hip(e, "hipMalloc depth plane", __FILE__, __LINE__); }
   r->images.push_back(im);
   *out = &r->images.back();
   return SMESH_OK;
@@ -1461,9 +1461,9 @@ int check_camera(const smesh_camera_t* cam) {
 hipError_t alloc_side(smesh_renderer* r, int i) {
   smesh_renderer::Side& sd = r->side[i];
   if (sd.frags) return hipSuccess;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&sd.big_queue), (size_t)r->big_capacity * 8);   // (upper half: the medium triangles again, push_mid)
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sd.big_count), 16);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&sd.frags), std::max<uint64_t>(r->F * sizeof(TriFrag), 16));
+  hipError_t e = dev_malloc(reinterpret_cast<void**>(&sd.big_queue), (size_t)r->big_capacity * 8);   // (upper half: the medium triangles again, push_mid)
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&sd.big_count), 16);
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&sd.frags), std::max<uint64_t>(r->F * sizeof(TriFrag), 16));
   if (e == hipSuccess) e = hipMemsetAsync(sd.big_count, 0, 16, r->ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(r->ctx->stream);
   return e;
@@ -1564,11 +1564,11 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   r->ctx = ctx; r->V = V; r->F = F; r->num_primitives = F;
   r->big_capacity = (uint32_t)std::max<uint64_t>(F, 1);
   mesh_bounds(vertices, V, faces, F, r->bounds);
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->verts), std::max<uint64_t>(V * 12, 16));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->faces), std::max<uint64_t>(F * 12, 16));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->vs[0].sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
+  hipError_t e = dev_malloc(reinterpret_cast<void**>(&r->verts), std::max<uint64_t>(V * 12, 16));
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&r->faces), std::max<uint64_t>(F * 12, 16));
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&r->vs[0].sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
   if (e == hipSuccess) e = alloc_side(r, 0);
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->vs[0].huge_queue), (size_t)r->big_capacity * 4);
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&r->vs[0].huge_queue), (size_t)r->big_capacity * 4);
   if (e == hipSuccess && V) e = hipMemcpyAsync(r->verts, vertices, V * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1707,7 +1707,7 @@ int smesh_renderer_create_triangles(const float* vertices, uint64_t V, const int
     for (int k = 0; k < 3; k++) hf[3 * i + k] = faces[3 * (uint64_t)order[i] + k];
   smesh_renderer* r = nullptr;
   SMESH_TRY(create_common(vertices, V, hf.data(), F, device, &r));
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->prim_id), F * 4);
+  hipError_t e = dev_malloc(reinterpret_cast<void**>(&r->prim_id), F * 4);
   if (e == hipSuccess) e = hipMemcpyAsync(r->prim_id, order.data(), F * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
   if (e != hipSuccess) { smesh_renderer_destroy(r); return fail_hip(e, "primitive id table upload", __FILE__, __LINE__); }
@@ -1767,9 +1767,9 @@ int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_
     smesh_camera_t* d_cams = nullptr;
     float* d_best = nullptr;
     int32_t* d_faces = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_cams), K * sizeof(smesh_camera_t));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_best), F * 4);
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_faces), F * 12);
+    hipError_t e = dev_malloc(reinterpret_cast<void**>(&d_cams), K * sizeof(smesh_camera_t));
+    if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&d_best), F * 4);
+    if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&d_faces), F * 12);
     if (e == hipSuccess) e = hipMemcpyAsync(d_cams, cameras, K * sizeof(smesh_camera_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
@@ -1779,9 +1779,9 @@ int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_
     }
     if (e == hipSuccess) e = hipMemcpyAsync(best.data(), d_best, F * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (d_cams) (void)hipFree(d_cams);
-    if (d_best) (void)hipFree(d_best);
-    if (d_faces) (void)hipFree(d_faces);
+    if (d_cams) (void)dev_free(d_cams);
+    if (d_best) (void)dev_free(d_best);
+    if (d_faces) (void)dev_free(d_faces);
     if (e != hipSuccess) { smesh_renderer_destroy(r); return fail_hip(e, "texel area reduction", __FILE__, __LINE__); }
   }
   uint64_t total = 0;
@@ -1793,8 +1793,8 @@ int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_
   }
   if (total >= 0xFFFFFFFFull) { smesh_renderer_destroy(r); return fail(SMESH_ERR_INVALID, "texel count overflows uint32"); }
   r->num_primitives = total;
-  hipError_t e = hipMalloc(reinterpret_cast<void**>(&r->tex_res), std::max<uint64_t>(F * 4, 16));
-  if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&r->tex_first), std::max<uint64_t>(F * 4, 16));
+  hipError_t e = dev_malloc(reinterpret_cast<void**>(&r->tex_res), std::max<uint64_t>(F * 4, 16));
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&r->tex_first), std::max<uint64_t>(F * 4, 16));
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->tex_res, r->h_res.data(), F * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->tex_first, r->h_first.data(), F * 4, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -1809,17 +1809,17 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   (void)hipStreamSynchronize(r->ctx->raster_stream);
   (void)hipStreamSynchronize(r->ctx->stream);
   for (void* p : {(void*)r->prim_id, (void*)r->verts, (void*)r->faces, (void*)r->tex_res, (void*)r->tex_first})
-    if (p) (void)hipFree(p);
+    if (p) (void)dev_free(p);
   for (auto& sd : r->side)
     for (void* p : {(void*)sd.big_queue, (void*)sd.big_count, (void*)sd.frags})
-      if (p) (void)hipFree(p);
+      if (p) (void)dev_free(p);
   for (auto& vs : r->vs)
     for (void* p : {(void*)vs.sv, (void*)vs.huge_queue, (void*)vs.keys, (void*)vs.fq.key, (void*)vs.fq.pix, (void*)vs.fq.count, (void*)vs.fq.flag})
-      if (p) (void)hipFree(p);
-  for (auto& im : r->images) { (void)hipFree(im.idx); (void)hipFree(im.depth); }
+      if (p) (void)dev_free(p);
+  for (auto& im : r->images) { (void)dev_free(im.idx); (void)dev_free(im.depth); }
   r->own_idx.release();
   r->match_stage.release();
-  if (r->d_hash) (void)hipFree(r->d_hash);
+  if (r->d_hash) (void)dev_free(r->d_hash);
   for (int sd = 0; sd < kRecordSides; sd++)
     if (r->hash_ev[sd]) (void)hipEventDestroy(r->hash_ev[sd]);
   for (auto& f : r->fused) f.release();
@@ -2344,7 +2344,7 @@ int smesh_renderer_seal_render(smesh_renderer_t* r, const uint32_t* indices_dev)
     if (r->last_idx[sd] != indices_dev || !r->rec_valid[sd] || r->hash_valid[sd]) continue;
     SMESH_HIP(hipSetDevice(ctx->device));
     if (!r->d_hash) {
-      SMESH_HIP(hipMalloc(reinterpret_cast<void**>(&r->d_hash), (kRecordSides + 1) * sizeof(unsigned long long)));
+      SMESH_HIP(dev_malloc(reinterpret_cast<void**>(&r->d_hash), (kRecordSides + 1) * sizeof(unsigned long long)));
       SMESH_HIP(hipMemsetAsync(r->d_hash, 0, (kRecordSides + 1) * sizeof(unsigned long long), ctx->stream));
     }
     SMESH_TRY(plane_checksum(ctx, ctx->stream, indices_dev, r->last_W[sd] * r->last_H[sd], r->d_hash + sd));

@@ -74,6 +74,9 @@ def allreduce_rows_raw(aggregator, row_lo, row_hi, group=None, comm=None):
     dist = _dist()
     if not dist.is_available() or not dist.is_initialized() or row_hi <= row_lo:
         return aggregator
+    import os
+    if dist.get_world_size(group) == 1 and not os.environ.get("SMESH_FORCE_ALLREDUCE"):
+        return aggregator          # (as allreduce_raw: nothing to add, no round trip through the host)
     import torch
     if dist.get_backend(group) == "nccl" and hasattr(aggregator, "raw_device_array"):
         # in place in HBM on torch's stream (Mul: the pair folded into the float32 hi plane first -- the exact float64 exchange is
@@ -103,6 +106,14 @@ def allreduce_rows_raw(aggregator, row_lo, row_hi, group=None, comm=None):
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     aggregator.set_raw_rows(row_lo, raw, 0)
     return aggregator
+
+
+def part_rows(primitives, part, nparts):
+    """Accumulator rows [lo, hi) that part `part` of `nparts` of a job cut by row range leaves final (`smesh_fuse_part_rows`: whole
+    64-row blocks).  A function of its arguments alone -- every rank of a sharded job derives the same ranges from it."""
+    P, part, nparts = int(primitives), int(part), int(nparts)
+    blocks = (P + 63) // 64
+    return min(P, 64 * (blocks * part // nparts)), min(P, 64 * (blocks * (part + 1) // nparts))
 
 
 def owned_rows(primitives, rank, world_size):
@@ -147,7 +158,8 @@ def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None,
                        exchange="allreduce", nparts=4, held=24):
     """Fuse this rank's share of `cameras` and exchange.  `probs_of_view(k)` returns the (W,H,C) class-probability image of view k
     (host or device).  `comm`: native communicator (see allreduce_raw).  Returns `(aggregator, (row_lo, row_hi))`: the rows of
-    THIS rank's accumulator that hold the fusion of all views afterwards.
+    THIS rank's accumulator that hold the fusion of all views afterwards.  (Until round 3 the function returned the aggregator
+    alone -- or the row range alone for a reduce-scatter -- and read SMESH_EXCHANGE; callers of that contract unpack the pair now.)
 
     `exchange` (an explicit argument, never the environment):
       "allreduce" (default, what north_star names) -- every rank ends with the whole fusion, rows (0, P).  With `nparts` > 1 the last
@@ -167,8 +179,11 @@ def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None,
         else:
             rank, world = 0, 1
     mine = list(shard_views(len(cameras), rank, world, contiguous))
-    ranged = exchange == "allreduce" and int(nparts) > 1 and hasattr(aggregator, "fuse_views_ranged") and len(mine) > 0
-    tail = mine[max(0, len(mine) - min(int(held), 32)):] if ranged else []
+    # Every rank must issue the SAME sequence of collectives whatever its share of the views is (a rank without views, a rank whose
+    # library call fell back to the unranged job): whether the exchange is cut, and into which row ranges, is a function of
+    # (primitives, nparts) alone -- `part_rows` -- never of this rank's views.
+    ranged = exchange == "allreduce" and int(nparts) > 1 and hasattr(aggregator, "fuse_views_ranged")
+    tail = mine[max(0, len(mine) - max(1, min(int(held), 32))):] if ranged else []
     head = mine[:len(mine) - len(tail)]
     if hasattr(aggregator, "fuse_views"):
         # eight views per call: the library shares rasteriser and fusion launches between them
@@ -182,10 +197,22 @@ def fuse_views_sharded(renderer, aggregator, cameras, probs_of_view, group=None,
     if exchange == "reduce_scatter":
         return aggregator, tuple(reduce_scatter_raw(aggregator, group, comm))
     if ranged:
-        images = [probs_of_view(k) for k in tail]      # (kept alive until the last part has been queued)
-        aggregator.fuse_views_ranged(renderer, [cameras[k] for k in tail], images, nparts=int(nparts),
-                                     on_rows=lambda lo, hi: allreduce_rows_raw(aggregator, lo, hi, group, comm))
-        del images
+        canon = [r for r in (part_rows(aggregator.primitives, p, int(nparts)) for p in range(int(nparts))) if r[1] > r[0]]
+        sent = []
+
+        def on_rows(lo, hi):
+            # a finished range is exchanged at once if it is the next one of the canonical sequence; anything else (the library
+            # fused everything with part 0: host images, a re-ordered mesh, a texel renderer ...) waits for the end of the call
+            if len(sent) < len(canon) and (lo, hi) == canon[len(sent)]:
+                sent.append((lo, hi))
+                allreduce_rows_raw(aggregator, lo, hi, group, comm)
+
+        if tail:
+            images = [probs_of_view(k) for k in tail]      # (kept alive until the last part has been queued)
+            aggregator.fuse_views_ranged(renderer, [cameras[k] for k in tail], images, nparts=int(nparts), on_rows=on_rows)
+            del images
+        for lo, hi in canon[len(sent):]:                    # (a rank without views; ranges the call above did not report)
+            allreduce_rows_raw(aggregator, lo, hi, group, comm)
     else:
         allreduce_raw(aggregator, group, comm)
     return aggregator, (0, aggregator.primitives)

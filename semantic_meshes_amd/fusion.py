@@ -5,6 +5,7 @@ include/Fusion.h:42-76 (add1/add2/reset/get), /root/reference/include/semantic_m
 The class count is a run-time value here (compile-time CLASSES_NUMS list in the reference).
 """
 import ctypes
+import threading
 
 import numpy as np
 
@@ -32,6 +33,7 @@ class _MeshAggregator:
                                                      self.images_equal_weight, self.device, ctypes.byref(h)))
         self._h = h
         self._inflight = []     # (completion token, [objects]) of asynchronous calls whose device inputs may still be being read
+        self._inflight_lock = threading.Lock()   # (the harness adds from a worker thread while the main thread may call get())
 
     def _hold(self, keepalives):
         """The asynchronous entry points read DEVICE images after they return.  `release_to()` orders the stream `describe()` guessed for
@@ -45,21 +47,27 @@ class _MeshAggregator:
             return
         tok = ctypes.c_uint64(0)
         _lib.check(_lib.lib().smesh_token_record(self.device, ctypes.byref(tok)))
-        self._inflight.append((tok.value, foreign))
+        with self._inflight_lock:
+            self._inflight.append((tok.value, foreign))
 
     def _drain(self):
         done = ctypes.c_int(0)
-        while self._inflight:
-            _lib.check(_lib.lib().smesh_token_done(self.device, ctypes.c_uint64(self._inflight[0][0]), ctypes.byref(done)))
-            if not done.value:
-                break
-            self._inflight.pop(0)
+        with self._inflight_lock:      # (a token goes back to the library's pool exactly once)
+            while self._inflight:
+                _lib.check(_lib.lib().smesh_token_done(self.device, ctypes.c_uint64(self._inflight[0][0]), ctypes.byref(done)))
+                if not done.value:
+                    break
+                self._inflight.pop(0)
 
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h is not None and h.value:
             try:
-                _lib.lib().smesh_aggregator_destroy(h)
+                _lib.lib().smesh_aggregator_destroy(h)      # (waits for the device: every outstanding token is done afterwards)
+                done = ctypes.c_int(0)
+                for tok, _ in getattr(self, "_inflight", []):
+                    _lib.lib().smesh_token_done(self.device, ctypes.c_uint64(tok), ctypes.byref(done))   # hands the event back to the pool
+                self._inflight = []
             except Exception:
                 pass
 

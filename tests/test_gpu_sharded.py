@@ -29,13 +29,47 @@ assert _lib.lib().smesh_backend() == b"hip-gfx950"
 mesh, cams = small_scene(60, 30, 320, 240, views=8)
 P, C = len(mesh.faces), 19
 renderer = sm.render.triangles(mesh)
+repeats = int(os.environ.get("SMESH_SHARDED_REPEATS", "1"))
+dump_dir = os.environ["SMESH_DUMP_DIR"]
 
 def probs_of_view(k):
     W, H = cams[k].resolution
     return synth.device_probs(W, H, C, synth.probs_seed(3, k), 0.05, 0)
 
+# Self-diagnosis (VERDICT r4 next #1): every host-side exchange of a row range is bracketed by snapshots of the rows it moves --
+# this rank's partial sums going in, the sums over ranks coming out -- which every rank writes per leg; a leg that fails also writes
+# them, with what it compared, to SMESH_DUMP_DIR/FAILED_rank<r>_<kind>_<leg>_<repeat>.npz before it raises.  The parent then adds
+# the ranks' partial sums up itself (diagnose_sharded_dumps): partial sums that do not add up to the single-process job -> a rank's
+# FUSION lost or doubled something; they do, and the rows coming out of the exchange differ -> the EXCHANGE; both fine -> get() /
+# get_rows().
+snap = []
+_exchange = smdist.allreduce_rows_raw
+def _spied(aggregator, row_lo, row_hi, group=None, comm=None):
+    pre = aggregator.get_raw_rows(row_lo, row_hi)
+    out = _exchange(aggregator, row_lo, row_hi, group, comm)
+    snap.append((int(row_lo), int(row_hi), pre, aggregator.get_raw_rows(row_lo, row_hi)))
+    return out
+smdist.allreduce_rows_raw = _spied
+
+def leg(name, kind, rep, check, **arrays):
+    out = dict(arrays, repeat=np.asarray(rep))
+    for i, (lo, hi, pre, post) in enumerate(snap):
+        out["x%d_range" % i] = np.asarray([lo, hi]); out["x%d_pre" % i] = pre; out["x%d_post" % i] = post
+    del snap[:]
+    # every rank leaves what it exchanged in this leg (overwritten by the next repeat): when ONE rank fails, its peers stop at the next
+    # collective with this leg's file still in place, and the parent adds the partial sums of all ranks up
+    np.savez(os.path.join(os.environ["SMESH_SNAP_DIR"], "rank%d_%s_%s.npz" % (rank, kind, name)), **out)
+    try:
+        check()
+    except AssertionError as e:
+        path = os.path.join(dump_dir, "FAILED_rank%d_%s_%s_%d.npz" % (rank, kind, name, rep))
+        np.savez(path, **out)
+        print("SHARDED-MISMATCH rank %d kind %s leg %s repeat %d -> %s: %s" % (rank, kind, name, rep, path, e), flush=True)
+        raise
+
 out = {}
-for kind in ("sum", "summax", "mul"):
+for rep in range(repeats):
+  for kind in ("sum", "summax", "mul"):
     whole = sm.fusion.MeshAggregator(P, C, kind)
     whole.fuse_views(renderer, cams, [probs_of_view(k) for k in range(len(cams))])
     want, want_raw = whole.get(), whole.get_raw()
@@ -45,28 +79,102 @@ for kind in ("sum", "summax", "mul"):
     assert rows == (0, P)
     kernel = _lib.lib().smesh_last_fuse_kernel().decode()
     assert kernel.startswith("k_fuse_tri"), kernel            # the HIP triangle-order path ran on this rank's shard
-    got = agg.get()
+    got, got_raw = agg.get(), agg.get_raw()
     # partial float32 sums added once instead of eight terms in order: 1e-5 for every aggregator (Mul's (hi, lo) pairs travel as float64)
-    assert_fused_close(got, want, rtol=1e-5)
-    np.testing.assert_allclose(agg.get_raw(), want_raw, rtol=1e-5, atol=1e-5)
+    def ranged():
+        assert_fused_close(got, want, rtol=1e-5)
+        np.testing.assert_allclose(got_raw, want_raw, rtol=1e-5, atol=1e-5)
+    leg("ranged", kind, rep, ranged, got=got, want=want, got_raw=got_raw, want_raw=want_raw)
     assert (want.sum(axis=1) > 0.5).sum() > P // 3
     # ... and ONE all-reduce after the last view (nparts = 1): the same sums
     agg1 = sm.fusion.MeshAggregator(P, C, kind)
     smdist.fuse_views_sharded(renderer, agg1, cams, probs_of_view, contiguous=(kind != "summax"), nparts=1)
-    assert_fused_close(agg1.get(), want, rtol=1e-5)
-    # (per row the same float32 additions in the same order; the sum over ranks may associate differently per range)
-    np.testing.assert_allclose(agg1.get_raw(), agg.get_raw(), rtol=2e-6, atol=1e-6)
+    got1, got1_raw = agg1.get(), agg1.get_raw()
+    def single():
+        assert_fused_close(got1, want, rtol=1e-5)
+        # (per row the same float32 additions in the same order; the sum over ranks may associate differently per range)
+        np.testing.assert_allclose(got1_raw, got_raw, rtol=2e-6, atol=1e-6)
+    leg("one_exchange", kind, rep, single, got=got1, want=want, got_raw=got1_raw, want_raw=want_raw)
     # opt-in exchange: this rank normalises its own slice of rows
     agg2 = sm.fusion.MeshAggregator(P, C, kind)
     _, (lo, hi) = smdist.fuse_views_sharded(renderer, agg2, cams, probs_of_view, exchange="reduce_scatter")
     assert (lo, hi) == smdist.owned_rows(P, rank, world)
-    assert_fused_close(agg2.get_rows(lo, hi), want[lo:hi], rtol=1e-5)
+    got2 = agg2.get_rows(lo, hi)
+    def scattered():
+        assert_fused_close(got2, want[lo:hi], rtol=1e-5)
+    leg("reduce_scatter", kind, rep, scattered, got=got2, want=want[lo:hi], rows=np.asarray([lo, hi]), want_raw=want_raw,
+        got_raw=agg2.get_raw_rows(0, P))
     out[kind] = got
 np.savez(os.environ["SMESH_OUT"], **out)
 dist.barrier()
 dist.destroy_process_group()
 print("rank %d ok" % rank)
 '''
+
+
+def run_sharded_workers(tmp_path, world, repeats=1, timeout=600):
+    """Launches WORKER as `world` ranks sharing the box's GPU; returns (return codes, outputs, dump directory).  A rank whose leg
+    fails leaves FAILED_rank<r>_<kind>_<leg>_<repeat>.npz in gpurun_out/sharded_dump (which comes back from the GPU box); the
+    per-leg snapshots of ALL ranks are then copied beside it."""
+    import glob
+    import shutil
+    script = os.path.join(tmp_path, "worker.py")
+    open(script, "w").write(WORKER)
+    dump_dir = os.path.join(ROOT, "gpurun_out", "sharded_dump")
+    os.makedirs(dump_dir, exist_ok=True)
+    port = _free_port()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   SMESH_ROOT=ROOT, SMESH_OUT=os.path.join(tmp_path, "rank%d.npz" % rank), OMP_NUM_THREADS="1",
+                   SMESH_DUMP_DIR=dump_dir, SMESH_SNAP_DIR=str(tmp_path), SMESH_SHARDED_REPEATS=str(repeats))
+        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = []
+    deadline = None
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout if deadline is None else 20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            out, _ = p.communicate()
+        if p.returncode != 0:
+            deadline = True     # (a failed rank leaves its peers blocked in the next collective: no point in waiting `timeout` for each)
+        outs.append(out.decode(errors="replace"))
+    codes = [p.returncode for p in procs]
+    if any(codes):
+        for path in glob.glob(os.path.join(tmp_path, "rank*_*_*.npz")):
+            shutil.copy(path, dump_dir)
+    return codes, outs, dump_dir
+
+
+def diagnose_sharded_dumps(dump_dir):
+    """What the dumps of a failed run say, one line per failed leg: which stage produced the wrong rows -- a rank's fusion (the
+    partial sums of the ranks do not add up to the single-process sums), the exchange (they do, what came out of it differs) or the
+    read-out (both fine)."""
+    import glob
+    lines = []
+    for path in sorted(glob.glob(os.path.join(dump_dir, "FAILED_rank*.npz"))):
+        name = os.path.basename(path)[len("FAILED_"):-len(".npz")]
+        rank_s, kind, rest = name.split("_", 2)
+        legname, rep = rest.rsplit("_", 1)
+        d = np.load(path)
+        peers = [np.load(q) for q in sorted(glob.glob(os.path.join(dump_dir, "rank*_%s_%s.npz" % (kind, legname))))]
+        peers = [q for q in peers if int(q["repeat"]) == int(rep)]
+        verdict = ["%d peer snapshots of repeat %s" % (len(peers), rep)]
+        n = 0
+        while "x%d_range" % n in d:
+            lo, hi = (int(v) for v in d["x%d_range" % n])
+            post, want = d["x%d_post" % n].astype(np.float64), d["want_raw"][lo:hi].astype(np.float64)
+            tol = 1e-5 * np.abs(want) + 1e-5
+            verdict.append("rows [%d, %d): %d rows out of the exchange differ from the single-process sums" % (lo, hi, (np.abs(post - want) > tol).any(axis=1).sum()))
+            if peers and all("x%d_pre" % n in q for q in peers) and kind != "mul":
+                total = sum(q["x%d_pre" % n].astype(np.float64) for q in peers)
+                verdict.append("sum of the %d ranks' partial sums: %d rows differ from the single-process sums (FUSION if > 0), %d rows "
+                               "differ from what the exchange returned (EXCHANGE if > 0)" % (
+                                   len(peers), (np.abs(total - want) > tol).any(axis=1).sum(), (np.abs(total - post) > tol).any(axis=1).sum()))
+            n += 1
+        lines.append("%s: %s" % (os.path.basename(path), "; ".join(verdict)))
+    return lines
 
 
 def _free_port():
@@ -80,24 +188,9 @@ def _free_port():
 @pytest.mark.parametrize("world", [2, 8])
 def test_ranks_on_one_gpu_hip_aggregators_equal_the_single_process_job(tmp_path, sm, oracle, world):
     """Two ranks, and cfg3's eight (one view per rank of the eight-view scene), sharing the test box's GPU."""
-    script = os.path.join(tmp_path, "worker.py")
-    open(script, "w").write(WORKER)
-    port = _free_port()
-    procs = []
-    for rank in range(world):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   SMESH_ROOT=ROOT, SMESH_OUT=os.path.join(tmp_path, "rank%d.npz" % rank), OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, script], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
-    outs = []
-    for p in procs:
-        try:
-            out, _ = p.communicate(timeout=600)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            out, _ = p.communicate()
-        outs.append(out.decode(errors="replace"))
-    for rank, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-3000:])
+    codes, outs, dump_dir = run_sharded_workers(tmp_path, world)
+    for rank, (code, out) in enumerate(zip(codes, outs)):
+        assert code == 0, "rank %d failed:\n%s\n%s" % (rank, out[-3000:], "\n".join(diagnose_sharded_dumps(dump_dir)))
         assert "rank %d ok" % rank in out
     # every rank holds the same result (an all-reduce), and it is the oracle's fusion of all eight views
     from helpers import small_scene, assert_fused_close
@@ -310,3 +403,51 @@ def test_cfg3_geometry_eight_ranks_on_one_gpu(tmp_path, sm):
     from helpers import assert_fused_close
     assert (want.sum(axis=1) > 0.5).sum() > len(rows) // 4
     assert_fused_close(fused, want, rtol=1e-5)
+
+
+GROUPED = r'''
+import os, sys, ctypes
+import numpy as np
+sys.path.insert(0, os.environ["SMESH_ROOT"])
+sys.path.insert(0, os.path.join(os.environ["SMESH_ROOT"], "tests"))
+import semantic_meshes_amd as sm
+from semantic_meshes_amd import comm as smcomm, synth
+from helpers import small_scene, assert_fused_close
+mesh, cams = small_scene(60, 30, 320, 240, views=6)
+P, C = len(mesh.faces), 19
+renderer = sm.render.triangles(mesh)
+probs = [synth.device_probs(320, 240, C, synth.probs_seed(6, k), 0.05, 0) for k in range(len(cams))]
+comms = smcomm.create_all([0, 0, 0])          # three "GPUs" of one process (the mock's ranks), all on device 0
+assert [c.nranks() for c in comms] == [(0, 3), (1, 3), (2, 3)]
+for kind in ("sum", "summax", "mul"):
+    whole = sm.fusion.MeshAggregator(P, C, kind)
+    whole.fuse_views(renderer, cams, probs)
+    aggs = [sm.fusion.MeshAggregator(P, C, kind) for _ in comms]
+    for r, a in enumerate(aggs):
+        a.fuse_views(renderer, cams[2 * r:2 * r + 2], probs[2 * r:2 * r + 2])
+    partial = aggs[0].get()
+    smcomm.allreduce_all(comms, aggs)
+    for a in aggs:
+        assert_fused_close(a.get(), whole.get(), rtol=1e-5)
+    assert np.abs(partial - whole.get()).max() > 1e-3          # (the partial sums of one rank are NOT the fusion: the reduction did something)
+mock = ctypes.CDLL(os.environ["SMESH_RCCL_LIB"])
+assert mock.mock_rccl_groups_with_work() == 3, mock.mock_rccl_groups_with_work()
+print("grouped ok")
+'''
+
+
+def test_grouped_allreduce_of_one_process_driving_several_gpus(tmp_path, sm):
+    """`smesh_allreduce` with n > 1 (`comm.create_all` + `comm.allreduce_all`: one process, several GPUs, the collectives grouped).
+    RCCL refuses two ranks per device, so on the one-GPU box the library is pointed at tests/mock_rccl.hip (SMESH_RCCL_LIB), which
+    keeps RCCL's group semantics: a grouped ncclAllReduce reaches its stream at ncclGroupEnd.  ADVICE r4 (high): the Mul epilogue
+    (float64 image -> (hi, lo) pairs) was launched inside the group, i.e. ahead of the reduction, and every GPU kept its own partial
+    sums without an error.  Three ranks, Sum / Summax / Mul: every aggregator ends with the fusion of all six views."""
+    mock = os.path.join(ROOT, "tests", "libmock_rccl.so")
+    src = os.path.join(ROOT, "tests", "mock_rccl.hip")
+    if not os.path.exists(mock) or os.path.getmtime(mock) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", mock, src])
+    script = os.path.join(tmp_path, "grouped.py")
+    open(script, "w").write(GROUPED)
+    env = dict(os.environ, SMESH_ROOT=ROOT, SMESH_RCCL_LIB=mock)
+    out = subprocess.run([sys.executable, script], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "grouped ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
