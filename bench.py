@@ -49,11 +49,13 @@ def prof_read(device, slot):
     return ms.value, int(r.value), int(n.value), int(v.value)
 
 
-def pmc_traffic(workload, kernel_prefix, views_per_launch, group_pipeline=False):
-    """HBM bytes per launch of the dominant kernel, measured NOW (`--pmc`): two short runs of this script under
+def pmc_traffic(workload, kernel_prefix, steps, warmup):
+    """HBM bytes per launch of every instance of the dominant kernel, measured NOW (`--pmc`): two short runs of this script under
     `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, as /opt/skills/guides/MI355X_MICROARCH.md prescribes (the TCC
     block cannot count both at once) -- and traffic = (2 x FETCH_SIZE + WRITE_SIZE) KiB x 1024 (gfx950: FETCH_SIZE counts 64 B per
-    128-byte request), averaged over the launches of the kernel instance that fuses `views_per_launch` views."""
+    128-byte request), averaged over the launches of each kernel instance.  The passes run `--steps steps --warmup warmup` with the group
+    pipeline off (one kernel at a time on the GPU), so that they launch the same instances (8 / 4 / 2 / 1 views) as the caller's run.
+    Returns ({views per launch (0: not a template instance) -> bytes per launch}, note)."""
     import csv
     import shutil
     import subprocess
@@ -66,14 +68,13 @@ def pmc_traffic(workload, kernel_prefix, views_per_launch, group_pipeline=False)
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, counter)
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
-                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "16", "--warmup", "8", "--no-cpu-baseline", "--no-host-path",
-                   "--no-pmc"]
-            if group_pipeline:
-                cmd.append("--group-pipeline")
+                   os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--repeats", "1",
+                   "--no-cpu-baseline", "--no-host-path", "--no-pmc", "--no-group-pipeline"]
             env = dict(os.environ, TMPDIR="/tmp")
             env.pop("RANK", None)
             try:
-                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                               timeout=900 if workload in ("cfg5", "cfg4t") else 300)
             except subprocess.TimeoutExpired:
                 return None, "rocprofv3 --pmc %s timed out" % counter
             path = None
@@ -91,15 +92,21 @@ def pmc_traffic(workload, kernel_prefix, views_per_launch, group_pipeline=False)
             per[counter] = {n: acc[n] / cnt[n] for n in acc}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    # the instance that takes `views_per_launch` views: k_fuse_tri<C, kind, exact, NV>; the run-time-view kernels have one instance
-    cands = [n for n in per["FETCH_SIZE"] if kernel_prefix in n and n in per["WRITE_SIZE"]]
-    exact = [n for n in cands if n.rstrip(">").endswith(", %d" % views_per_launch)]
-    name = (exact or sorted(cands, key=lambda n: -per["FETCH_SIZE"][n]) or [None])[0]
-    if name is None:
+    # k_fuse_tri<C, kind, exact, NV>: one instance per view count; the run-time-view kernels (k_fuse_tri_any / _wide / k_fuse_texel_multi) have one
+    cands = [n for n in per["FETCH_SIZE"] if kernel_prefix in n and n in per["WRITE_SIZE"] and "_big" not in n]
+    if not cands:
         return None, "no launch of %s in the counter files" % kernel_prefix
-    traffic = int((2.0 * per["FETCH_SIZE"][name] + per["WRITE_SIZE"][name]) * 1024)
-    return traffic, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --workload %s --steps 16 "
-                     "--warmup 8`, kernel %s: (2 x %.0f + %.0f) KiB" % (workload, name, per["FETCH_SIZE"][name], per["WRITE_SIZE"][name]))
+    by_nv, names = {}, {}
+    for n in cands:
+        tail = n.rstrip(">").rsplit(",", 1)[-1].strip() if n.endswith(">") else ""
+        nv = int(tail) if tail.isdigit() and int(tail) in (1, 2, 4, 8) else 0
+        t = int((2.0 * per["FETCH_SIZE"][n] + per["WRITE_SIZE"][n]) * 1024)
+        if nv not in by_nv or t > by_nv[nv]:
+            by_nv[nv], names[nv] = t, n
+    top = max(by_nv, key=lambda k: by_nv[k])
+    return by_nv, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over `bench.py --workload %s --steps %d "
+                   "--warmup %d --no-group-pipeline`, kernel %s: (2 x %.0f + %.0f) KiB per launch" % (
+                       workload, steps, warmup, names[top], per["FETCH_SIZE"][names[top]], per["WRITE_SIZE"][names[top]]))
 
 
 def cpu_baseline(workload, budget_s=20.0):
@@ -231,6 +238,29 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
         fusion._MeshAggregator.match_renders = keep
     bytes_per_view = 4 * W * H + 4 * W * H * C + 8 * C * T_mean
     scatter_path, scatter_kernel = _lib.lib().smesh_last_add_path().decode(), _lib.lib().smesh_last_fuse_kernel().decode()
+    # ... and the same images handed over as ONE batch (add_many: the record passes of the eight images in one launch each, one
+    # k_fuse_tri<.., 8> launch): same sums, bit for bit
+    batched = None
+    try:
+        keep2 = fusion._MeshAggregator.match_renders
+        fusion._MeshAggregator.match_renders = False
+        bagg = fusion.MeshAggregator(primitives=P, classes=C, device=device)
+        pb = [probs[k % len(probs)] for k in range(views)]
+        best = None
+        for rep in range(3):
+            _lib.synchronize(device)
+            t0 = time.perf_counter()
+            bagg.add_many(images, pb)
+            _lib.synchronize(device)
+            d = (time.perf_counter() - t0) / views
+            best = d if best is None else min(best, d)
+        fusion._MeshAggregator.match_renders = keep2
+        batched = {"ms_per_view": round(1e3 * best, 4), "frac": round(bytes_per_view / best / 1e9 / HBM_PEAK_GBS, 4),
+                   "path": _lib.lib().smesh_last_add_path().decode(),
+                   "what": "add_many(%d device copies of renders, device probs): one call, best of 3, host-timed" % views}
+        del bagg
+    except Exception as e:
+        batched = {"error": str(e)[:200]}
     # ... and the same copies with content matching ON, of renders that were exported (np.asarray seals a plane): the harness-shaped
     # case (eval_scannet.py:211-238).  Round 2 recognised them by checksum and fused on the renderer's records; since round 3 the
     # Python layer skips the checksum (a host read-back per call) wherever add() rebuilds the records from the image -- `path` says which
@@ -259,7 +289,7 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
                            "(taken only where the image records are off: SMESH_ADD_RECORDS_MIN_C / texel renderers), %d views" % nm}
     except Exception as e:
         matched = {"error": str(e)[:200]}
-    return {"matched_copies": matched, "ms_per_view": round(1e3 * dt, 4), "views_per_s": round(1.0 / dt, 1), "path": scatter_path,
+    return {"matched_copies": matched, "batched": batched, "ms_per_view": round(1e3 * dt, 4), "views_per_s": round(1.0 / dt, 1), "path": scatter_path,
             "kernel": scatter_kernel, "frac": round(bytes_per_view / dt / 1e9 / HBM_PEAK_GBS, 4),
             "what": "add(device copy of a render, device probs), one call per view, %d views, host-timed" % views}
 
@@ -284,12 +314,22 @@ def main():
                          "range runs on the exchange stream beside the fusion of the next (1 = one all-reduce after the last view)")
     ap.add_argument("--held-views", type=int, default=int(os.environ.get("SMESH_BENCH_HELD_VIEWS", "24")),
                     help="N > 1: how many of the rank's last views are fused by row range (at most 32)")
-    ap.add_argument("--group-pipeline", action="store_true",
-                    help="SMESH_GROUP_PIPELINE=1: the rasteriser of group g+1 beside the fusion of group g (two streams, two banks of "
-                         "view slots); more views/s, but the fusion kernel's own duration -- the roofline divisor -- stretches")
+    ap.add_argument("--group-pipeline", dest="group_pipeline", action="store_true", default=None,
+                    help="the library's default since round 5: the rasteriser of group g+1 on a second stream beside the fusion of group g "
+                         "(same kernels, same results, +6 %% views/s).  The fusion kernel's own duration -- the roofline divisor -- is then "
+                         "measured in a short SERIALISED leg of the same run (roofline.note)")
+    ap.add_argument("--no-group-pipeline", dest="group_pipeline", action="store_false",
+                    help="one kernel at a time on the GPU throughout (what rounds 1-4 timed); the roofline comes from the timed region itself")
+    ap.add_argument("--repeats", type=int, default=int(os.environ.get("SMESH_BENCH_REPEATS", "7")),
+                    help="the K-step timed region (barrier, K steps, exchange, barrier) is run this many times; `value` is the MEDIAN region, "
+                         "config.repeats / value_min / value_max say how far the others were")
     args = ap.parse_args()
-    if args.group_pipeline:
-        os.environ["SMESH_GROUP_PIPELINE"] = "1"      # (read by the library at its first grouped call)
+    if args.group_pipeline is not None:
+        _lib.check(_lib.lib().smesh_set_option(b"group_pipeline", 1 if args.group_pipeline else 0))
+    gp = ctypes.c_int64(0)
+    _lib.check(_lib.lib().smesh_get_option(b"group_pipeline", ctypes.byref(gp)))
+    pipelined = bool(gp.value)
+    args.repeats = max(1, args.repeats)
     if args.steps is None:
         args.steps = {"cfg5": 24}.get(args.workload, 200)
     if args.warmup is None:
@@ -297,7 +337,7 @@ def main():
 
     if args.pmc is None:
         import shutil
-        args.pmc = (args.gpus == 1 and "RANK" not in os.environ and args.workload in ("cfg2", "cfg1") and shutil.which("rocprofv3") is not None
+        args.pmc = (args.gpus == 1 and "RANK" not in os.environ and shutil.which("rocprofv3") is not None
                     and not os.environ.get("SMESH_BENCH_NO_PMC"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -470,47 +510,87 @@ def main():
         # each of them keeps the stream idle ~10 us (measured: 12 pairs = 0.1 ms of a 1.7 ms region).  Only the collectives are timed here;
         # the kernel's roofline is the N = 1 line's.
         prof_mask = 1 << _lib.PROF_EXCHANGE
+    # With the group pipeline the rasteriser of the next group runs BESIDE a fusion launch, so a launch's duration inside the timed
+    # regions is not the kernel's own: the regions run without event pairs around the fusion launches (which also spares them the
+    # ~6 us of stream idle time per event), and the kernel is timed in a serialised leg afterwards (below).
+    serial_leg = pipelined and not launched and prof_mask != 0
+    region_mask = (prof_mask & ~(1 << _lib.PROF_FUSE_SCATTER)) if serial_leg else prof_mask
     # HIP events on the library's stream around every 8th launch of the dominant kernel when every view is its own call (an event
     # pair costs ~4 us of stream time = 5 % of a cfg2 view); with fuse_views around the fusion launches of every THIRD group, the
     # first one included (measured: the two events of a group keep the stream idle for 2 x 6 us = 2 % of a group of eight cfg2
     # views; bracketing all of them lowered `value` from 14.3 k to 14.0 k views/s).  The library counts the launches and views
     # inside the bracketed regions itself (smesh_profile_read_ex), so the averages below are over exactly the regions that were timed.
     prof_every = int(os.environ.get("SMESH_BENCH_PROFILE_EVERY", "8" if B == 1 else "3"))
-    if ranged:
-        prof_every = 1      # (the fusion launches of a held group are cut in `parts` regions: time them all or the sums mean nothing)
+    if ranged or serial_leg:
+        prof_every = 1      # (ranged: the fusion launches of a held group are cut in `parts` regions; serialised leg: every launch counts)
     elif B > 1 and args.steps <= 40 and "SMESH_BENCH_PROFILE_EVERY" not in os.environ:
         prof_every = 1      # short runs (the driver's --steps 20: three groups): every group, so that the average is over >= 3 launches
     _lib.check(_lib.lib().smesh_profile_sample_every(device, prof_every))
-    _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask))
-    barrier()
-    _lib.synchronize(device)
-    t0 = time.perf_counter()
-    mark(0)
-    ranges = fuse_and_exchange(args.warmup, total_views)     # (records mark 1 behind the last fusion kernel)
-    mark(2)
-    barrier()                      # the only host synchronisation of the timed region
-    dt = time.perf_counter() - t0
-    _lib.check(_lib.lib().smesh_profile_enable(device, 0))
-    # where this rank's device time went on the MAIN stream: marks 0 -> 1 = its views (render + fuse), 1 -> 2 = the part of the
-    # exchange that nothing hid (its own transfers AND the wait for the slowest rank to arrive; with the exchange under the fusion:
-    # what was left of the collectives when the last range had been fused).  Over all ranks: the max of each.
-    compute_ms, exposed_ms = elapsed(0, 1), elapsed(1, 2)
+
+    # ---- the timed region, `repeats` times: barrier | K steps (+ the exchange) | barrier.  `value` is the median region. ----
+    regions = []          # per repeat: [dt, compute_ms, exposed_ms, -exposed_ms] of THIS rank
+    ranges = None
+    for rep in range(args.repeats):
+        agg.reset()       # (untimed: every region fuses its K views into an empty accumulator, the last one's result is what get() returns)
+        _lib.check(_lib.lib().smesh_profile_enable(device, region_mask))
+        barrier()
+        _lib.synchronize(device)
+        t0 = time.perf_counter()
+        mark(0)
+        ranges = fuse_and_exchange(args.warmup, total_views)     # (records mark 1 behind the last fusion kernel)
+        mark(2)
+        barrier()                      # the only host synchronisation of the timed region
+        dt_rep = time.perf_counter() - t0
+        _lib.check(_lib.lib().smesh_profile_enable(device, 0))
+        # where this rank's device time went on the MAIN stream: marks 0 -> 1 = its views (render + fuse), 1 -> 2 = the part of the
+        # exchange that nothing hid (its own transfers AND the wait for the slowest rank to arrive; with the exchange under the fusion:
+        # what was left of the collectives when the last range had been fused).  Over all ranks: the max of each.
+        c_ms, e_ms = elapsed(0, 1), elapsed(1, 2)
+        regions.append([dt_rep, c_ms, e_ms, -e_ms])
     # the collectives themselves (HIP events around them on the stream they run on): equals the exposed part when nothing overlaps
-    exchange_ms = prof_read(device, _lib.PROF_EXCHANGE)[0] if (comm is not None and prof_mask) else exposed_ms
+    exchange_ms = prof_read(device, _lib.PROF_EXCHANGE)[0] / args.repeats if (comm is not None and region_mask) else None
     if ranged and comm is None:
-        exchange_ms = 1e3 * exchange_host_s[0]                # (torch plumbing: host-timed, synchronous)
-    compute_ms_max, exposed_ms_max, exposed_ms_min, exchange_ms_max = compute_ms, exposed_ms, exposed_ms, exchange_ms
+        exchange_ms = 1e3 * exchange_host_s[0] / args.repeats                # (torch plumbing: host-timed, synchronous)
+    flat = [v for r in regions for v in r] + [exchange_ms if exchange_ms is not None else 0.0]
     if comm is not None:
-        dt, compute_ms_max, exposed_ms_max, neg_min, exchange_ms_max = comm.reduce_scalars(
-            [dt, compute_ms, exposed_ms, -exposed_ms, exchange_ms], "max")
-        exposed_ms_min = -neg_min
+        flat_max = []
+        for i in range(0, len(flat), 60):                      # (smesh_comm_allreduce_f64 takes at most 64 values)
+            flat_max += comm.reduce_scalars(flat[i:i + 60], "max")
     elif dist is not None:
         import torch
-        t = torch.tensor([dt, compute_ms, exposed_ms, -exposed_ms, exchange_ms], dtype=torch.float64,
-                         device="cpu" if backend == "gloo" else "cuda:%d" % device)
+        t = torch.tensor(flat, dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda:%d" % device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt, compute_ms_max, exposed_ms_max, neg_min, exchange_ms_max = (float(v) for v in t.tolist())
-        exposed_ms_min = -neg_min
+        flat_max = [float(v) for v in t.tolist()]
+    else:
+        flat_max = list(flat)
+    regions_max = [flat_max[4 * i:4 * i + 4] for i in range(args.repeats)]
+    order = sorted(range(args.repeats), key=lambda i: regions_max[i][0])
+    med = order[(args.repeats - 1) // 2]                            # the median region (the lower one of an even count)
+    dt, compute_ms_max, exposed_ms_max = regions_max[med][0], regions_max[med][1], regions_max[med][2]
+    exposed_ms_min = -regions_max[med][3]
+    dt_min, dt_max = regions_max[order[0]][0], regions_max[order[-1]][0]
+    compute_ms, exposed_ms = regions[med][1], regions[med][2]
+    if exchange_ms is None:
+        exchange_ms, exchange_ms_max = exposed_ms, exposed_ms_max
+    else:
+        exchange_ms_max = flat_max[-1]
+
+    # ---- the serialised leg: the fusion kernel's own duration (roofline), one kernel at a time on the GPU ----
+    leg_views = 0
+    if serial_leg:
+        _lib.check(_lib.lib().smesh_set_option(b"group_pipeline", 0))
+        _lib.check(_lib.lib().smesh_profile_reset(device))
+        _lib.check(_lib.lib().smesh_profile_sample_every(device, 1))
+        leg_views = min(args.steps, 64)
+        leg_first = args.warmup
+        fuse_range(leg_first, leg_first + min(B, leg_views))         # (untimed: the first serial group behind pipelined ones)
+        _lib.synchronize(device)
+        _lib.check(_lib.lib().smesh_profile_enable(device, prof_mask & ~(1 << _lib.PROF_EXCHANGE)))
+        fuse_range(leg_first, leg_first + leg_views)
+        _lib.synchronize(device)
+        _lib.check(_lib.lib().smesh_profile_enable(device, 0))
+        _lib.check(_lib.lib().smesh_set_option(b"group_pipeline", 1))
+        # (the accumulator now holds the leg's views too: the result checks below only count annotated primitives)
 
     t1 = time.perf_counter()
     fused = agg.get() if exchange == "allreduce" else agg.get_rows(*owned)
@@ -557,31 +637,45 @@ def main():
         if B > 1 and prof_mask and not ranged:
             cap = 8     # smesh_aggregator_max_fused_views (Mul with 41 .. 48 classes: 2 -- not a bench workload)
             cap = min(cap, int(os.environ.get("SMESH_FUSE_VIEWS", "8")))
-            for call, i in enumerate(range(args.warmup, total_views, B)):
+            # the calls whose fusion launches were bracketed: those of the serialised leg, or of every timed region
+            first_call, end_call, times = ((args.warmup, args.warmup + leg_views, 1) if serial_leg else (args.warmup, total_views, args.repeats))
+            for call, i in enumerate(range(first_call, end_call, B)):
                 if call % prof_every:
                     continue           # (not one of the bracketed calls)
-                left = min(i + B, total_views) - i
+                left = min(i + B, end_call) - i
                 while left:
                     nv = 1
                     while nv * 2 <= min(cap, left):
                         nv *= 2
-                    mix[nv] = mix.get(nv, 0) + 1
+                    mix[nv] = mix.get(nv, 0) + times
                     left -= nv
             if sum(mix.values()) != k_launches or sum(k * v for k, v in mix.items()) != k_views:
                 mix = {}
         timed = k_launches > 0 and k_ms > 0     # (N > 1 with the exchange under the fusion: the fusion launches are not bracketed)
         achieved = bytes_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         achieved_needed = needed_per_view * k_views / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic, traffic_source = None, None
+        # roofline.traffic: HBM bytes per launch from the PMC counters, for the instance that fuses the most views per launch;
+        # frac_traffic: the counter bytes of ALL the timed launches (each instance's own bytes x how often it was timed; an
+        # instance the counter passes did not see: the largest one's bytes scaled by views) over the time those launches took --
+        # round 4 divided the eight-view instance's bytes by the mean duration of an {8, 8, 4} mix
+        traffic, traffic_source, traffic_by_nv, traffic_timed = None, None, None, None
         vpl_int = int(round(views_per_launch)) if views_per_launch else 1
         if args.pmc and world == 1:
             try:
-                traffic, traffic_source = pmc_traffic(args.workload, fuse_kernel, vpl_int, args.group_pipeline)
+                sub_steps, sub_warm = (args.steps, args.warmup) if args.steps <= 40 else (16, 8)
+                traffic_by_nv, traffic_source = pmc_traffic(args.workload, fuse_kernel, sub_steps, sub_warm)
             except Exception as e:
-                traffic, traffic_source = None, "pmc passes failed: %s" % str(e)[:160]
+                traffic_by_nv, traffic_source = None, "pmc passes failed: %s" % str(e)[:160]
+        if traffic_by_nv:
+            top = max(traffic_by_nv)                      # views per launch of the largest instance (0: a run-time-view kernel)
+            traffic = traffic_by_nv[top]
+            if top == 0 or not mix:
+                per_view = traffic / max(views_per_launch if top == 0 else top, 1)
+                traffic_timed = per_view * k_views
+            else:
+                traffic_timed = sum(cnt * (traffic_by_nv[nv] if nv in traffic_by_nv else traffic * nv / top) for nv, cnt in mix.items())
         if traffic is None:
-            # not measured in this run (the default: two more passes of the whole script under rocprofv3 take a minute): the
-            # committed PMC summary of this round, for the kernel instance that ran
+            # not measured in this run: the committed PMC summary of an earlier round, for the kernel instance that ran
             note = traffic_source
             tpath = os.path.join(ROOT, "profiles", "fusion_traffic.json")
             if os.path.exists(tpath):
@@ -590,7 +684,9 @@ def main():
                     entry = json.load(open(tpath)).get(tkey)
                     if entry:
                         traffic = entry.get("hbm_bytes_per_launch")
-                        traffic_source = "profiles/fusion_traffic.json [%s] (committed PMC passes of this round; `--pmc` measures it in the run)" % tkey
+                        vpl_entry = 8 if tkey.endswith("_x8") else 2 if tkey.endswith("_pair") else 1
+                        traffic_timed = traffic / vpl_entry * k_views
+                        traffic_source = "profiles/fusion_traffic.json [%s] (committed PMC passes of an EARLIER round; `--pmc` measures it in the run)" % tkey
                 except Exception:
                     traffic = None
             if traffic is None and note:
@@ -599,7 +695,7 @@ def main():
             "metric": ("views/sec fused (1080p, 19 classes, 1M-tri mesh)" if args.workload == "cfg2" else
                        "views/sec fused (%s: %dx%d, %d classes, %d triangles%s)" % (args.workload, W, H, C, F,
                                                                                    ", %d texel primitives" % P if texels else "")),
-            "value": round(world * args.steps / dt, 2),
+            "value": round(world * args.steps / dt, 2),            # the MEDIAN of `repeats` timed regions
             "unit": "views/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -613,7 +709,11 @@ def main():
             "config": {"workload": "%s: %d-triangle grid mesh%s, %d views/GPU at %dx%d, %d classes, probs resident in HBM"
                                    % (args.workload, F, " as %d texel primitives" % P if texels else "", args.steps, W, H, C),
                        "views_per_call": B,
-                       "group_pipeline": bool(int(os.environ.get("SMESH_GROUP_PIPELINE", "0") or 0)),
+                       "group_pipeline": pipelined,
+                       "repeats": args.repeats,
+                       "value_min": round(world * args.steps / dt_max, 2), "value_max": round(world * args.steps / dt_min, 2),
+                       "value_spread": round((dt_max - dt_min) / dt, 4),
+                       "region_ms": [round(1e3 * r[0], 3) for r in regions_max],
                        "sharding": "views dp%d, one RCCL %s of float32[P,C]" % (world, exchange.replace("_", "-")),
                        "allreduce": allreduce_impl, "exchange": exchange, "nranks": nranks_reported,
                        # the exchange moves the raw accumulator once: ring all-reduce 2 (N-1)/N x, reduce-scatter (N-1)/N x per link
@@ -635,13 +735,18 @@ def main():
             # pixels and a row round trip per view that the kernel does not perform -- it flatters
             "roofline": {"frac_needed": round(achieved_needed / HBM_PEAK_GBS, 4) if timed else None,
                          "kernel": KERNEL_NOTES.get(fuse_kernel, fuse_kernel),
-                         "note": ("N > 1 with the exchange under the fusion: the fusion launches are not bracketed with events here (an event pair "
-                                  "around each of exchange_parts x groups launches costs what the overlap saves); the kernel's roofline is the "
-                                  "N = 1 line's") if ranged else None,
+                         "note": (("N > 1 with the exchange under the fusion: the fusion launches are not bracketed with events here (an event pair "
+                                   "around each of exchange_parts x groups launches costs what the overlap saves); the kernel's roofline is the "
+                                   "N = 1 line's") if ranged else
+                                  ("kernel durations from a SERIALISED leg of this run (group pipeline off, %d views right after the timed regions, every "
+                                   "fusion launch bracketed with HIP events on the library stream): in the timed regions the rasteriser of the next group "
+                                   "runs beside each fusion launch, whose duration is then not the kernel's own.  us_per_view <= ms_per_step still holds."
+                                   % leg_views) if serial_leg else None),
                          "bound": "hbm",
                          "achieved": round(achieved, 1) if timed else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if timed else None, "traffic": traffic, "traffic_source": traffic_source,
-                         "frac_traffic": (round(traffic / t_launch / 1e9 / HBM_PEAK_GBS, 4) if (traffic and timed) else None),
+                         "frac_traffic": (round(traffic_timed / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if (traffic_timed and timed) else None),
+                         "traffic_by_views_per_launch": ({str(k): v for k, v in sorted(traffic_by_nv.items(), reverse=True)} if traffic_by_nv else None),
                          "algorithmic_bytes_per_view": int(bytes_per_view),
                          "algorithmic_bytes_per_launch": int(bytes_per_view * views_per_launch),
                          "needed_bytes_per_view": int(needed_per_view),

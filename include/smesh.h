@@ -75,6 +75,11 @@ const char* smesh_backend(void);
 const char* smesh_last_error(void);
 /* Number of visible GPUs (oracle: 0). */
 int smesh_device_count(int* count);
+/* Run-time options by name (the environment supplies the defaults).  "group_pipeline" (0 / 1; default 1, SMESH_GROUP_PIPELINE):
+ * smesh_fuse_views rasterises group g + 1 of a batch on a second stream beside the fusion of group g -- same kernels, same inputs,
+ * same results.  A harness that needs ONE kernel's own duration (a roofline) turns it off for that measurement. */
+int smesh_set_option(const char* name, int64_t value);
+int smesh_get_option(const char* name, int64_t* value);
 /* Block until all work queued on `device` by this library has finished. */
 int smesh_synchronize(int device);
 
@@ -172,6 +177,14 @@ int smesh_aggregator_add_async(smesh_aggregator_t* a,
                                const float* probs, const int64_t probs_strides[3], int probs_memkind,
                                const float* weights, const int64_t weights_strides[2], int weights_memkind,
                                uint64_t width, uint64_t height);
+/* add() for a batch of `n` images of one size, in order (new functionality: the reference adds one image per call, Mesh.h:65-107).
+ * Same sums as n smesh_aggregator_add_async calls -- per accumulator row the same float32 additions in the same order -- but dense
+ * uint32 / int32 index planes and dense class vectors in DEVICE memory share their launches in groups of up to eight (one launch per
+ * record pass, one triangle-order fusion launch per group).  One dtype, one set of strides and one memory kind for all images;
+ * `weights` NULL or one pointer per image.  Asynchronous for device images (smesh_synchronize / smesh_token_*). */
+int smesh_aggregator_add_many(smesh_aggregator_t* a, uint64_t n, const void* const* indices, int idx_dtype, const int64_t idx_strides[2],
+                              int idx_memkind, const float* const* probs, const int64_t probs_strides[3], int probs_memkind,
+                              const float* const* weights, const int64_t weights_strides[2], int weights_memkind, uint64_t W, uint64_t H);
 
 /* Replaces ModelAggregator::get (Fusion.h:72-76; Mesh.h:131-132) with the output functor chain of
  * the chosen aggregator (Fusion.cu:47-49 / 67-69 / 79-82; Fusion.h:79-104): writes float32[P,C]. */

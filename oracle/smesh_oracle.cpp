@@ -821,6 +821,16 @@ int smesh_aggregator_add_async(smesh_aggregator_t* a, const void* indices, int i
                                const float* weights, const int64_t ws[2], int wmem, uint64_t W, uint64_t H) {
   return smesh_aggregator_add(a, indices, idx_dtype, is, imem, probs, ps, pmem, weights, ws, wmem, W, H);   // (synchronous like everything here)
 }
+int smesh_aggregator_add_many(smesh_aggregator_t* a, uint64_t n, const void* const* indices, int idx_dtype, const int64_t is[2], int imem,
+                              const float* const* probs, const int64_t ps[3], int pmem,
+                              const float* const* weights, const int64_t ws[2], int wmem, uint64_t W, uint64_t H) {
+  if (n && (!indices || !probs)) return fail(SMESH_ERR_INVALID, "NULL argument");
+  for (uint64_t i = 0; i < n; i++) {      // the reference's add(), image by image (Mesh.h:65-107)
+    const int st = smesh_aggregator_add(a, indices[i], idx_dtype, is, imem, probs[i], ps, pmem, weights ? weights[i] : nullptr, ws, wmem, W, H);
+    if (st != SMESH_OK) return st;
+  }
+  return SMESH_OK;
+}
 int smesh_stream_wait(int, void*) { return SMESH_OK; }   // the oracle has no streams: everything is synchronous
 int smesh_stream_release(int, void*) { return SMESH_OK; }
 int smesh_stream_handle(int, void** s) { if (s) *s = nullptr; return SMESH_OK; }
@@ -916,6 +926,8 @@ int smesh_host_free(void* p) { free(p); return SMESH_OK; }
 int smesh_device_malloc(int, uint64_t, void**) { return fail(SMESH_ERR_NODEVICE, "oracle has no device memory"); }
 int smesh_device_free(int, void*) { return SMESH_OK; }
 int smesh_device_trim(int, uint64_t* cached_bytes) { if (cached_bytes) *cached_bytes = 0; return SMESH_OK; }
+int smesh_set_option(const char* name, int64_t) { return name ? SMESH_OK : fail(SMESH_ERR_INVALID, "option name is NULL"); }   // (the oracle has no streams)
+int smesh_get_option(const char* name, int64_t* value) { if (!name || !value) return fail(SMESH_ERR_INVALID, "NULL argument"); *value = 0; return SMESH_OK; }
 int smesh_memcpy(void* dst, const void* src, uint64_t bytes, int dk, int sk, int) {
   if (dk != SMESH_MEM_HOST || sk != SMESH_MEM_HOST) return fail(SMESH_ERR_NODEVICE, "oracle has no device memory");
   std::memmove(dst, src, bytes);

@@ -62,6 +62,9 @@ SIGNATURES = {
     "smesh_aggregator_add_async": (c_int, [c_void_p, c_void_p, c_int, P(ctypes.c_int64), c_int,
                                            c_void_p, P(ctypes.c_int64), c_int,
                                            c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64]),
+    "smesh_aggregator_add_many": (c_int, [c_void_p, c_u64, P(c_void_p), c_int, P(ctypes.c_int64), c_int,
+                                          P(c_void_p), P(ctypes.c_int64), c_int,
+                                          P(c_void_p), P(ctypes.c_int64), c_int, c_u64, c_u64]),
     "smesh_aggregator_add_rendered": (c_int, [c_void_p, c_void_p, c_void_p,
                                               c_void_p, P(ctypes.c_int64), c_int,
                                               c_void_p, P(ctypes.c_int64), c_int, c_u64, c_u64]),
@@ -108,6 +111,8 @@ SIGNATURES = {
     "smesh_device_malloc": (c_int, [c_int, c_u64, P(c_void_p)]),
     "smesh_device_free": (c_int, [c_int, c_void_p]),
     "smesh_device_trim": (c_int, [c_int, P(c_u64)]),
+    "smesh_set_option": (c_int, [ctypes.c_char_p, ctypes.c_int64]),
+    "smesh_get_option": (c_int, [ctypes.c_char_p, P(ctypes.c_int64)]),
     "smesh_host_malloc": (c_int, [c_u64, P(c_void_p)]),
     "smesh_host_free": (c_int, [c_void_p]),
     "smesh_memcpy": (c_int, [c_void_p, c_void_p, c_u64, c_int, c_int, c_int]),

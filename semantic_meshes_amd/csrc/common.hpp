@@ -83,6 +83,10 @@ hipError_t dev_free(void* p);
 void dev_trim(int device);
 void dev_cache_stats(uint64_t* live_blocks, uint64_t* cached_blocks, uint64_t* cached_bytes);
 
+// Run-time options (smesh_set_option; the environment supplies the defaults).  group_pipeline: smesh_fuse_views rasterises group
+// g + 1 on the raster stream beside the fusion of group g (default on; SMESH_GROUP_PIPELINE=0).
+bool opt_group_pipeline();
+
 // Grow-only device scratch buffer.
 struct Scratch {
   void* ptr = nullptr;
@@ -205,5 +209,10 @@ int image_records_pending(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx
 int image_records_scatter_sparse(DeviceCtx* ctx, ImageRecords& r, int kind, const uint32_t* d_idx, const float* d_probs, const float* d_w,
                                  uint64_t W, uint64_t H, uint32_t C, float iew, float* acc, float* acc_lo, double* acc_d, hipStream_t st);
 int image_records_clear(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, uint64_t W, uint64_t H, hipStream_t st);
+bool image_records_build_group(DeviceCtx* ctx, ImageRecords* const* recs, const uint32_t* const* d_idx, int n, uint64_t W, uint64_t H, uint64_t P,
+                               int* status);
+int image_records_scatter_sparse_group(DeviceCtx* ctx, ImageRecords* const* recs, int n, int kind, const uint32_t* const* d_idx,
+                                       const float* const* d_probs, const float* const* d_w, uint64_t W, uint64_t H, uint32_t C, float iew,
+                                       float* acc, float* acc_lo, double* acc_d, hipStream_t st);
 
 }  // namespace smesh

@@ -2,6 +2,7 @@
 #include "common.hpp"
 
 #include <algorithm>
+#include <atomic>
 
 #include <cstdlib>
 #include <cstring>
@@ -25,6 +26,17 @@ int fail_hip(hipError_t e, const char* what, const char* file, int line) {
   // clear the sticky error so that later calls report their own failures
   (void)hipGetLastError();
   return (e == hipErrorNoDevice || e == hipErrorInvalidDevice) ? SMESH_ERR_NODEVICE : SMESH_ERR_RUNTIME;
+}
+
+static std::atomic<int> g_group_pipeline{-1};   // -1: not decided yet (the environment, else on)
+bool opt_group_pipeline() {
+  int v = g_group_pipeline.load();
+  if (v < 0) {
+    const char* e = getenv("SMESH_GROUP_PIPELINE");
+    v = e ? (atoi(e) != 0 ? 1 : 0) : 1;
+    g_group_pipeline.store(v);
+  }
+  return v != 0;
 }
 
 static std::mutex g_ctx_mu;
@@ -239,6 +251,20 @@ extern "C" {
 const char* smesh_backend(void) { return "hip-gfx950"; }
 
 const char* smesh_last_error(void) { return g_err.c_str(); }
+
+// Run-time options by name.  "group_pipeline" (0 / 1; default 1, or SMESH_GROUP_PIPELINE): smesh_fuse_views rasterises the next
+// group of views on a second stream beside the fusion of the current one -- same kernels, same inputs, same results; a harness
+// that wants one kernel's own duration (a roofline) turns it off for that measurement.
+int smesh_set_option(const char* name, int64_t value) {
+  if (!name) return fail(SMESH_ERR_INVALID, "option name is NULL");
+  if (!strcmp(name, "group_pipeline")) { g_group_pipeline.store(value != 0 ? 1 : 0); return SMESH_OK; }
+  return fail(SMESH_ERR_INVALID, std::string("unknown option: ") + name);
+}
+int smesh_get_option(const char* name, int64_t* value) {
+  if (!name || !value) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (!strcmp(name, "group_pipeline")) { *value = opt_group_pipeline() ? 1 : 0; return SMESH_OK; }
+  return fail(SMESH_ERR_INVALID, std::string("unknown option: ") + name);
+}
 
 int smesh_device_count(int* count) {
   if (!count) return fail(SMESH_ERR_INVALID, "count is NULL");

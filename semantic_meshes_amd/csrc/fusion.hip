@@ -1138,15 +1138,21 @@ __device__ __forceinline__ void fuse_pixel_wide(ACC4 (&ac)[NCH], const fvec4 (&p
   }
 }
 
+// A pointer read from LDS is the same in every lane: said so, it lives in scalar registers.
+__device__ __forceinline__ const float* uniform_ptr(const float* p) {
+  const uint64_t v = reinterpret_cast<uint64_t>(p);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return reinterpret_cast<const float*>((uint64_t)lo | ((uint64_t)hi << 32));
+}
+
 // Up to eight views of the same mesh in one launch (`nv`, a run-time count: one instance per row width), in order: a triangle's
 // accumulator row -- 600 bytes each way at C = 150, two thirds of what a cfg5 view moves -- makes ONE round trip for all of them, and
 // the additions happen in the order `nv` launches would have made them (a store and a load of a float32 row change nothing).  The
 // per-view state of the wave's 64 triangles (box origin, mask of visible pixels) and the views' pointers are parked in LDS, so
 // that the view loop is a run-time loop over broadcast reads instead of eight copies of the code.  A triangle that is big in any
 // of the views belongs to k_fuse_big_any for all of them.
-template <int KIND, int NCH>
+template <int KIND, int NCH, int B>   // B: visible triangles whose rows and next pixels are in flight together
 __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews<8> vw, int nv) {
-  constexpr int B = NCH == 1 ? 4 : 2;      // visible triangles whose rows and next pixels are in flight together
   __shared__ ViewState S;
   const int l = threadIdx.x;
   const uint32_t C = a.C;
@@ -1218,8 +1224,63 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
 #pragma unroll
     for (int b = 0; b < B; b++)
       if (t[b] >= 0 && !(SMESH_ABL(a.dbg) & 4)) load_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
-    // (a software-pipelined variant -- one pixel stream per triangle across the views, the next pixel's class vector requested
-    // before the current one is added -- was slower at cfg5: 423 vs 500 views/s, 124 VGPRs instead of 88)
+    if constexpr (KIND != SMESH_AGG_MUL) {
+      // Sum / Summax: every triangle of the batch is a STREAM of pixels -- its views in order, its pixels of a view in image order --
+      // and a round takes the next pixel of every stream whatever view it belongs to.  (Round 4 walked the views in lock step:
+      // a round loaded the pixels the B triangles have in ONE view.  At cfg5 a visible triangle has a pixel in three or four of a
+      // launch's eight views, so a round had one or two of its B loads in flight and a batch took eight dependent round trips; the
+      // counters put the kernel at 2.6 TB/s of scattered 600-byte rows: short of requests in flight, not of bandwidth.)  Per row the
+      // additions are the same, in the same order.
+      int sv[B];                       // the view a stream is in (wave-uniform, like everything below)
+      unsigned long long pm[B];        // its pixels of that view that are still to come
+      uint32_t org[B], Hs[B];
+      float w0[B];
+      const float* pr[B];
+      const float* wg[B];
+#pragma unroll
+      for (int b = 0; b < B; b++) { sv[b] = -1; pm[b] = 0ull; org[b] = 0u; Hs[b] = 0u; w0[b] = 0.0f; pr[b] = nullptr; wg[b] = nullptr; }
+      while (true) {
+        bool have[B];
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          if (t[b] >= 0) {
+            while (pm[b] == 0ull && sv[b] + 1 < nv) {      // on to the stream's next view that holds pixels of the triangle
+              sv[b]++;
+              const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lo[sv[b]][t[b]]);
+              const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.hi[sv[b]][t[b]]);
+              pm[b] = (unsigned long long)lo | ((unsigned long long)hi << 32);
+              if (pm[b]) {
+                org[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.org[sv[b]][t[b]]);
+                const uint32_t nt = (uint32_t)__popcll(pm[b]);                      // this primitive's pixels in this view (Mesh.h:90-93)
+                w0[b] = a.iew * (1.0f / ((float)nt)) + (1 - a.iew) * 1.0f;           // Mesh.h:100-102
+                pr[b] = uniform_ptr(S.view[sv[b]].probs);
+                wg[b] = uniform_ptr(S.view[sv[b]].weights);
+                Hs[b] = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.view[sv[b]].H);
+              }
+            }
+          }
+          have[b] = pm[b] != 0ull;
+          any = any || have[b];
+        }
+        if (!any) break;
+        fvec4 p[B][NCH];
+        float wt[B];
+#pragma unroll
+        for (int b = 0; b < B; b++) {
+          wt[b] = 1.0f;
+          if (have[b]) {
+            const uint64_t pix = pix_of(org[b], __ffsll((long long)pm[b]) - 1, Hs[b]);
+            pm[b] &= pm[b] - 1ull;
+            if (!(SMESH_ABL(a.dbg) & 8)) load_wide<NCH>(pr[b] + pix * C, C, l, p[b]);
+            if (wg[b]) wt[b] = wg[b][pix];
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < B; b++)
+          if (have[b]) fuse_pixel_wide<KIND, NCH>(ac[b], p[b], C, l, w0[b] * wt[b]);     // :103
+      }
+    } else
     for (int v = 0; v < nv; v++) {
       const float* __restrict__ probs = S.view[v].probs;
       const float* __restrict__ weights = S.view[v].weights;
@@ -1943,6 +2004,7 @@ struct smesh_aggregator {
   hipEvent_t ev_staged = nullptr;        // host inputs have been copied into the staging buffers
   Scratch out_tmp;                       // get(): normalised result before the D2H copy
   ImageRecords rec;                      // add() on an image the library did not render: per-primitive records (image_records.hip)
+  ImageRecords rec_many[7];              // add_many(): the record sets of the further images of a group of up to eight (rec is the first)
   // Exchange of row ranges beside the fusion (smesh_allreduce_rows, comm.cpp): ev_part marks the main stream where the range became
   // final, ev_xchg the exchange stream behind the range's collective; xchg_pending: the main stream has not yet waited for ev_xchg.
   hipEvent_t ev_part = nullptr, ev_xchg = nullptr;
@@ -2290,6 +2352,10 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   uint64_t scratch_stride = N;   // per-view scratch images of the big-triangle waves
   int G = 1;
   const int wide_chunks = (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) ? (a->C <= 256 ? 1 : a->C <= 512 ? 2 : 4) : 0;   // k_fuse_tri_wide
+  // rows (and their next pixels) in flight per wave: 4 for rows of up to 256 classes (Mul: its per-view partial sums in double are 32 more registers), 2 beyond
+  static const int wide_b_env = getenv("SMESH_WIDE_B") ? atoi(getenv("SMESH_WIDE_B")) : 0;   // (experiment knob: 2 / 4 / 8)
+  // (cfg5, Sum, views/s: 2 rows in flight and 8 waves per SIMD 509, 4 rows and 5 waves 496, 8 rows -- 284 registers, one wave -- 130)
+  const int wide_b = wide_b_env ? wide_b_env : (a->kind == SMESH_AGG_MUL ? 4 : 2);
   if (!specialised) {
     while ((((a->C + G - 1) / G + 3u) & ~3u) > (uint32_t)kSliceAny) G *= 2;   // lanes per accumulator row (can_fuse_triangles: G <= 64)
     // the big-triangle waves park per-pixel weights (and arg-max) here
@@ -2345,9 +2411,12 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     }
 #define SMESH_FW(K)                                                                            \
     switch (wide_chunks) {                                                                     \
-      case 1:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 1>), tgrid, block, 0, st, t, tv, nviews); break; \
-      case 2:  hipLaunchKernelGGL((k_fuse_tri_wide<K, 2>), tgrid, block, 0, st, t, tv, nviews); break; \
-      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4>), tgrid, block, 0, st, t, tv, nviews); break; \
+      case 1:  if (wide_b == 8) hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 8>), tgrid, block, 0, st, t, tv, nviews);   \
+               else if (wide_b == 2) hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 2>), tgrid, block, 0, st, t, tv, nviews); \
+               else hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 4>), tgrid, block, 0, st, t, tv, nviews); break; \
+      case 2:  if (wide_b >= 4) hipLaunchKernelGGL((k_fuse_tri_wide<K, 2, 4>), tgrid, block, 0, st, t, tv, nviews);   \
+               else hipLaunchKernelGGL((k_fuse_tri_wide<K, 2, 2>), tgrid, block, 0, st, t, tv, nviews); break; \
+      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4, 2>), tgrid, block, 0, st, t, tv, nviews); break; \
     }
 #define SMESH_FT(K)                                                                           \
     switch (tri_ct) {                                                                         \
@@ -2648,6 +2717,7 @@ int smesh_aggregator_destroy(smesh_aggregator_t* a) {
   for (Scratch* s : {&a->st_idx, &a->st_probs, &a->st_w, &a->nm_idx, &a->nm_probs, &a->nm_w, &a->fb_w, &a->fb_amax, &a->pw, &a->out_tmp})
     s->release();
   a->rec.release();
+  for (auto& r : a->rec_many) r.release();
   delete a;
   return SMESH_OK;
 }
@@ -2730,6 +2800,93 @@ int smesh_aggregator_add_async(smesh_aggregator_t* a, const void* indices, int i
 }
 
 
+// add() for a batch of images, in order (new functionality; the reference adds one image per call, Mesh.h:65-107).  The same sums
+// as `n` smesh_aggregator_add_async calls -- per accumulator row the same float32 additions in the same order (rows of sparse
+// primitives, whose pixels are added by float atomics, excepted) -- but images that are dense uint32 / int32 planes in DEVICE memory with
+// dense device class vectors share their kernel launches in groups of up to eight: ONE launch per record pass for the group
+// (image_records.hip), ONE triangle-order fusion launch (k_fuse_tri<.., 8>: a row makes one round trip for the group).  Everything
+// else goes through smesh_aggregator_add_async image by image.  `weights` may be NULL (no image has weights) or hold one pointer per
+// image.  Asynchronous for device images, like smesh_aggregator_add_async.
+int smesh_aggregator_add_many(smesh_aggregator_t* a, uint64_t n, const void* const* indices, int idx_dtype, const int64_t is[2], int imem,
+                              const float* const* probs, const int64_t ps[3], int pmem,
+                              const float* const* weights, const int64_t ws[2], int wmem, uint64_t W, uint64_t H) {
+  if (!a || (n && (!indices || !probs || !is || !ps))) return fail(SMESH_ERR_INVALID, "NULL argument");
+  if (weights && !ws) return fail(SMESH_ERR_INVALID, "weights without strides");
+  for (uint64_t i = 0; i < n; i++)
+    if (!indices[i] || !probs[i] || (weights && !weights[i])) return fail(SMESH_ERR_INVALID, "NULL image in the batch");
+  if (n == 0 || W == 0 || H == 0) return SMESH_OK;
+  bool grouped;
+  {
+    std::lock_guard<std::mutex> g(a->mu);
+    static const bool records_off = getenv("SMESH_ADD_RECORDS") && atoi(getenv("SMESH_ADD_RECORDS")) == 0;
+    const char* min_c_env = getenv("SMESH_ADD_RECORDS_MIN_C");
+    const uint32_t records_min_c = min_c_env ? (uint32_t)atoi(min_c_env) : kAddRecordsMinC;
+    grouped = n >= 2 && imem == SMESH_MEM_DEVICE && pmem == SMESH_MEM_DEVICE && (!weights || wmem == SMESH_MEM_DEVICE) &&
+              (idx_dtype == SMESH_IDX_U32 || idx_dtype == SMESH_IDX_I32) && is[0] == (int64_t)H && is[1] == 1 &&
+              ps[0] == (int64_t)(H * a->C) && ps[1] == (int64_t)a->C && ps[2] == 1 && (!weights || (ws[0] == (int64_t)H && ws[1] == 1)) &&
+              !records_off && a->C >= records_min_c && a->P > 0 && W <= 65535 && H <= 65535 && W * H < 0x7FFFFFFFull / 4 &&
+              smesh_aggregator_can_fuse_triangles(a, a->P) && smesh_aggregator_max_fused_views(a) >= 2;
+    for (uint64_t i = 0; i < n && grouped; i++) grouped = !(reinterpret_cast<uintptr_t>(probs[i]) & 15);
+  }
+  uint64_t i = 0;
+  while (i < n) {
+    int nv = 1;
+    if (grouped) {
+      std::lock_guard<std::mutex> g(a->mu);
+      const int max_nv = smesh_aggregator_max_fused_views(a);
+      while (nv * 2 <= std::min<uint64_t>((uint64_t)max_nv, n - i)) nv *= 2;
+    }
+    if (nv == 1) {
+      SMESH_TRY(aggregator_add(a, indices[i], idx_dtype, is, imem, probs[i], ps, pmem, weights ? weights[i] : nullptr, ws, wmem, W, H, false));
+      i += 1;
+      continue;
+    }
+    std::lock_guard<std::mutex> g(a->mu);
+    DeviceCtx* ctx = a->ctx;
+    std::lock_guard<std::recursive_mutex> lock(ctx->mu);
+    SMESH_HIP(hipSetDevice(ctx->device));
+    SMESH_TRY(smesh_aggregator_join_exchange(a));
+    SMESH_TRY(smesh_aggregator_refuse_scattered(a, "add_many()"));
+    ImageRecords* recs[8];
+    const uint32_t* idx[8];
+    const float* pr[8];
+    const float* wt[8];
+    for (int v = 0; v < nv; v++) {
+      recs[v] = v == 0 ? &a->rec : &a->rec_many[v - 1];
+      idx[v] = static_cast<const uint32_t*>(indices[i + v]);      // (int32 -1 and uint32 0xFFFFFFFF share a bit pattern)
+      pr[v] = probs[i + v];
+      wt[v] = weights ? weights[i + v] : nullptr;
+    }
+    int status = SMESH_OK;
+    bool built;
+    {
+      ProfScope prof(ctx, SMESH_PROF_FUSE_HIST);
+      built = image_records_build_group(ctx, recs, idx, nv, W, H, a->P, &status);
+    }
+    SMESH_TRY(status);
+    if (!built) {      // images that take round 2's record passes: one by one (the fusion launch is still shared)
+      for (int v = 0; v < nv; v++) {
+        SMESH_TRY(image_records_build(ctx, *recs[v], idx[v], W, H, a->P));
+        SMESH_TRY(image_records_pending(ctx, *recs[v], idx[v], W, H, ctx->stream));
+      }
+    }
+    RenderedView rv[8];
+    for (int v = 0; v < nv; v++) rv[v] = RenderedView{recs[v]->frags, recs[v]->big_queue, recs[v]->big_count, idx[v], pr[v], wt[v], W, H};
+    {
+      ProfScope fuse_region(ctx, SMESH_PROF_FUSE_SCATTER);
+      SMESH_TRY(smesh_aggregator_fuse_triangles(a, a->P, nullptr, (uint32_t)a->P, rv, nv));
+    }
+    if (a->kind == SMESH_AGG_MUL) SMESH_TRY(ensure_acc_d(a));
+    SMESH_TRY(image_records_scatter_sparse_group(ctx, recs, nv, a->kind, idx, pr, weights ? wt : nullptr, W, H, a->C, a->iew, a->acc, a->acc_lo,
+                                                 a->acc_d, ctx->stream));
+    for (int v = 0; v < nv; v++) SMESH_TRY(image_records_clear(ctx, *recs[v], idx[v], W, H, ctx->stream));
+    smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, false), "image-records");
+    i += (uint64_t)nv;
+  }
+  return SMESH_OK;
+}
+
+
 // rows [row_lo, row_hi) (row_lo a multiple of 4: the tiles move whole 16-byte pieces) normalised into d_out[(row_hi - row_lo) * C]
 static int finalize_into(smesh_aggregator* a, float* d_out, uint64_t row_lo = 0, uint64_t row_hi = ~(uint64_t)0) {
   DeviceCtx* ctx = a->ctx;
@@ -2787,7 +2944,7 @@ struct PinnedRing {
   }
 };
 void parallel_copy(char* dst, const char* src, size_t n) {
-  constexpr int kThreads = 6;
+  constexpr int kThreads = 12;     // (6 until round 5: first-touch page faults of a fresh pageable array, not the copy, are what a thread spends its time on)
   if (n < (1u << 20)) { memcpy(dst, src, n); return; }
   std::thread th[kThreads];
   const size_t per = ((n + kThreads - 1) / kThreads + 63) & ~(size_t)63;   // (rounded UP: n / kThreads rounded down and already a multiple of 64 left the

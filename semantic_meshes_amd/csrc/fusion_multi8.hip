@@ -19,12 +19,12 @@ namespace {
 
 void smesh_launch_fuse_tri_8(int kind, int tri_ct, dim3 grid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv) {
   const dim3 block(kWave);
-  // Group pipeline (SMESH_GROUP_PIPELINE=1, raster.hip): the rasteriser of the next group runs beside this launch, and the one-wave
+  // Group pipeline (the default since round 5; SMESH_GROUP_PIPELINE=0 / smesh_set_option turn it off; raster.hip): the rasteriser of the next group runs beside this launch, and the one-wave
   // workgroups of this kernel would take every wave slot that frees up.  An LDS pad caps them at five per CU -- alone the kernel
   // loses 2 % that way (it is bound by the memory system, not by occupancy) -- and leaves the rest of the register file to the
   // rasteriser's waves.  SMESH_FUSE_LDS_PAD overrides (bytes).
-  static const unsigned pad = getenv("SMESH_FUSE_LDS_PAD") ? (unsigned)atoi(getenv("SMESH_FUSE_LDS_PAD"))
-                              : (getenv("SMESH_GROUP_PIPELINE") && atoi(getenv("SMESH_GROUP_PIPELINE")) != 0) ? 24576u : 0u;
+  static const int pad_env = getenv("SMESH_FUSE_LDS_PAD") ? atoi(getenv("SMESH_FUSE_LDS_PAD")) : -1;
+  const unsigned pad = pad_env >= 0 ? (unsigned)pad_env : (opt_group_pipeline() ? 24576u : 0u);
   TriViews<8> vn;
   for (int v = 0; v < 8; v++) vn.v[v] = tv.v[v];
 #define SMESH_FTN(K)                                                                                     \

@@ -30,6 +30,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 using namespace smesh;
@@ -187,10 +188,10 @@ __device__ __forceinline__ unsigned long long shfl64(unsigned long long x, int s
 // worked out in registers: equal neighbours across columns are one wave shuffle, two DPP row shifts and three ballots, a run's first match in the next
 // column is bit arithmetic on them, and the (at most four) runs of a chain are folded into its root by two pointer-doubling hops --
 // no LDS, no loops over rows.
-__global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t strips_y,
-                                                       uint32_t nstrips, uint32_t strips_per_xcd, uint32_t tag, int dbg,
-                                                       unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
-                                                       uint32_t* __restrict__ big_count) {
+__device__ __forceinline__ void rec_moments_block(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t strips_y,
+                                                  uint32_t nstrips, uint32_t strips_per_xcd, uint32_t tag, int dbg,
+                                                  unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
+                                                  uint32_t* __restrict__ big_count) {
   const uint32_t b = blockIdx.x;
   const int l = threadIdx.x;
   if (b == 0u && l == 0) { big_count[0] = 0u; big_count[2] = 0u; big_count[3] = 0u; }   // (R, later on the stream, is the first to touch them)
@@ -281,6 +282,36 @@ __global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restric
   }
 }
 
+__global__ __launch_bounds__(kWave) void k_rec_moments(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t strips_y,
+                                                       uint32_t nstrips, uint32_t strips_per_xcd, uint32_t tag, int dbg,
+                                                       unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
+                                                       uint32_t* __restrict__ big_count) {
+  rec_moments_block(idx, W, H, P, strips_y, nstrips, strips_per_xcd, tag, dbg, mom, frags, big_count);
+}
+
+// Up to eight images of the same size in ONE launch per pass (smesh_aggregator_add_many): image blockIdx.y with its own record set.
+// Same blocks, same work per image as the one-image kernels above and below; what goes away is seven of every eight launches -- the
+// passes that find nothing to do (E and D on a rendering) cost a launch each, ~5 us of a 75 us call.
+struct RecImage {
+  const uint32_t* idx;
+  const float* probs;
+  const float* weights;
+  unsigned long long* mom;
+  TriFrag* frags;
+  uint4* big4;
+  uint32_t* big_queue;
+  uint32_t* big_count;
+  uint32_t tag;
+};
+struct RecGroup {
+  RecImage im[8];
+};
+__global__ __launch_bounds__(kWave) void k_rec_moments_group(RecGroup g, uint32_t W, uint32_t H, uint32_t P, uint32_t strips_y, uint32_t nstrips,
+                                                             uint32_t strips_per_xcd, int dbg) {
+  const RecImage& r = g.im[blockIdx.y];
+  rec_moments_block(r.idx, W, H, P, strips_y, nstrips, strips_per_xcd, r.tag, dbg, r.mom, r.frags, r.big_count);
+}
+
 // Bits of the pixels equal to v in an 8-column x 8-row window at (xs, ys), bit dx * 8 + dy.  The window lies inside the image.
 __device__ __forceinline__ unsigned long long scan8(const uint32_t* __restrict__ idx, uint32_t H, uint32_t xs, uint32_t ys, uint32_t v) {
   unsigned long long mask = 0ull;
@@ -306,9 +337,9 @@ __device__ __forceinline__ uint4 record_from_window(unsigned long long mask, uin
   return make_uint4((xs + jx) | ((ys + jy) << 16), 1u, (uint32_t)mask, (uint32_t)(mask >> 32));
 }
 
-__global__ __launch_bounds__(kBlock) void k_rec_resolve(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t tag,
-                                                        int dbg, unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
-                                                        uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+__device__ __forceinline__ void rec_resolve_block(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t tag,
+                                                  int dbg, unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
+                                                  uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
   const uint32_t v = blockIdx.x * kBlock + threadIdx.x;
   if (v >= P) return;
   const unsigned long long m = mom[v];
@@ -384,6 +415,16 @@ __global__ __launch_bounds__(kBlock) void k_rec_resolve(const uint32_t* __restri
   if (queue) big_queue[atomicAdd(big_count, 1u)] = v;                        // capacity P: a primitive is queued at most once
 }
 
+__global__ __launch_bounds__(kBlock) void k_rec_resolve(const uint32_t* __restrict__ idx, uint32_t W, uint32_t H, uint32_t P, uint32_t tag,
+                                                        int dbg, unsigned long long* __restrict__ mom, TriFrag* __restrict__ frags,
+                                                        uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+  rec_resolve_block(idx, W, H, P, tag, dbg, mom, frags, big_queue, big_count);
+}
+__global__ __launch_bounds__(kBlock) void k_rec_resolve_group(RecGroup g, uint32_t W, uint32_t H, uint32_t P, int dbg) {
+  const RecImage& r = g.im[blockIdx.y];
+  rec_resolve_block(r.idx, W, H, P, r.tag, dbg, r.mom, r.frags, r.big_queue, r.big_count);
+}
+
 // Pixels of the sparse primitives (k_rec_big), in pixel order: Mesh.h:94-106 with one float atomic per class.  One thread per pixel;
 // an image without sparse primitives -- every rendering -- leaves at the first test.  Mul adds on the hi plane (hi + lo is the value).
 // One pixel of pass D: Mesh.h:94-106 for a pixel of a sparse primitive, one float atomic per class.
@@ -431,6 +472,15 @@ __global__ __launch_bounds__(kBlock) void k_scatter_sparse(const uint32_t* __res
     scatter_sparse_pixel<KIND>(i, idx, probs, weights, P, C, iew, frags, acc, acc_d);
 }
 
+template <int KIND>
+__global__ __launch_bounds__(kBlock) void k_scatter_sparse_group(RecGroup g, uint64_t N, uint32_t P, uint32_t C, float iew, float* __restrict__ acc,
+                                                                 double* __restrict__ acc_d) {
+  const RecImage& r = g.im[blockIdx.y];
+  if (r.big_count[2] == 0u) return;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < N; i += (uint64_t)gridDim.x * kBlock)
+    scatter_sparse_pixel<KIND>(i, r.idx, r.probs, r.weights, P, C, iew, r.frags, acc, acc_d);
+}
+
 // Mul, behind pass D: every sparse primitive (they are all in the queue) folds the float64 sums of this image's terms into its (hi, lo)
 // row, re-centred on the row's largest finite element ("Mul state", fuse_tri.inc.hpp), and leaves the scratch row zero again.
 __global__ __launch_bounds__(kBlock) void k_fold_sparse(const TriFrag* __restrict__ frags, const uint32_t* __restrict__ big_queue,
@@ -461,9 +511,9 @@ __global__ __launch_bounds__(kBlock) void k_fold_sparse(const TriFrag* __restric
 // set per run of a column.  C': the kind 2 record, or "sparse" as k_rec_big decides -- by the workgroup that finishes pass E LAST
 // (a ticket counter, big_count[3]: it has seen every other workgroup's fence, so their atomics have landed).  No workgroup ever
 // waits for another one: nothing here depends on how many of them are resident at once (round 3's grid barrier did).
-__global__ __launch_bounds__(kBlock) void k_rec_extent(const uint32_t* __restrict__ idx, uint64_t N, uint32_t H, uint32_t P,
-                                                       TriFrag* __restrict__ frags, uint4* __restrict__ big4,
-                                                       const uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+__device__ __forceinline__ void rec_extent_block(const uint32_t* __restrict__ idx, uint64_t N, uint32_t H, uint32_t P,
+                                                 TriFrag* __restrict__ frags, uint4* __restrict__ big4,
+                                                 const uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
   const uint32_t nbig = big_count[0];       // final: pass R ran before this launch
   if (nbig == 0u) return;
   for (uint64_t base = (uint64_t)blockIdx.x * kBlock; base < N; base += (uint64_t)gridDim.x * kBlock) {
@@ -524,6 +574,16 @@ __global__ __launch_bounds__(kBlock) void k_rec_extent(const uint32_t* __restric
     frags[v] = rec;
     big4[v] = make_uint4(0u, 0u, 0u, 0u);
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_rec_extent(const uint32_t* __restrict__ idx, uint64_t N, uint32_t H, uint32_t P,
+                                                       TriFrag* __restrict__ frags, uint4* __restrict__ big4,
+                                                       const uint32_t* __restrict__ big_queue, uint32_t* __restrict__ big_count) {
+  rec_extent_block(idx, N, H, P, frags, big4, big_queue, big_count);
+}
+__global__ __launch_bounds__(kBlock) void k_rec_extent_group(RecGroup g, uint64_t N, uint32_t H, uint32_t P) {
+  const RecImage& r = g.im[blockIdx.y];
+  rec_extent_block(r.idx, N, H, P, r.frags, r.big4, r.big_queue, r.big_count);     // (the ticket counts the blocks of THIS image: gridDim.x)
 }
 
 // After the fusion, when the image is much smaller than the primitive count: only the records the image touched.
@@ -604,6 +664,79 @@ int image_records_build(DeviceCtx* ctx, ImageRecords& r, const uint32_t* d_idx, 
   hipLaunchKernelGGL(k_rec_origin, grid, block, 0, st, d_idx, N, (uint32_t)H, (uint32_t)P, r.cand);
   hipLaunchKernelGGL(k_rec_mask, grid, block, 0, st, d_idx, N, (uint32_t)H, (uint32_t)P, r.cand, r.big4, r.frags, r.big_queue, r.big_count);
   hipLaunchKernelGGL(k_rec_big, dim3(64), block, 0, st, d_idx, (uint32_t)H, r.cand, r.big4, r.frags, r.big_queue, r.big_count);
+  SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
+}
+
+// smesh_aggregator_add_many: the records of `n` <= 8 images of the same size, each into its own set, with ONE launch per pass
+// (M, R, E).  Returns false (nothing launched) when the images do not take the moments passes: the caller then builds them one by one.
+bool image_records_build_group(DeviceCtx* ctx, ImageRecords* const* recs, const uint32_t* const* d_idx, int n, uint64_t W, uint64_t H, uint64_t P,
+                               int* status) {
+  *status = SMESH_OK;
+  if (n < 1 || n > 8 || W > 65535 || H > 65535 || !use_moments(W, H, P)) return false;
+  hipStream_t st = ctx->stream;
+  RecGroup g;
+  memset(&g, 0, sizeof g);
+  for (int i = 0; i < n; i++) {
+    ImageRecords& r = *recs[i];
+    if (r.P != P || !r.frags) {
+      r.release();
+      const size_t np = (size_t)(P ? P : 1);
+      char* base = nullptr;
+      const size_t total = block_bytes(np) + np * (sizeof(uint4) + 8 + 4);
+      hipError_t e = dev_malloc(reinterpret_cast<void**>(&base), total);
+      if (e != hipSuccess) { *status = fail_hip(e, "image records allocation", __FILE__, __LINE__); return true; }
+      r.frags = reinterpret_cast<TriFrag*>(base);
+      r.cand = reinterpret_cast<uint32_t*>(base + np * sizeof(TriFrag));
+      r.big_count = reinterpret_cast<uint32_t*>(base + np * (sizeof(TriFrag) + 4));
+      r.big4 = reinterpret_cast<uint4*>(base + block_bytes(np));
+      r.mom = reinterpret_cast<unsigned long long*>(base + block_bytes(np) + np * sizeof(uint4));
+      r.big_queue = reinterpret_cast<uint32_t*>(base + block_bytes(np) + np * (sizeof(uint4) + 8));
+      r.P = P;
+      if (hipMemsetAsync(base, 0, total, st) != hipSuccess) { *status = fail(SMESH_ERR_RUNTIME, "image records: clearing a new record set failed"); return true; }
+      r.clean = true;
+    } else if (!r.moments && !r.clean) {
+      // the set was last used by passes A / B and not cleared: start from zero
+      if (hipMemsetAsync(r.frags, 0, block_bytes(P ? P : 1), st) != hipSuccess) { *status = fail(SMESH_ERR_RUNTIME, "image records: clear failed"); return true; }
+    }
+    r.moments = true;
+    r.clean = false;
+    g.im[i] = RecImage{d_idx[i], nullptr, nullptr, r.mom, r.frags, r.big4, r.big_queue, r.big_count, r.tag};
+    r.tag ^= 6u;      // 2 <-> 4
+  }
+  static const int dbg = SMESH_ABL_ENV("SMESH_REC_DBG");
+  const uint64_t N = W * H;
+  const uint32_t strips_y = (uint32_t)div_up(H, kTY), nstrips = (uint32_t)div_up(W, kSX) * strips_y;
+  const uint32_t strips_per_xcd = (uint32_t)div_up(nstrips, 8);
+  hipLaunchKernelGGL(k_rec_moments_group, dim3(strips_per_xcd * 8, (uint32_t)n), dim3(kWave), 0, st, g, (uint32_t)W, (uint32_t)H, (uint32_t)P, strips_y,
+                     nstrips, strips_per_xcd, dbg);
+  hipLaunchKernelGGL(k_rec_resolve_group, dim3((uint32_t)div_up(P ? P : 1, kBlock), (uint32_t)n), dim3(kBlock), 0, st, g, (uint32_t)W, (uint32_t)H,
+                     (uint32_t)P, dbg);
+  const uint32_t eg = (uint32_t)std::min<uint64_t>(div_up(N, kBlock), (uint64_t)std::max(1, ctx->num_cus / n));
+  hipLaunchKernelGGL(k_rec_extent_group, dim3(eg, (uint32_t)n), dim3(kBlock), 0, st, g, N, (uint32_t)H, (uint32_t)P);
+  if (hipGetLastError() != hipSuccess) *status = fail(SMESH_ERR_RUNTIME, "image records: group launch failed");
+  return true;
+}
+
+// Pass D for the images of a group (behind their fusion launch), one launch; Mul: the fold of each image behind it, image by image.
+int image_records_scatter_sparse_group(DeviceCtx* ctx, ImageRecords* const* recs, int n, int kind, const uint32_t* const* d_idx,
+                                       const float* const* d_probs, const float* const* d_w, uint64_t W, uint64_t H, uint32_t C, float iew,
+                                       float* acc, float* acc_lo, double* acc_d, hipStream_t st) {
+  if (kind == SMESH_AGG_MUL) {     // (the float64 scratch rows serve one image at a time)
+    for (int i = 0; i < n; i++)
+      SMESH_TRY(image_records_scatter_sparse(ctx, *recs[i], kind, d_idx[i], d_probs[i], d_w ? d_w[i] : nullptr, W, H, C, iew, acc, acc_lo, acc_d, st));
+    return SMESH_OK;
+  }
+  RecGroup g;
+  memset(&g, 0, sizeof g);
+  for (int i = 0; i < n; i++) {
+    const ImageRecords& r = *recs[i];
+    g.im[i] = RecImage{d_idx[i], d_probs[i], d_w ? d_w[i] : nullptr, r.mom, r.frags, r.big4, r.big_queue, r.big_count, 0u};
+  }
+  const uint64_t N = W * H;
+  const dim3 grid((uint32_t)std::min<uint64_t>(div_up(N, kBlock), (uint64_t)std::max(1, 2 * ctx->num_cus / n)), (uint32_t)n), block(kBlock);
+  if (kind == SMESH_AGG_SUM) hipLaunchKernelGGL(k_scatter_sparse_group<SMESH_AGG_SUM>, grid, block, 0, st, g, N, (uint32_t)recs[0]->P, C, iew, acc, acc_d);
+  else hipLaunchKernelGGL(k_scatter_sparse_group<SMESH_AGG_SUMMAX>, grid, block, 0, st, g, N, (uint32_t)recs[0]->P, C, iew, acc, acc_d);
   SMESH_HIP(hipGetLastError());
   return SMESH_OK;
 }

@@ -604,10 +604,10 @@ __device__ __forceinline__ Claim4 wave_claim_prepare4(uint32_t T0, uint32_t n01,
 // One lane per triangle (bounding box <= 8 x 8; larger ones: see the end of the kernel): coverage walk, slot
 // reservation in the (at most 2 x 2) tiles the box overlaps, then depth per covered sample and the queue stores.
 // The edge functions are shade()'s, expression for expression.
-// `f`: this lane's triangle (a.F: none), `i0 .. i2` its vertex indices (valid when f < a.F); `wave0`: the triangle of lane 0;
-// `sub`: the wave's sub-queue in every tile.
+// `f`: this lane's triangle (a.F: none; ANY triangle: lanes need not hold consecutive ones), `i0 .. i2` its vertex indices (valid
+// when f < a.F); `sub`: the wave's sub-queue in every tile.
 __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64_t f, const int32_t i0, const int32_t i1, const int32_t i2,
-                                               const uint64_t wave0, const uint32_t sub) {
+                                               const uint32_t sub) {
   const int lane = threadIdx.x & 63;
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
@@ -744,7 +744,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
     const double e2A = bd(t.e2.A), e2B = bd(t.e2.B), e2C = bd(t.e2.C);
     const double iz0 = bd(t.iz0), iz1 = bd(t.iz1), iz2 = bd(t.iz2);
     const int c0 = bi(t.cls0), c1 = bi(t.cls1), c2 = bi(t.cls2);
-    const uint32_t fb = (uint32_t)wave0 + (uint32_t)src;
+    const uint32_t fb = (uint32_t)bi((int)(uint32_t)f);      // (the owner lane's triangle: lanes need not hold consecutive ones, see raster_frag_wave)
     const uint32_t fbid = (uint32_t)bi((int)pid);
     uint32_t tfirst = 0u, tres = 0u;
     if (a.tex_res) { tfirst = a.tex_first[fb]; tres = a.tex_res[fb]; }
@@ -796,21 +796,28 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
 // meshes of millions of triangles) the next group's vertex indices are requested before the current group is shaded (three
 // registers), so that it starts one memory round trip ahead: cfg4 666 -> 627 us per eight-view launch with four groups; nothing at
 // cfg2 (169 / 171 / 175 / 182 us with 1 / 2 / 4 / 8 groups, tools/raster_groups.sh), where one group per wave stays.
+// One wave = a.groups x a.tpw consecutive triangles (tpw: 64 for large meshes; fewer for small ones, so that the cooperative
+// medium-triangle loop has enough waves to spread over the chip).  With several groups per wave (LOOP: the grouped launches of
+// meshes of millions of triangles) the next group's vertex indices are requested before the current group is shaded (three
+// registers), so that it starts one memory round trip ahead: cfg4 666 -> 627 us per eight-view launch with four groups; nothing at
+// cfg2 (169 / 171 / 175 / 182 us with 1 / 2 / 4 / 8 groups, tools/raster_groups.sh), where one group per wave stays.
+// (Lane compaction -- cull a group by bounding box first, park the triangles that can emit in an LDS ring, shade full waves of
+// them -- removes a third (cfg2) to three quarters (cfg4) of the wave instructions and was measured SLOWER in rounds 2 and 5:
+// cfg2 33.1 -> 38.0 us per view for the raster stage, cfg4 4 777 -> 4 615 views/s.  The kernel waits for memory round trips, not for
+// issue slots; NOTES/round5.md.)
 template <bool LOOP>
 __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint64_t wave_id) {
   const int lane = threadIdx.x & 63;
   const uint32_t G = LOOP ? a.groups : 1u;
-  uint64_t wave0 = wave_id * G * a.tpw;
-  uint64_t f = lane < (int)a.tpw ? wave0 + lane : a.F;
+  uint64_t f = lane < (int)a.tpw ? wave_id * G * a.tpw + lane : a.F;
   int32_t n0 = 0, n1 = 0, n2 = 0;
   if (f < a.F) { n0 = a.faces[3 * f + 0]; n1 = a.faces[3 * f + 1]; n2 = a.faces[3 * f + 2]; }
   for (uint32_t g = 0; g < G; g++) {
     const int32_t i0 = n0, i1 = n1, i2 = n2;
     const uint64_t fn = f + 64u;          // (G > 1 only with 64 triangles per group)
     if (g + 1 < G && fn < a.F) { n0 = a.faces[3 * fn + 0]; n1 = a.faces[3 * fn + 1]; n2 = a.faces[3 * fn + 2]; }
-    raster_frag_64(a, f, i0, i1, i2, wave0, (uint32_t)(wave_id * G + g) & (kQSub - 1));
+    raster_frag_64(a, f, i0, i1, i2, (uint32_t)(wave_id * G + g) & (kQSub - 1));
     f = fn < a.F ? fn : a.F;
-    wave0 += 64u;
   }
 }
 
@@ -829,7 +836,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) voi
   const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
   raster_frag_wave<true>(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
 }
-
 // The largest triangles (box over kMedium x kMedium) and the triangles that cross the near plane (clip_piece), between k_raster_frag
 // and k_tile_resolve: one workgroup per screen tile scans their queue, keeps those whose box overlaps the tile and shades the
 // overlap, 256 samples at a time, piece by piece.  The fragments go through the global key image (64-bit atomicMin; the lanes of
@@ -1116,6 +1122,7 @@ struct smesh_renderer {
   } held;
   // smesh_fuse_views, group pipeline: bank b (slots b * kMaxGroup ...) has been rasterised / its fusion has been queued
   hipEvent_t ev_bank_rendered[2] = {nullptr, nullptr}, ev_bank_consumed[2] = {nullptr, nullptr}, ev_main_fence = nullptr;
+  hipEvent_t ev_raster_done = nullptr;   // main_after_raster()
   uint64_t group_seq = 0;
   bool bank_used[2] = {false, false};
   hipEvent_t ev_rendered[2] = {nullptr, nullptr};   // raster stream: slot is complete
@@ -1185,6 +1192,18 @@ int ensure_keys(smesh_renderer::ViewScratch& vs, uint64_t W, uint64_t H, hipStre
   vs.keys_pixels = N;
   hipLaunchKernelGGL(k_fill_keys, dim3((uint32_t)div_up(N, 256)), dim3(256), 0, st, vs.keys, N);
   SMESH_HIP(hipGetLastError());
+  return SMESH_OK;
+}
+
+// The main stream takes over renderer state that the raster stream may still be using (the last group of a pipelined
+// smesh_fuse_views call): a device-side wait on an event, never a host synchronisation -- the group pipeline is the default since
+// round 5, and a plain render() or a ranged job right behind a fuse_views call must not stall the host for it.
+int main_after_raster(smesh_renderer* r) {
+  if (!r->raster_pending) return SMESH_OK;
+  if (!r->ev_raster_done) SMESH_HIP(hipEventCreateWithFlags(&r->ev_raster_done, hipEventDisableTiming));
+  SMESH_HIP(hipEventRecord(r->ev_raster_done, r->ctx->raster_stream));
+  SMESH_HIP(hipStreamWaitEvent(r->ctx->stream, r->ev_raster_done, 0));
+  r->raster_pending = false;
   return SMESH_OK;
 }
 
@@ -1280,10 +1299,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   if (!st) {
     // plain render()/render_device(): main stream, after whatever smesh_fuse_view left on the raster stream
     st = ctx->stream;
-    if (r->raster_pending) {
-      SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
-      r->raster_pending = false;
-    }
+    SMESH_TRY(main_after_raster(r));
     r->main_pending = true;
   }
   const uint64_t W = cam->width, H = cam->height, N = W * H;
@@ -1935,9 +1951,8 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
       SMESH_HIP(hipStreamSynchronize(ctx->stream));
       r->main_pending = false;
     }
-  } else if (r->raster_pending) {
-    SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
-    r->raster_pending = false;
+  } else {
+    SMESH_TRY(main_after_raster(r));
   }
   if (r->fused[slot].bytes < N * 8) {
     // growing a slot frees the old buffer: nothing may still be reading it
@@ -2001,13 +2016,10 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
     SMESH_HIP(hipSetDevice(ctx->device));
     SMESH_TRY(smesh_aggregator_join_exchange(a));   // (rows still being exchanged on the exchange stream: smesh_allreduce_rows)
-    static const bool group_pipeline_on = getenv("SMESH_GROUP_PIPELINE") && atoi(getenv("SMESH_GROUP_PIPELINE")) != 0;
+    const bool group_pipeline_on = opt_group_pipeline();     // (default on since round 5; SMESH_GROUP_PIPELINE=0 / smesh_set_option)
     const bool use_pipeline = grouped && group_pipeline_on;
     if (!use_pipeline) {
-      if (r->raster_pending) {
-        SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
-        r->raster_pending = false;
-      }
+      SMESH_TRY(main_after_raster(r));
       r->main_pending = true;   // the renderer's scratch is in use on the main stream
     }
     // Group pipeline (SMESH_GROUP_PIPELINE=1; off by default): the rasteriser launches of this group go to the raster stream and
@@ -2174,10 +2186,7 @@ int smesh_fuse_views_begin(smesh_renderer_t* r, smesh_aggregator_t* a, const sme
   std::lock_guard<std::recursive_mutex> lock(ctx->mu);
   SMESH_HIP(hipSetDevice(ctx->device));
   SMESH_TRY(smesh_aggregator_join_exchange(a));   // (an exchange of an earlier job still in flight on the exchange stream)
-  if (r->raster_pending) {
-    SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
-    r->raster_pending = false;
-  }
+  SMESH_TRY(main_after_raster(r));
   r->main_pending = true;
   smesh_renderer::HeldJob& h = r->held;
   h = smesh_renderer::HeldJob();

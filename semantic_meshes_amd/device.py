@@ -194,13 +194,15 @@ def pinned_empty(shape, dtype=np.float32):
 _result_free = {}            # nbytes -> [pointers of free buffers]
 _result_live = [0]           # page-locked bytes handed out or parked
 _RESULT_MIN = 4 << 20
-_RESULT_LIMIT = int(os.environ.get("SMESH_RESULT_POOL_MB", "4096")) << 20
-_RESULT_KEEP = 2             # free buffers kept per size
+# (round 5: 32 GiB, so that cfg5's 12 GB result lands in page-locked memory too -- 438 ms through the staging ring into pageable
+#  memory, 27 GB/s, against the DMA's ~55 GB/s; a host that cannot lock that much falls back to the ring, below)
+_RESULT_LIMIT = int(os.environ.get("SMESH_RESULT_POOL_MB", "32768")) << 20
+_RESULT_KEEP = 2             # free buffers kept per size (one for results of 1 GiB and more)
 
 
 def _recycle_result(n, ptr):
     free = _result_free.setdefault(n, [])
-    if len(free) < _RESULT_KEEP:
+    if len(free) < (1 if n >= (1 << 30) else _RESULT_KEEP):
         free.append(ptr)
     else:
         _result_live[0] -= n

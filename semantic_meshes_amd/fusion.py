@@ -148,6 +148,54 @@ class _MeshAggregator:
         self._hold([k0 if imem == _lib.MEM_DEVICE else None, k1 if pmem == _lib.MEM_DEVICE else None,
                     k2 if (wp is not None and wmem == _lib.MEM_DEVICE) else None])
 
+    def add_many(self, primitive_images, probs_images, weights_images=None):
+        """`add()` for a batch of views, in order (new functionality; the reference's loop adds one image per call).  Same sums as
+        the calls one by one -- per accumulator row the same float32 additions in the same order -- but device-resident dense
+        uint32 / int32 index images with dense float32 device class vectors, all of one size, share their kernel launches in groups
+        of up to eight (`smesh_aggregator_add_many`).  Anything else in the batch is added image by image."""
+        prims, probs = list(primitive_images), list(probs_images)
+        wts = None if weights_images is None else list(weights_images)
+        n = len(prims)
+        if len(probs) != n or (wts is not None and len(wts) != n):
+            raise ValueError("add_many needs one probs image (and one weights image) per primitive image")
+        if n == 0:
+            return
+        streams, desc = [], []
+        for i in range(n):
+            pi = prims[i]
+            if type(pi).__name__ == "PyCapsule":
+                from . import dlpack
+                own = dlpack.own_capsule_owner(pi)
+                if own is not None:
+                    pi = own
+            d_i = describe(pi, 2, "primitive image", self.device, streams)
+            d_p = describe(probs[i], 3, "probs image", self.device, streams)
+            d_w = None if wts is None or wts[i] is None else describe(wts[i], 2, "weights image", self.device, streams)
+            desc.append((d_i, d_p, d_w))
+        (ip0, imem0, ishape0, idt0, istr0, _), (pp0, pmem0, pshape0, pdt0, pstr0, _), w0 = desc[0]
+        uniform = idt0 in _IDX_CODES and pdt0 == np.float32 and imem0 == _lib.MEM_DEVICE and pmem0 == _lib.MEM_DEVICE
+        for d_i, d_p, d_w in desc:
+            uniform = (uniform and d_i[1:5] == (imem0, ishape0, idt0, istr0) and d_p[1:5] == (pmem0, pshape0, pdt0, pstr0)
+                       and (d_w is None) == (w0 is None)
+                       and (d_w is None or (d_w[1] == _lib.MEM_DEVICE and d_w[3] == np.float32 and tuple(d_w[2]) == tuple(ishape0) and d_w[4] == w0[4])))
+        if uniform and (tuple(ishape0) != tuple(pshape0[:2]) or pshape0[2] != self.classes):
+            uniform = False      # (add() raises the reference's error for the image concerned)
+        if not uniform or n < 2:
+            for i in range(n):
+                self.add(prims[i], probs[i], None if wts is None else wts[i])
+            return
+        W, H = ishape0
+        if W == 0 or H == 0:
+            return
+        iptr = (ctypes.c_void_p * n)(*[d[0][0] for d in desc])
+        pptr = (ctypes.c_void_p * n)(*[d[1][0] for d in desc])
+        wptr = None if w0 is None else (ctypes.c_void_p * n)(*[d[2][0] for d in desc])
+        _lib.check(_lib.lib().smesh_aggregator_add_many(
+            self._h, n, iptr, _IDX_CODES[idt0], _c64(istr0), imem0, pptr, _c64(pstr0), pmem0,
+            wptr, None if w0 is None else _c64(w0[4]), _lib.MEM_DEVICE if w0 is not None else _lib.MEM_HOST, W, H))
+        release_to(self.device, streams)
+        self._hold([d[0][5] for d in desc] + [d[1][5] for d in desc] + [d[2][5] for d in desc if d[2] is not None])
+
     # class-wide switch for the content check above
     match_renders = os.environ.get("SMESH_MATCH_RENDERS", "1") != "0"
 

@@ -493,3 +493,77 @@ def test_four_processes_add_foreign_images_with_sparse_primitives_concurrently(t
         out, err = p.communicate(timeout=900)
         assert p.returncode == 0, "worker %d: %s\n%s" % (i, out[-1000:], err[-3000:])
         assert "worker %d ok" % (100 + i) in out
+
+
+@pytest.mark.parametrize("kind", ["sum", "summax", "mul"])
+@pytest.mark.parametrize("C", [19, 40, 64])
+def test_add_many_equals_sequential_add_bit_for_bit(sm, oracle, kind, C):
+    """`add_many` (smesh_aggregator_add_many: the record passes of up to eight device-resident images in one launch each, one
+    k_fuse_tri<.., 8> launch per group) leaves the raw accumulator of `add()` image by image -- bit for bit: per row the same float32
+    additions in the same order -- for eleven images (groups of 8 + 2 + 1), with and without weights, uint32 and int32 planes; and both
+    equal the float32 single-threaded reference loop for Sum / Summax (Mul: 1e-5 of the float64 oracle)."""
+    from semantic_meshes_amd.device import to_device
+    mesh, cams = small_scene(120, 60, 320, 240, views=11)
+    P = len(mesh.faces)
+    rng = np.random.default_rng(77 + C)
+    o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
+    images = [o.render(cam)[0] for cam in cams]
+    probs = [random_probs(rng, 320, 240, C) for _ in cams]
+    wts = [rng.random((320, 240), dtype=np.float32) + 0.25 for _ in cams]
+    d_probs = [to_device(p) for p in probs]
+    d_wts = [to_device(w) for w in wts]
+    for dtype, with_w in ((np.uint32, False), (np.int32, True)):
+        d_img = [to_device(im.astype(dtype)) for im in images]
+        seq = sm.fusion.MeshAggregator(P, C, kind, 0.5)
+        for k in range(len(cams)):
+            seq.add(d_img[k], d_probs[k], d_wts[k] if with_w else None)
+        many = sm.fusion.MeshAggregator(P, C, kind, 0.5)
+        many.add_many(d_img, d_probs, d_wts if with_w else None)
+        assert path(sm) == "image-records"
+        assert np.array_equal(many.get_raw().view(np.uint32), seq.get_raw().view(np.uint32)), (kind, C, dtype)
+        assert np.array_equal(many.get(), seq.get())
+        oracle.set_accum_double(kind == "mul")
+        try:
+            oagg = oracle.OracleAggregator(P, C, kind, 0.5)
+            for k in range(len(cams)):
+                oagg.add(images[k], probs[k], wts[k] if with_w else None)
+            if kind == "mul":
+                assert_fused_close(many.get(), oagg.get(), rtol=1e-5)
+            else:
+                assert np.array_equal(many.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
+        finally:
+            oracle.set_accum_double(False)
+
+
+def test_add_many_falls_back_image_by_image_and_takes_blobs(sm, oracle):
+    """What the grouped launches do not take goes through add() image by image with the same result: host arrays, a batch of mixed
+    memory, a single image.  Blob images (primitives of every size, sparse ones among them: float atomics) in one group: 1e-5."""
+    from semantic_meshes_amd.device import to_device
+    W, H, P, C = 200, 160, 400, 19
+    rng = np.random.default_rng(5)
+    images = [blob_image(rng, W, H, P, 300) for _ in range(5)]
+    images[3][::7, ::5] = np.uint32(17)                       # a primitive scattered all over the image: "sparse" (pass D)
+    probs = [random_probs(rng, W, H, C) for _ in images]
+    oracle.set_accum_double(True)
+    try:
+        for kind in ("sum", "summax", "mul"):
+            oagg = oracle.OracleAggregator(P, C, kind)
+            for im, p in zip(images, probs):
+                oagg.add(im, p)
+            want = oagg.get()
+            for variant in ("device", "host", "mixed", "single"):
+                agg = sm.fusion.MeshAggregator(P, C, kind)
+                if variant == "device":
+                    agg.add_many([to_device(im) for im in images], [to_device(p) for p in probs])
+                elif variant == "host":
+                    agg.add_many(images, probs)
+                elif variant == "mixed":
+                    agg.add_many([to_device(im) if i % 2 else im for i, im in enumerate(images)], [to_device(p) for p in probs])
+                else:
+                    for im, p in zip(images, probs):
+                        agg.add_many([to_device(im)], [to_device(p)])
+                assert_fused_close(agg.get(), want, rtol=1e-5)
+    finally:
+        oracle.set_accum_double(False)
+    with pytest.raises(ValueError):
+        sm.fusion.MeshAggregator(P, C).add_many(images, probs[:-1])

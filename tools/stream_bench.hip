@@ -44,13 +44,65 @@ __global__ __launch_bounds__(64) void k_rows(float* __restrict__ acc, uint64_t r
     }
   }
 }
+// 600-byte rows read from SCATTERED positions of a large buffer, `inflight` rows per wave at a time: what k_fuse_tri_wide does to the
+// class-vector images at cfg5 (a visible triangle's pixel is one 600-byte row of a 5.3 GB image, eight images per launch).
+//   stride = 0: row index = a hash of (wave, step) -- no locality at all
+//   stride > 0: wave w reads rows (w * stride + step) mod rows: neighbouring waves read rows `stride` apart (an image column apart)
+template <int INFLIGHT>
+__global__ __launch_bounds__(64) void k_gather_rows(const float* __restrict__ buf, uint64_t rows, int C, uint32_t steps, uint64_t stride, float* sink) {
+  const int l = threadIdx.x;
+  const int c = 4 * l;
+  float s = 0.f;
+  for (uint32_t st = 0; st < steps; st += INFLIGHT) {
+    fvec4 v[INFLIGHT];
+#pragma unroll
+    for (int b = 0; b < INFLIGHT; b++) {
+      uint64_t r;
+      if (stride) r = ((uint64_t)blockIdx.x * stride + st + b) % rows;
+      else {
+        uint64_t h = ((uint64_t)blockIdx.x * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(st + b) * 0xBF58476D1CE4E5B9ull);
+        h ^= h >> 29; h *= 0x94D049BB133111EBull; h ^= h >> 32;
+        r = h % rows;
+      }
+      v[b] = fvec4{0.f, 0.f, 0.f, 0.f};
+      if (c + 4 <= C) v[b] = *reinterpret_cast<const fvec4_a4*>(buf + r * C + c);
+    }
+#pragma unroll
+    for (int b = 0; b < INFLIGHT; b++) s += v[b].x + v[b].y + v[b].z + v[b].w;
+  }
+  if (s == 123.456f) *sink = s;
+}
+
 template <typename F> float timeit(F f, int reps = 5) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   f(); CK(hipDeviceSynchronize());
   CK(hipEventRecord(a)); for (int i = 0; i < reps; i++) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
 }
-int main() {
+int gather_main() {
+  // scattered 600-byte rows: footprint 12 GB and 42 GB (eight cfg5 images), 2 / 4 / 8 rows in flight per wave, 8 waves per SIMD worth of workgroups
+  float* sink; CK(hipMalloc(&sink, 4));
+  for (uint64_t gb : {12ull, 42ull}) {
+    const uint64_t bytes = gb << 30;
+    float* buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 0, bytes));
+    const uint64_t rows = bytes / 600;
+    const uint32_t waves = 312500, steps = 96;            // ~ the waves of a cfg5 launch, ~ the rows a wave reads in it
+    for (uint64_t stride : {0ull, 2160ull, 1ull}) {
+      const double total = (double)waves * steps * 600.0;
+      const float t2 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<2>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink); }, 3);
+      const float t4 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<4>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink); }, 3);
+      const float t8 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<8>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink); }, 3);
+      printf("gather of 600-B rows, footprint %2llu GB, %s: 2 in flight %6.2f TB/s   4 in flight %6.2f TB/s   8 in flight %6.2f TB/s   (%.1f GB read)\n",
+             (unsigned long long)gb, stride == 0 ? "hashed positions      " : stride == 1 ? "consecutive rows      " : "rows 2160 apart (x+1) ",
+             total / 1e12 / (t2 * 1e-3), total / 1e12 / (t4 * 1e-3), total / 1e12 / (t8 * 1e-3), total / 1e9);
+    }
+    CK(hipFree(buf));
+  }
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1 && argv[1][0] == 'g') return gather_main();
   const uint64_t maxb = 12ull << 30;
   float* buf; CK(hipMalloc(&buf, maxb)); CK(hipMemset(buf, 0, maxb));
   float* sink; CK(hipMalloc(&sink, 4));
