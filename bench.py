@@ -474,7 +474,7 @@ def main():
 
     def fuse_range(first, last):
         """views [first, last) in order: one fuse_view call per view, or fuse_views on batches of B (the library then
-        shares launches between the views of a group, see DESIGN.md 3.0)"""
+        shares launches between the views of a group, see DESIGN.md 3.2)"""
         if B == 1:
             for i in range(first, last):
                 agg.fuse_view(renderer, cams[i], probs[i])

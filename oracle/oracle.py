@@ -107,13 +107,13 @@ def set_fast_histogram(on):
 
 def set_mul_literal(on):
     """Independent yardstick: the Mul term as the literal reading of Fusion.cu:83-87, logf(powf(p, w)) with p^w rounded to
-    float32 first, instead of the spec'd w * log_spec(p) (DESIGN.md 3.3 #6)."""
+    float32 first, instead of the spec'd w * log_spec(p) (DESIGN.md 4 #7)."""
     lib().smesh_oracle_set_mul_literal(1 if on else 0)
 
 
 def set_edge_five_op(on):
     """Independent yardstick: the round-1 edge function sign * (dx (py - ly) - dy (px - lx)) instead of the spec'd
-    fma(A, px, fma(B, py, C)) (DESIGN.md 3.3 #3)."""
+    fma(A, px, fma(B, py, C)) (DESIGN.md 4 #4)."""
     lib().smesh_oracle_set_edge_five_op(1 if on else 0)
 
 

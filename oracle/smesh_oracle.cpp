@@ -193,7 +193,7 @@ inline uint32_t texel_index(uint32_t res, double b1, double b2) {
   return (uint32_t)(row * (row + 1) / 2 + tu);
 }
 
-// ---- near-plane clipping (round 3; DESIGN.md "Raster spec" #1b) ---------------------------------------------------------------
+// ---- near-plane clipping (round 3; DESIGN.md "Raster spec" 2) ---------------------------------------------------------------
 // A vertex is FRONT when its float32 camera-space z is > kNear and everything about it is finite (project_vertex gives it screen
 // coordinates), BEHIND when its camera-space coordinates are finite and z <= kNear, UNUSABLE otherwise.  A triangle with an unusable
 // vertex, or with no front vertex, emits nothing.  A triangle with front AND behind vertices is cut along the plane z_c = kNear:

@@ -152,6 +152,7 @@ struct TriFuseArgs {
   // big triangles take only triangles at positions [f_lo, f_hi).  A launch over everything: blk_first = 0, f_lo = 0, f_hi = F.
   uint32_t blk_first;
   uint32_t f_lo, f_hi;
+  uint32_t lds_pad;           // host side only: dynamic LDS of the eight-view k_fuse_tri launch (caps its workgroups per CU beside the rasteriser, fusion_multi8.hip)
 };
 
 // What k_fuse_tri needs to know about ONE of the views it fuses in a launch (the per-view part of TriFuseArgs), and NV of them.
@@ -182,6 +183,7 @@ struct RenderedView {
   int64_t ps0 = 0, ps1 = 0;     // element strides of x and y of `probs` when it is not the dense (W,H,C) image (class stride 1); 0, 0: dense
   bool mid_queue = false;       // big_queue[big_capacity ...] lists the medium triangles of this view, big_len[3] of them (the rasteriser's renders)
   bool no_big = false;          // PROVEN on the host (raster.hip no_big_possible): no triangle of this view has a box over 8 x 8 pixels -- big_queue is empty
+  bool fine = false;            // bounded on the host (raster.hip box_extent_bound <= 48 pixels): a finely tessellated mesh seen from outside -- few or no queued triangles
 };
 
 // Medium triangles: a bounding box over 8 x 8 pixels of at most kMidBox pixels (16 x 16: beyond that a whole wave per triangle --

@@ -6,7 +6,7 @@
 // launch gap per group of eight views, and on meshes that do have medium triangles the two kernels now share
 // the chip instead of running one after the other.
 //
-// Why sixteen lanes per entry: a mesh of 90 000 triangles at 1080p (~23 pixels per triangle, boxes
+// Why sixteen lanes per entry (NOTES/round3.md): a mesh of 90 000 triangles at 1080p (~23 pixels per triangle, boxes
 // just over 8 x 8 -- a decimated indoor scan, eval-scannet/simplify_scannet_meshes.py) spent 115 us per view in the tail blocks of
 // k_fuse_tri, where ONE WAVE takes one queued triangle at a time through all the views of the launch (fuse_box): a chain of dependent
 // memory round trips (queue entry -> records -> index plane -> class vectors -> row) with a quarter of the lanes busy -- and seven

@@ -534,8 +534,10 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(fuse_tri_
   }
   float accr[CT];
   bool rows_loaded = false;
-  // Mul: the view's contributions are summed from zero (in double where the registers allow it) and meet the re-centred row once
-  typedef typename std::conditional<(CT <= 24), double, float>::type part_t;
+  // Mul: the view's contributions are summed from zero in double and meet the re-centred row once.  (Until round 5 in float32 beyond
+  // 24 register slots: the Mul instances for 25 .. 48 classes sit at 270 - 330 registers, one wave per SIMD, with or without the
+  // 40 further ones -- and add_many's test found an element at 1.4e-5 of the float64 oracle at 40 classes.)
+  typedef double part_t;
   constexpr int PT = KIND == SMESH_AGG_MUL ? CT : 1;
 #pragma unroll
   for (int v = 0; v < NV; v++) {

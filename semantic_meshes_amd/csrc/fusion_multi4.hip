@@ -1,6 +1,6 @@
 // fusion_multi4.hip -- the four-views-per-launch instances of the triangle-order fusion kernel k_fuse_tri (class counts up to 40:
 // exact instances 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 / 16 / 24 / 32 / 40).  A translation unit of its own so that the
-// instance sets compile in parallel (see fusion_pair.hip, DESIGN.md 3.0).
+// instance sets compile in parallel (see fusion_pair.hip, DESIGN.md 3.2).
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"

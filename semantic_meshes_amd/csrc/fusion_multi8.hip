@@ -1,6 +1,6 @@
 // fusion_multi8.hip -- the eight-views-per-launch instances of the triangle-order fusion kernel k_fuse_tri (class counts up to 40:
 // exact instances 5 / 13 / 19 / 20 / 21 / 40, run-time-C instances sized 8 / 16 / 24 / 32 / 40).  A translation unit of its own so that the
-// instance sets compile in parallel (see fusion_pair.hip, DESIGN.md 3.0).
+// instance sets compile in parallel (see fusion_pair.hip, DESIGN.md 3.2).
 #include <hip/hip_runtime.h>
 
 #include "common.hpp"
@@ -22,9 +22,9 @@ void smesh_launch_fuse_tri_8(int kind, int tri_ct, dim3 grid, hipStream_t st, co
   // Group pipeline (the default since round 5; SMESH_GROUP_PIPELINE=0 / smesh_set_option turn it off; raster.hip): the rasteriser of the next group runs beside this launch, and the one-wave
   // workgroups of this kernel would take every wave slot that frees up.  An LDS pad caps them at five per CU -- alone the kernel
   // loses 2 % that way (it is bound by the memory system, not by occupancy) -- and leaves the rest of the register file to the
-  // rasteriser's waves.  SMESH_FUSE_LDS_PAD overrides (bytes).
+  // rasteriser's waves (NOTES/round2.md).  SMESH_FUSE_LDS_PAD overrides (bytes).
   static const int pad_env = getenv("SMESH_FUSE_LDS_PAD") ? atoi(getenv("SMESH_FUSE_LDS_PAD")) : -1;
-  const unsigned pad = pad_env >= 0 ? (unsigned)pad_env : (opt_group_pipeline() ? 24576u : 0u);
+  const unsigned pad = pad_env >= 0 ? (unsigned)pad_env : t.lds_pad;      // (decided per launch: smesh_aggregator_fuse_triangles)
   TriViews<8> vn;
   for (int v = 0; v < 8; v++) vn.v[v] = tv.v[v];
 #define SMESH_FTN(K)                                                                                     \

@@ -1,5 +1,5 @@
 // fusion_pair.hip -- the two-views-per-launch instances of the triangle-order fusion kernel (smesh_fuse_views; see fusion.hip and
-// DESIGN.md 3.0).  A translation unit of its own: the 36 instances take as long to compile as the rest of fusion.hip.
+// DESIGN.md 3.2).  A translation unit of its own: the 36 instances take as long to compile as the rest of fusion.hip.
 // (fusion_multi4.hip / fusion_multi8.hip: the four- and eight-view instances for class counts up to 24.)
 #include <hip/hip_runtime.h>
 

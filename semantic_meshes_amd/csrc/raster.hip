@@ -306,7 +306,7 @@ __device__ __forceinline__ bool load_tri(const RasterArgs& a, uint64_t f, Tri& t
   return setup_tri(va, vb, vc, a.W, a.H, t);
 }
 
-// ---- near-plane clipping (round 3; DESIGN.md "Raster spec" 1b; oracle: clip_edge / clip_triangle, operation for operation) --------
+// ---- near-plane clipping (round 3; DESIGN.md "Raster spec" 2; oracle: clip_edge / clip_triangle, operation for operation) --------
 // A triangle with vertices in front of AND at / behind the near plane z_c = kNear is cut along it.  On every edge from a front
 // vertex F to a behind vertex B the point I = F + t (B - F), t = (zF - n) / (zF - zB), is computed in double FROM THE FRONT VERTEX
 // (the two triangles sharing the edge compute the same I: the cut edge F-I stays watertight) and projected with z = n exactly.
@@ -1099,8 +1099,8 @@ struct smesh_renderer {
   uint32_t* tex_first = nullptr;   // [F]
   std::vector<int32_t> h_faces;    // texel renderers: re-ordered faces
   std::vector<uint32_t> h_res, h_first;
-  // What a render leaves behind for the triangle-order fusion.  Two sets: with SMESH_FUSE_PIPELINE the rasteriser of
-  // view k+1 (raster stream) fills one while the fusion of view k (main stream) still reads the other.
+  // What a render leaves behind for the triangle-order fusion: one set per view slot (two banks of eight: the group pipeline
+  // rasterises into one bank while the other is being fused), then the held ones; render_device() rotates over the first six.
   struct Side {
     uint32_t* big_queue = nullptr;   // [big_capacity] triangles with a bounding box > 8 x 8
     uint32_t* big_count = nullptr;   // [0] length of the queue; emptied by the next render's vertex kernel
@@ -1125,8 +1125,6 @@ struct smesh_renderer {
   hipEvent_t ev_raster_done = nullptr;   // main_after_raster()
   uint64_t group_seq = 0;
   bool bank_used[2] = {false, false};
-  hipEvent_t ev_rendered[2] = {nullptr, nullptr};   // raster stream: slot is complete
-  hipEvent_t ev_consumed[2] = {nullptr, nullptr};   // main stream: the fusion kernels have read the slot
   uint64_t fused_seq = 0;
   // the index planes handed out by the last TWO smesh_renderer_render_device() calls (they alternate between the two
   // sets of per-triangle records): last_idx[s] is the plane side[s] still describes, or null
@@ -1430,7 +1428,9 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   ProfScope prof(ctx, SMESH_PROF_RASTER, st);
   hipLaunchKernelGGL(k_project_vertices_group, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, pg);
   SMESH_HIP(hipGetLastError());
-  hipLaunchKernelGGL(k_raster_frag_group, dim3((uint32_t)n * rg.blocks_per_view), dim3(256), 0, st, rg);
+  // (experiment knob: an LDS pad caps the rasteriser's workgroups per CU when it runs beside a fusion launch -- group pipeline)
+  static const unsigned raster_pad = getenv("SMESH_RASTER_LDS_PAD") ? (unsigned)atoi(getenv("SMESH_RASTER_LDS_PAD")) : 0u;
+  hipLaunchKernelGGL(k_raster_frag_group, dim3((uint32_t)n * rg.blocks_per_view), dim3(256), (st == ctx->raster_stream ? raster_pad : 0u), st, rg);
   SMESH_HIP(hipGetLastError());
   bool huge_needed = false;   // (no_huge_possible: a proof that the queue of every view of the group stays empty)
   for (int v = 0; v < n; v++) huge_needed = huge_needed || !no_huge_possible(r, &cams[v]);
@@ -1843,8 +1843,6 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
     if (i == 0 && r->ev_main_fence) (void)hipEventDestroy(r->ev_main_fence);
     if (r->ev_bank_rendered[i]) (void)hipEventDestroy(r->ev_bank_rendered[i]);
     if (r->ev_bank_consumed[i]) (void)hipEventDestroy(r->ev_bank_consumed[i]);
-    if (r->ev_rendered[i]) (void)hipEventDestroy(r->ev_rendered[i]);
-    if (r->ev_consumed[i]) (void)hipEventDestroy(r->ev_consumed[i]);
   }
   delete r;
   return SMESH_OK;
@@ -1934,45 +1932,21 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   SMESH_HIP(hipSetDevice(ctx->device));
   SMESH_TRY(smesh_aggregator_join_exchange(a));   // (rows still being exchanged on the exchange stream: smesh_allreduce_rows)
   const uint64_t W = cam->width, H = cam->height, N = W * H;
-  // Optional two-stage pipeline over two HIP streams (SMESH_FUSE_PIPELINE=1): the rasteriser of this view
-  // runs on the raster stream while the main stream is still fusing the previous view; events hand the index
-  // image over and back (the per-triangle records are double-buffered: side[slot]).  Measured on cfg2 it gains
-  // under 1 %: k_raster_frag stretches from 44 to 82 us while k_fuse_tri runs beside it, and every cross-stream
-  // event costs 10-20 us of latency, so it is off by default (and kernel timings stay clean).
-  static const bool pipelined = getenv("SMESH_FUSE_PIPELINE") && atoi(getenv("SMESH_FUSE_PIPELINE")) != 0;
-  const int slot = pipelined ? (int)(r->fused_seq & 1u) : 0;
-  hipStream_t rst = pipelined ? ctx->raster_stream : ctx->stream;
-  if (pipelined) {
-    for (int i = 0; i < 2; i++) {
-      if (!r->ev_rendered[i]) SMESH_HIP(hipEventCreateWithFlags(&r->ev_rendered[i], hipEventDisableTiming));
-      if (!r->ev_consumed[i]) SMESH_HIP(hipEventCreateWithFlags(&r->ev_consumed[i], hipEventDisableTiming));
-    }
-    if (r->main_pending) {   // a plain render() used the renderer's scratch on the main stream
-      SMESH_HIP(hipStreamSynchronize(ctx->stream));
-      r->main_pending = false;
-    }
-  } else {
-    SMESH_TRY(main_after_raster(r));
-  }
+  // One view: everything on the main stream (the rasteriser of view k + 1 on a second stream beside the fusion of view k was an
+  // opt-in until round 5 -- SMESH_FUSE_PIPELINE, +0.6 % -- and is gone: batches overlap through smesh_fuse_views' group pipeline).
+  const int slot = 0;
+  SMESH_TRY(main_after_raster(r));          // (a pipelined smesh_fuse_views call may still be rasterising into the view slots)
+  r->main_pending = true;                   // the next pipelined group must wait for what this call does to slot 0 on the main stream
   if (r->fused[slot].bytes < N * 8) {
     // growing a slot frees the old buffer: nothing may still be reading it
     SMESH_HIP(hipStreamSynchronize(ctx->raster_stream));
     SMESH_HIP(hipStreamSynchronize(ctx->stream));
     SMESH_TRY(r->fused[slot].reserve(N * 8));
-  } else if (pipelined && r->fused_seq >= 2) {
-    SMESH_HIP(hipStreamWaitEvent(ctx->raster_stream, r->ev_consumed[slot], 0));   // view k-2 has been fused
   }
   uint32_t* d_idx = static_cast<uint32_t*>(r->fused[slot].ptr);
   r->last_idx[slot] = nullptr; r->rec_valid[slot] = false;   // the records of a render_device() on this side are being overwritten
-  if (slot == 1) SMESH_HIP(alloc_side(r, 1));
-  SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, rst, slot));   // the fusion only consumes the index plane
-  if (pipelined) {
-    r->raster_pending = true;
-    SMESH_HIP(hipEventRecord(r->ev_rendered[slot], ctx->raster_stream));
-    SMESH_HIP(hipStreamWaitEvent(ctx->stream, r->ev_rendered[slot], 0));
-  }
+  SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, ctx->stream, slot));   // the fusion only consumes the index plane
   SMESH_TRY(fuse_rendered(r, a, slot, d_idx, probs, weights, memkind, W, H));
-  if (pipelined) SMESH_HIP(hipEventRecord(r->ev_consumed[slot], ctx->stream));
   r->fused_seq++;
   return SMESH_OK;
 }
@@ -2105,6 +2079,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
           rv[v] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[base + j + v].ptr), probs[k],
                                weights ? weights[k] : nullptr, cams[k].width, cams[k].height, 0, 0, true};
           rv[v].no_big = no_big_possible(r, &cams[k]);
+          rv[v].fine = box_extent_bound(r, &cams[k]) <= 48.0;      // (the bound is ~4 x the largest box: cfg2 13 - 33, boxes under 8 pixels; a 250 000-triangle mesh at 1080p 27 - 66, boxes of ~12)
         }
         SMESH_TRY(smesh_aggregator_fuse_triangles(a, r->F, r->prim_id, r->big_capacity, rv, nv));
         j += nv;

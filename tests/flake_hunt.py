@@ -1,4 +1,4 @@
-"""Hunt for the intermittent wrong result of the sharded path (DESIGN.md "One unexplained failure").
+"""Hunt for the intermittent wrong result of the sharded path (NOTES/round4.md "One unexplained failure", NOTES/round5.md 1).
 
 Not collected by pytest (no test_ prefix): run on the GPU box as
 

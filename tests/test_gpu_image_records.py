@@ -519,6 +519,9 @@ def test_add_many_equals_sequential_add_bit_for_bit(sm, oracle, kind, C):
             seq.add(d_img[k], d_probs[k], d_wts[k] if with_w else None)
         many = sm.fusion.MeshAggregator(P, C, kind, 0.5)
         many.add_many(d_img, d_probs, d_wts if with_w else None)
+        if STRIP:      # (the atomic scatter-add: add_many goes image by image, float atomics have no order)
+            assert_fused_close(many.get(), seq.get(), rtol=1e-5)
+            continue
         assert path(sm) == "image-records"
         assert np.array_equal(many.get_raw().view(np.uint32), seq.get_raw().view(np.uint32)), (kind, C, dtype)
         assert np.array_equal(many.get(), seq.get())

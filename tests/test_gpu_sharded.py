@@ -321,7 +321,7 @@ def test_fuse_views_ranged_where_rows_are_not_in_triangle_order(sm):
     from helpers import small_scene
     mesh, cams = small_scene(200, 100, 160, 120, views=3)
     rng = np.random.default_rng(5)
-    shuffled = Mesh(mesh.vertices, mesh.faces[rng.permutation(len(mesh.faces))])     # (the renderer re-orders such a mesh: DESIGN.md 3.2, face order)
+    shuffled = Mesh(mesh.vertices, mesh.faces[rng.permutation(len(mesh.faces))])     # (the renderer re-orders such a mesh: DESIGN.md 2, NOTES/kernels_rounds1-4.md "Face order")
     for n, renderer in enumerate((sm.render.triangles(shuffled), sm.render.texels(mesh, cams, 0.5))):
         P, C = renderer.getPrimitivesNum(), 7
         probs = [synth.device_probs(160, 120, C, synth.probs_seed(4, k), 0.0, 0) for k in range(3)]

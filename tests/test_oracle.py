@@ -22,7 +22,7 @@ def _unrle(vals, lens, shape):
 
 # ---- rasteriser -----------------------------------------------------------------------------------
 def near_plane_scene():
-    """Raster spec B-3 (DESIGN.md 3.3, round 3): triangles that cross the near plane z_c = 1e-6 are CLIPPED against it.
+    """Raster spec B-3 (DESIGN.md 4, round 3): triangles that cross the near plane z_c = 1e-6 are CLIPPED against it.
     Camera at the origin looking down +z; triangle 0 lies in front, triangle 1 (nearer, covering triangle 0) has one vertex
     behind the camera, triangle 2 has a vertex exactly on the camera plane."""
     from semantic_meshes_amd import data
@@ -312,7 +312,7 @@ def test_ka12_mul_aggregator(oracle):
 
 
 def test_mul_spec_against_the_literal_pow_then_log_reading(oracle):
-    """ADVICE r2: the spec'd Mul term w * log_spec(p) (DESIGN.md 3.3 #6) against an INDEPENDENT restatement of the literal reading of
+    """ADVICE r2: the spec'd Mul term w * log_spec(p) (DESIGN.md 4 #7) against an INDEPENDENT restatement of the literal reading of
     Fusion.cu:83-87 -- logf(powf(p, w)), p^w rounded to float32 before the log, libm on both calls.  (i) For probabilities a
     network emits the two agree to 1e-5 on get(); (ii) where p^w underflows float32 (w * ln p < ~-103) the literal form yields
     -inf and eliminates the class for good, the spec'd form keeps a finite term: the one known behavioural difference."""

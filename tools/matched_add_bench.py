@@ -1,5 +1,5 @@
 """add() on device-resident COPIES of renders whose originals were exported (sealed): the content match of
-smesh_aggregator_add_matched with device-resident probs, ms per cfg2 view ("Index images that went through
+smesh_aggregator_add_matched with device-resident probs, ms per cfg2 view (NOTES/round2.md, "Index images that went through
 another framework").  Compared with the untouched render (add_rendered) and with matching off (scatter-add)."""
 import os
 import sys

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(64) void k_rows(float* __restrict__ acc, uint64_t r
 //   stride = 0: row index = a hash of (wave, step) -- no locality at all
 //   stride > 0: wave w reads rows (w * stride + step) mod rows: neighbouring waves read rows `stride` apart (an image column apart)
 template <int INFLIGHT>
-__global__ __launch_bounds__(64) void k_gather_rows(const float* __restrict__ buf, uint64_t rows, int C, uint32_t steps, uint64_t stride, float* sink) {
+__global__ __launch_bounds__(64) void k_gather_rows(const float* __restrict__ buf, uint64_t rows, int C, uint32_t steps, uint64_t stride, float* sink,
+                                                    int row_floats) {
   const int l = threadIdx.x;
   const int c = 4 * l;
   float s = 0.f;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(64) void k_gather_rows(const float* __restrict__ bu
         r = h % rows;
       }
       v[b] = fvec4{0.f, 0.f, 0.f, 0.f};
-      if (c + 4 <= C) v[b] = *reinterpret_cast<const fvec4_a4*>(buf + r * C + c);
+      if (c + 4 <= C) v[b] = *reinterpret_cast<const fvec4_a4*>(buf + r * (uint64_t)row_floats + c);
     }
 #pragma unroll
     for (int b = 0; b < INFLIGHT; b++) s += v[b].x + v[b].y + v[b].z + v[b].w;
@@ -89,9 +90,15 @@ int gather_main() {
     const uint32_t waves = 312500, steps = 96;            // ~ the waves of a cfg5 launch, ~ the rows a wave reads in it
     for (uint64_t stride : {0ull, 2160ull, 1ull}) {
       const double total = (double)waves * steps * 600.0;
-      const float t2 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<2>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink); }, 3);
-      const float t4 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<4>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink); }, 3);
-      const float t8 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<8>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink); }, 3);
+      const float t2 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<2>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink, 150); }, 3);
+      const float t4 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<4>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink, 150); }, 3);
+      const float t8 = timeit([&] { hipLaunchKernelGGL(k_gather_rows<8>, dim3(waves), dim3(64), 0, 0, buf, rows, 150, steps, stride, sink, 150); }, 3);
+      if (stride == 0) {   // the same 600 bytes read from rows padded to 640 bytes (five whole 128-byte lines, aligned): what padding the accumulator rows would buy
+        const uint64_t prow = bytes / 640;
+        const float tp = timeit([&] { hipLaunchKernelGGL(k_gather_rows<4>, dim3(waves), dim3(64), 0, 0, buf, prow, 150, steps, stride, sink, 160); }, 3);
+        printf("   ... 600 of 640-byte rows at 128-byte alignment, 4 in flight: %6.2f TB/s useful (%6.2f TB/s of whole lines)\n",
+               total / 1e12 / (tp * 1e-3), total * 640.0 / 600.0 / 1e12 / (tp * 1e-3));
+      }
       printf("gather of 600-B rows, footprint %2llu GB, %s: 2 in flight %6.2f TB/s   4 in flight %6.2f TB/s   8 in flight %6.2f TB/s   (%.1f GB read)\n",
              (unsigned long long)gb, stride == 0 ? "hashed positions      " : stride == 1 ? "consecutive rows      " : "rows 2160 apart (x+1) ",
              total / 1e12 / (t2 * 1e-3), total / 1e12 / (t4 * 1e-3), total / 1e12 / (t8 * 1e-3), total / 1e9);
