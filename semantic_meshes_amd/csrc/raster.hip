@@ -601,57 +601,35 @@ __device__ __forceinline__ Claim4 wave_claim_prepare4(uint32_t T0, uint32_t n01,
   return c;
 }
 
-// One lane per triangle (bounding box <= 8 x 8; larger ones: see the end of the kernel): coverage walk, slot
-// reservation in the (at most 2 x 2) tiles the box overlaps, then depth per covered sample and the queue stores.
-// The edge functions are shade()'s, expression for expression.
-// `f`: this lane's triangle (a.F: none; ANY triangle: lanes need not hold consecutive ones), `i0 .. i2` its vertex indices (valid
-// when f < a.F); `sub`: the wave's sub-queue in every tile.
-__device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64_t f, const int32_t i0, const int32_t i1, const int32_t i2,
-                                               const uint32_t sub) {
-  const int lane = threadIdx.x & 63;
-  TriFrag rec;
-  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
-  Tri t;
-  t.x0 = 0; t.y0 = 0;
+// Coverage of the (at most 8 x 8) box at (X0, Y0), bw x bh samples, by triangle t: bit dx * 8 + dy per covered sample.  One flattened
+// loop (trip count bw * bh, not max bw x max bh over the wave's lanes).  The edge functions are shade()'s, expression for expression.
+__device__ __forceinline__ unsigned long long walk_box(const Tri& t, const int X0, const int Y0, const int bw, const int bh) {
   unsigned long long cover = 0ull;
-  bool medium = false;
-  const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // value written to the index image
-  const int have = f < a.F ? load_tri_ex(a, f, t, i0, i1, i2) : 0;   // 2: crosses the near plane (t holds only its screen box)
-  if (have) {
-    const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
-    rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
-    if (bw > 8 || bh > 8 || have == 2) {
-      const uint32_t slot = atomicAdd(a.big_count, 1u);          // every such triangle: the fusion walks this queue
-      if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
-      push_mid(a, f, bw * bh);
-      rec.kind = 2;
-      rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
-      if (bw <= kMedium && bh <= kMedium && have == 1) medium = true;   // rasterised below by the whole wave
-      else {                                                     // rasterised by the tile workgroups it overlaps
-        const uint32_t hs = atomicAdd(a.big_count + 2, 1u);
-        if (hs < a.big_capacity) a.huge_queue[hs] = (uint32_t)f;
-      }
-    } else if (!(SMESH_ABL(a.dbg) & 2)) {
-      // one flattened loop over the box (trip count bw * bh, not max bw x max bh over the wave's lanes)
-      const int area = bw * bh;
-      int dx = 0, dy = 0;
-      const double py0 = (double)t.y0 + 0.5;
-      double px = (double)t.x0 + 0.5, py = py0;   // advanced by exact steps of 1.0
-      for (int k = 0; k < area; k++) {
-        const double w0 = eval_edge(t.e0, px, py);
-        const double w1 = eval_edge(t.e1, px, py);
-        const double w2 = eval_edge(t.e2, px, py);
-        const bool in = edge_accepts(w0, t.cls0) && edge_accepts(w1, t.cls1) && edge_accepts(w2, t.cls2);
-        if (in) cover |= 1ull << (dx * 8 + dy);
-        py += 1.0;
-        if (++dy == bh) { dy = 0; dx++; py = py0; px += 1.0; }
-      }
-    }
+  const int area = bw * bh;
+  int dx = 0, dy = 0;
+  const double py0 = (double)Y0 + 0.5;
+  double px = (double)X0 + 0.5, py = py0;   // advanced by exact steps of 1.0
+  for (int k = 0; k < area; k++) {
+    const double w0 = eval_edge(t.e0, px, py);
+    const double w1 = eval_edge(t.e1, px, py);
+    const double w2 = eval_edge(t.e2, px, py);
+    const bool in = edge_accepts(w0, t.cls0) && edge_accepts(w1, t.cls1) && edge_accepts(w2, t.cls2);
+    if (in) cover |= 1ull << (dx * 8 + dy);
+    py += 1.0;
+    if (++dy == bh) { dy = 0; dx++; py = py0; px += 1.0; }
   }
-  if (SMESH_ABL(a.dbg) & 4) { if (a.frags && f < a.F) { rec.mask = cover; a.frags[f] = rec; } return; }   // ablation: setup + coverage only
+  return cover;
+}
+
+// The covered samples `cover` (bit dx * 8 + dy) of the 8 x 8 box at (X0, Y0) go to the fragment queues: slot reservation in the (at
+// most 2 x 2) tiles the box overlaps -- lanes grouped by their first tile, ONE atomic per (wave, tile) -- then depth per covered
+// sample and the stores.  WHOLE WAVE must call (lanes without samples pass cover = 0).  Returns the mask of the samples that got a key.
+__device__ __forceinline__ unsigned long long emit_cover(const RasterArgs& a, const Tri& t, const uint64_t f, const uint32_t pid,
+                                                         const int X0, const int Y0, unsigned long long cover, const uint32_t sub) {
+  const int lane = threadIdx.x & 63;
   // split the box at the tile borders: columns dx < bx / rows dy < by belong to tile (tx0, ty0)
-  const uint32_t tx0 = (uint32_t)t.x0 / kQW, ty0 = (uint32_t)t.y0 / kQH;
-  const int bx = (int)(tx0 + 1) * kQW - t.x0, by = (int)(ty0 + 1) * kQH - t.y0;
+  const uint32_t tx0 = (uint32_t)X0 / kQW, ty0 = (uint32_t)Y0 / kQH;
+  const int bx = (int)(tx0 + 1) * kQW - X0, by = (int)(ty0 + 1) * kQH - Y0;
   const unsigned long long lox = bx >= 8 ? ~0ull : ((1ull << (8 * bx)) - 1ull);
   const unsigned long long loy = by >= 8 ? ~0ull : (0x0101010101010101ull * ((1ull << by) - 1ull));
   const uint32_t T0 = tx0 * a.q.tiles_y + ty0;
@@ -680,7 +658,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   for (unsigned long long m = cover; m; m &= m - 1ull) {
     const int bit = __ffsll((long long)m) - 1;
     const int dx = bit >> 3, dy = bit & 7;
-    const int x = t.x0 + dx, y = t.y0 + dy;
+    const int x = X0 + dx, y = Y0 + dy;
     const double px = (double)x + 0.5, py = (double)y + 0.5;
     const double w0 = eval_edge(t.e0, px, py);
     const double w1 = eval_edge(t.e1, px, py);
@@ -711,9 +689,71 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
       atomicOr(&a.q.flag[(tx0 + (hx ? 1u : 0u)) * a.q.tiles_y + ty0 + (hy ? 1u : 0u)], 1u);
     }
   }
-  if (mask) rec.kind = 1;
-  if (rec.kind == 1) rec.mask = mask;
-  if (a.frags && f < a.F) a.frags[f] = rec;
+  return mask;
+}
+
+// One lane per triangle.  Box <= 8 x 8: coverage walk (walk_box) and the fragments (emit_cover), and the record's mask.  Box up to
+// kLaneBox x kLaneBox (round 5): the SAME lane walks the box as up to (kLaneBox / 8)^2 sub-boxes of 8 x 8, one per wave-uniform round
+// -- its set-up stays in registers, every round is the small-triangle procedure, and only covered samples reach the queues.  (Until
+// round 5 every box over 8 x 8 went through the cooperative loop below: one triangle at a time per wave, ~100 instructions per 64
+// samples plus ~40 to broadcast the triangle, null keys for the uncovered samples -- a mesh of ~20-pixel triangles spent 41 us per
+// 1080p view there.)  Larger boxes, up to kMedium x kMedium: the cooperative loop.
+// `f`: this lane's triangle (a.F: none; ANY triangle: lanes need not hold consecutive ones), `i0 .. i2` its vertex indices (valid
+// when f < a.F); `sub`: the wave's sub-queue in every tile.
+constexpr int kLaneBox = 24;
+constexpr int kLaneBoxMin = 20;
+__device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64_t f, const int32_t i0, const int32_t i1, const int32_t i2,
+                                               const uint32_t sub) {
+  const int lane = threadIdx.x & 63;
+  TriFrag rec;
+  rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
+  Tri t;
+  t.x0 = 0; t.y0 = 0; t.x1 = -1; t.y1 = -1;
+  unsigned long long cover = 0ull;
+  bool medium = false, lanebox = false;
+  const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // value written to the index image
+  const int have = f < a.F ? load_tri_ex(a, f, t, i0, i1, i2) : 0;   // 2: crosses the near plane (t holds only its screen box)
+  if (have) {
+    const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
+    rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
+    if (bw > 8 || bh > 8 || have == 2) {
+      const uint32_t slot = atomicAdd(a.big_count, 1u);          // every such triangle: the fusion walks this queue
+      if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
+      push_mid(a, f, bw * bh);
+      rec.kind = 2;
+      rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
+      if (bw <= kLaneBox && bh <= kLaneBox && have == 1) lanebox = true;     // rasterised below by this lane, sub-box by sub-box
+      else if (bw <= kMedium && bh <= kMedium && have == 1) medium = true;   // rasterised below by the whole wave
+      else {                                                     // rasterised by the tile workgroups it overlaps
+        const uint32_t hs = atomicAdd(a.big_count + 2, 1u);
+        if (hs < a.big_capacity) a.huge_queue[hs] = (uint32_t)f;
+      }
+    } else if (!(SMESH_ABL(a.dbg) & 2)) {
+      cover = walk_box(t, t.x0, t.y0, bw, bh);
+    }
+  }
+  if (SMESH_ABL(a.dbg) & 4) { if (a.frags && f < a.F) { rec.mask = cover; a.frags[f] = rec; } return; }   // ablation: setup + coverage only
+  {
+    const unsigned long long mask = emit_cover(a, t, f, pid, t.x0, t.y0, cover, sub);
+    if (mask) rec.kind = 1;
+    if (rec.kind == 1) rec.mask = mask;
+    if (a.frags && f < a.F) a.frags[f] = rec;
+  }
+  // ---- boxes over 8 x 8 up to kLaneBox x kLaneBox: this lane's sub-boxes, one per round (wave-uniform trip count) -- where the wave
+  // holds enough of them: a round costs what a whole small-triangle pass costs (~2 200 instructions) however many lanes take part,
+  // the cooperative loop ~350 - 450 per triangle, so a wave with fewer than kLaneBoxMin such triangles hands them to that loop
+  if ((int)__popcll(__ballot(lanebox)) < kLaneBoxMin) { medium = medium || lanebox; lanebox = false; }
+  if (__ballot(lanebox) != 0ull && !(SMESH_ABL(a.dbg) & 1)) {
+    constexpr int kSub = kLaneBox / 8;
+    for (int k = 0; k < kSub * kSub; k++) {
+      const int X0 = t.x0 + 8 * (k / kSub), Y0 = t.y0 + 8 * (k % kSub);
+      const int bw = lanebox ? min(t.x1 - X0 + 1, 8) : 0, bh = lanebox ? min(t.y1 - Y0 + 1, 8) : 0;
+      const bool on = bw > 0 && bh > 0;
+      if (__ballot(on) == 0ull) continue;
+      const unsigned long long cv = on ? walk_box(t, X0, Y0, bw, bh) : 0ull;
+      (void)emit_cover(a, t, f, pid, on ? X0 : 0, on ? Y0 : 0, cv, sub);
+    }
+  }
 
   // ---- medium triangles (box up to kMedium x kMedium): one at a time, all 64 lanes on its bounding box.  The
   // triangle is broadcast from its owner lane (readlane -> scalar registers).  Queue slots: the box overlaps at most
@@ -941,6 +981,7 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
 #pragma unroll
   for (uint32_t k = 0; k < kSpec; k++)
     if (sq_lane + k * kGroup < n) atomicMin(&skeys[spec_pix[k]], spec_key[k]);
+  // (skipping the null keys of the cooperative loop's sub-rectangles here was measured slower: 10 000 triangles 0.083 -> 0.090 ms per view)
   for (uint32_t i = sq_lane + kSpec * kGroup; i < n; i += kGroup) atomicMin(&skeys[q.pix[qbase + i]], q.key[qbase + i]);
   __syncthreads();
   // The depth test is decided: tell the triangle-order fusion which fragments of the small triangles LOST it, by clearing their
@@ -1262,7 +1303,7 @@ CameraArgs camera_args(const smesh_camera_t* cam) {
 }
 
 // Kernel arguments of a render of a W x H view with scratch set `vs`, leaving its records in side `side` (queues: a.q).
-RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int side, uint64_t W, uint64_t H) {
+RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int side, uint64_t W, uint64_t H, int nviews = 1) {
   RasterArgs a;
   a.faces = r->faces; a.verts = r->verts; a.sv = vs.sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
   a.prim_id = r->prim_id;
@@ -1273,8 +1314,15 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   { static const int rdbg = SMESH_ABL_ENV("SMESH_RDBG"); a.dbg = rdbg; }
   a.q = FragQueues();
   a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~kMinWaves waves
-  static const uint64_t min_waves = getenv("SMESH_RASTER_MIN_WAVES") ? (uint64_t)std::max(1, atoi(getenv("SMESH_RASTER_MIN_WAVES"))) : 2048u;
-  while (a.tpw > 1 && r->F / a.tpw < min_waves) a.tpw >>= 1;
+  // Meshes of 32 768 triangles and more count the waves of the whole launch (`nviews` views) and are content with 1 024 of them: their
+  // boxes over 8 x 8 are mostly the ones a lane walks itself, sub-box by sub-box (raster_frag_64), and a round of that costs the same
+  // for 16 lanes as for 64 -- 1080p, fuse_views, ms per view: 90 000 triangles 0.086 -> 0.077, 40 000 triangles 0.100 -> 0.081.
+  // Coarser meshes need the waves for the cooperative loop (10 000 triangles: 0.084 with 2 048 waves per view, 0.091 with 1 024).
+  static const uint64_t min_waves_env = getenv("SMESH_RASTER_MIN_WAVES") ? (uint64_t)std::max(1, atoi(getenv("SMESH_RASTER_MIN_WAVES"))) : 0u;
+  const bool fine = r->F >= 32768u;
+  const uint64_t min_waves = min_waves_env ? min_waves_env : (fine ? 1024u : 2048u);
+  const uint64_t launch_views = fine ? (uint64_t)std::max(1, nviews) : 1u;
+  while (a.tpw > 1 && launch_views * r->F / a.tpw < min_waves) a.tpw >>= 1;
   a.groups = 1;  // (frag_groups() decides per launch)
   return a;
 }
@@ -1413,7 +1461,7 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     pg.cam[v] = camera_args(&cams[v]);
     pg.sv[v] = vs.sv;
     pg.big_count[v] = r->side[side_base + v].big_count;
-    rg.view[v] = raster_args(r, vs, side_base + v, W, H);
+    rg.view[v] = raster_args(r, vs, side_base + v, W, H, n);
     rg.view[v].cam = pg.cam[v];
     rg.view[v].q = vs.fq;
     rg.idx[v] = static_cast<uint32_t*>(r->fused[side_base + v].ptr);
