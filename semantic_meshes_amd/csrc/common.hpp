@@ -165,6 +165,7 @@ struct TriView {
   const uint32_t* big_len;    // [0] queue length, [1] "check the masks against the index plane" flag of the render
   uint32_t W, H;
   uint32_t ps0, ps1;          // k_fuse_tri only: element strides of x and y of `probs` (dense: H * C and C; a (H,W,C) tensor seen as (W,H,C): C and W * C)
+  const uint8_t* kinds;       // k_fuse_texel_multi only: TriFrag::kind of every triangle, a byte each (null: read the records)
 };
 template <int NV>
 struct TriViews {
@@ -183,6 +184,7 @@ struct RenderedView {
   int64_t ps0 = 0, ps1 = 0;     // element strides of x and y of `probs` when it is not the dense (W,H,C) image (class stride 1); 0, 0: dense
   bool mid_queue = false;       // big_queue[big_capacity ...] lists the medium triangles of this view, big_len[3] of them (the rasteriser's renders)
   bool no_big = false;          // PROVEN on the host (raster.hip no_big_possible): no triangle of this view has a box over 8 x 8 pixels -- big_queue is empty
+  const uint8_t* kinds = nullptr;   // texel renderers: TriFrag::kind of every triangle again, a byte each (RasterArgs::kinds)
   bool fine = false;            // bounded on the host (raster.hip box_extent_bound <= 48 pixels): a finely tessellated mesh seen from outside -- few or no queued triangles
 };
 

@@ -1574,6 +1574,7 @@ template <int KIND>
 __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a, TriViews<8> vw, int nv) {
   __shared__ TriView s_view[8];
   __shared__ uint32_t s_tri[kTexelBlock];
+  __shared__ uint8_t s_in[kTexelBlock];      // bit v: the triangle emitted fragments in view v
   __shared__ uint32_t s_wave_count[kTexelBlock / kWave];
   const uint32_t C = a.C;
   const int t = threadIdx.x, l = t & (kWave - 1), wv = t / kWave;
@@ -1589,12 +1590,15 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a,
   // loads for the seven triangles out of eight that no view sees), again after the compaction, and so is each view's first
   // candidate pixel.
   bool seen = false;
+  uint32_t in_views = 0u;
   {
     uint16_t kind[8];
 #pragma unroll
-    for (int v = 0; v < 8; v++) kind[v] = (v < nv && f < a.F) ? s_view[v].frags[f].kind : (uint16_t)0;
+    for (int v = 0; v < 8; v++)   // (a byte per triangle where the renderer left them: seven triangles in eight emitted nothing at cfg4)
+      kind[v] = (v < nv && f < a.F) ? (s_view[v].kinds ? (uint16_t)s_view[v].kinds[f] : s_view[v].frags[f].kind) : (uint16_t)0;
 #pragma unroll
-    for (int v = 0; v < 8; v++) seen = seen || kind[v] == 1;
+    for (int v = 0; v < 8; v++) in_views |= kind[v] == 1 ? 1u << v : 0u;
+    seen = in_views != 0u;
   }
   const unsigned long long ballot = __ballot(seen);
   if (l == 0) s_wave_count[wv] = (uint32_t)__popcll(ballot);
@@ -1606,20 +1610,25 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel_multi(TriFuseArgs a,
     if (w < wv) base += c;
     total += c;
   }
-  if (seen) s_tri[base + (uint32_t)__popcll(ballot & ((1ull << l) - 1ull))] = (uint32_t)f;
+  if (seen) {
+    const uint32_t slot = base + (uint32_t)__popcll(ballot & ((1ull << l) - 1ull));
+    s_tri[slot] = (uint32_t)f;
+    s_in[slot] = (uint8_t)in_views;
+  }
   __syncthreads();
   if ((uint32_t)t >= total) return;
   const uint32_t g = s_tri[t];
+  in_views = s_in[t];       // (a triangle seen at all is seen in one or two of the eight views at cfg4: only those records are read)
   // this triangle in all views: box origin, mask of emitted fragments, and the index under the first of them -- all in flight together
   uint32_t org[8], t0[8];
   unsigned long long msk[8];
 #pragma unroll
   for (int v = 0; v < 8; v++) {
     org[v] = 0u; msk[v] = 0ull;
-    if (v < nv) {
+    if (in_views >> v & 1u) {
       const TriFrag rec = s_view[v].frags[g];
       org[v] = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
-      msk[v] = rec.kind == 1 ? rec.mask : 0ull;
+      msk[v] = rec.mask;
     }
   }
   const uint32_t first = a.tex_first[g], res = a.tex_res[g], cnt = res * (res + 1u) / 2u;
@@ -2530,7 +2539,7 @@ int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const ui
   TriViews<8> tv;
   for (int v = 0; v < 8; v++) {
     const RenderedView& rv = views[v < nviews ? v : 0];
-    tv.v[v] = TriView{rv.frags, rv.idx, rv.probs, rv.weights, rv.big_queue, rv.big_len, (uint32_t)rv.W, (uint32_t)rv.H};
+    tv.v[v] = TriView{rv.frags, rv.idx, rv.probs, rv.weights, rv.big_queue, rv.big_len, (uint32_t)rv.W, (uint32_t)rv.H, 0u, 0u, rv.kinds};
   }
   TriFuseArgs t;
   t.frags = views[0].frags; t.idx = views[0].idx; t.probs = views[0].probs; t.weights = views[0].weights;

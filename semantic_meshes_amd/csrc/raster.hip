@@ -281,6 +281,8 @@ struct RasterArgs {
                               //     records still hold fragments that lost the depth test (the fusion must check them)
   uint32_t big_capacity;
   TriFrag* frags;             // per-triangle fragment records for the triangle-order fusion (may be null)
+  uint8_t* kinds;             // texel renderers: the records' `kind` again, a byte per triangle (k_fuse_texel_multi reads these instead of
+                              // sixteen bytes per triangle and view to find the one triangle in eight that emitted anything); else null
   FragQueues q;               // fragment-queue path only
   uint32_t tpw;               // k_raster_frag: triangles per group of a wave (power of two <= 64)
   uint32_t groups;            // k_raster_frag: groups per wave (1; 2 with tpw = 64 when the launch has waves to spare)
@@ -522,6 +524,7 @@ __global__ void k_raster_small(RasterArgs a) {
     }
   }
   if (a.frags) a.frags[f] = rec;
+  if (a.kinds) a.kinds[f] = (uint8_t)rec.kind;
 }
 
 // One workgroup per (queued triangle, 64x64 pixel chunk of its bounding box); lanes run down columns.
@@ -738,6 +741,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
     if (mask) rec.kind = 1;
     if (rec.kind == 1) rec.mask = mask;
     if (a.frags && f < a.F) a.frags[f] = rec;
+    if (a.kinds && f < a.F) a.kinds[f] = (uint8_t)rec.kind;
   }
   // ---- boxes over 8 x 8 up to kLaneBox x kLaneBox: this lane's sub-boxes, one per round (wave-uniform trip count) -- where the wave
   // holds enough of them: a round costs what a whole small-triangle pass costs (~2 200 instructions) however many lanes take part,
@@ -831,11 +835,6 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   }
 }
 
-// One wave = a.groups x a.tpw consecutive triangles (tpw: 64 for large meshes; fewer for small ones, so that the cooperative
-// medium-triangle loop has enough waves to spread over the chip).  With several groups per wave (LOOP: the grouped launches of
-// meshes of millions of triangles) the next group's vertex indices are requested before the current group is shaded (three
-// registers), so that it starts one memory round trip ahead: cfg4 666 -> 627 us per eight-view launch with four groups; nothing at
-// cfg2 (169 / 171 / 175 / 182 us with 1 / 2 / 4 / 8 groups, tools/raster_groups.sh), where one group per wave stays.
 // One wave = a.groups x a.tpw consecutive triangles (tpw: 64 for large meshes; fewer for small ones, so that the cooperative
 // medium-triangle loop has enough waves to spread over the chip).  With several groups per wave (LOOP: the grouped launches of
 // meshes of millions of triangles) the next group's vertex indices are requested before the current group is shaded (three
@@ -1146,6 +1145,7 @@ struct smesh_renderer {
     uint32_t* big_queue = nullptr;   // [big_capacity] triangles with a bounding box > 8 x 8
     uint32_t* big_count = nullptr;   // [0] length of the queue; emptied by the next render's vertex kernel
     TriFrag* frags = nullptr;        // [F] per-triangle fragment records
+    uint8_t* kinds = nullptr;        // [F] texel renderers: TriFrag::kind, a byte per triangle
   } side[kSides];
   uint32_t big_capacity = 0;
   std::vector<ImagePair> images;   // pooled output planes
@@ -1311,6 +1311,7 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
   a.huge_queue = vs.huge_queue;
   a.frags = r->side[side].frags;
+  a.kinds = r->side[side].kinds;
   { static const int rdbg = SMESH_ABL_ENV("SMESH_RDBG"); a.dbg = rdbg; }
   a.q = FragQueues();
   a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~kMinWaves waves
@@ -1528,6 +1529,7 @@ hipError_t alloc_side(smesh_renderer* r, int i) {
   hipError_t e = dev_malloc(reinterpret_cast<void**>(&sd.big_queue), (size_t)r->big_capacity * 8);   // (upper half: the medium triangles again, push_mid)
   if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&sd.big_count), 16);
   if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&sd.frags), std::max<uint64_t>(r->F * sizeof(TriFrag), 16));
+  if (e == hipSuccess && r->texels) e = dev_malloc(reinterpret_cast<void**>(&sd.kinds), std::max<uint64_t>(r->F, 16));
   if (e == hipSuccess) e = hipMemsetAsync(sd.big_count, 0, 16, r->ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(r->ctx->stream);
   return e;
@@ -1875,7 +1877,7 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
   for (void* p : {(void*)r->prim_id, (void*)r->verts, (void*)r->faces, (void*)r->tex_res, (void*)r->tex_first})
     if (p) (void)dev_free(p);
   for (auto& sd : r->side)
-    for (void* p : {(void*)sd.big_queue, (void*)sd.big_count, (void*)sd.frags})
+    for (void* p : {(void*)sd.big_queue, (void*)sd.big_count, (void*)sd.frags, (void*)sd.kinds})
       if (p) (void)dev_free(p);
   for (auto& vs : r->vs)
     for (void* p : {(void*)vs.sv, (void*)vs.huge_queue, (void*)vs.keys, (void*)vs.fq.key, (void*)vs.fq.pix, (void*)vs.fq.count, (void*)vs.fq.flag})
@@ -2102,6 +2104,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
         rv[j] = RenderedView{sd.frags, sd.big_queue, sd.big_count, static_cast<const uint32_t*>(r->fused[base + j].ptr), probs[k],
                              weights ? weights[k] : nullptr, cams[k].width, cams[k].height};
         rv[j].no_big = no_big_possible(r, &cams[k]);
+        rv[j].kinds = sd.kinds;
       }
       SMESH_TRY(smesh_aggregator_fuse_texels_multi(a, r->F, r->tex_first, r->tex_res, r->big_capacity, rv, gn));
       smesh_note_fuse("k_fuse_texel", "render-records");

@@ -80,6 +80,87 @@ template <typename F> float timeit(F f, int reps = 5) {
   CK(hipEventRecord(a)); for (int i = 0; i < reps; i++) f(); CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b)); return ms / reps;
 }
+// Per-LANE rows of 160 bytes (C = 40: ten 16-byte loads of one lane) at hashed positions of a large buffer, read (the class vector of a
+// visible pixel) or read-modify-written (the texel's accumulator row): what k_fuse_texel_multi does at cfg4 / cfg4t -- every visible
+// pixel costs one such read and one such read-modify-write, 4.8 GB of accumulator at cfg4t.
+template <bool RMW>
+__global__ __launch_bounds__(256) void k_lane_rows(float* __restrict__ buf, uint64_t rows, uint32_t steps, float* sink) {
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  float s = 0.f;
+  for (uint32_t st = 0; st < steps; st++) {
+    uint64_t h = (id * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)st * 0xBF58476D1CE4E5B9ull);
+    h ^= h >> 29; h *= 0x94D049BB133111EBull; h ^= h >> 32;
+    float4* row = reinterpret_cast<float4*>(buf + (h % rows) * 40);
+    float4 v[10];
+#pragma unroll
+    for (int k = 0; k < 10; k++) v[k] = row[k];
+#pragma unroll
+    for (int k = 0; k < 10; k++) {
+      s += v[k].x + v[k].w;
+      if (RMW) { v[k].x += 1.f; v[k].y += 1.f; v[k].z += 1.f; v[k].w += 1.f; row[k] = v[k]; }
+    }
+  }
+  if (s == 123.456f) *sink = s;
+}
+// cfg4t's own pattern: the accumulator rows of the visible texels in ASCENDING order, one row in `stride` touched (672 102 visible
+// pixels of a view among 64 M texel rows: one in 96; eight views of a launch: one in 12), beside one 160-byte row per lane gathered
+// from hashed positions of a 200 MB class-vector image (`img`, or none).
+__global__ __launch_bounds__(256) void k_lane_rows_sparse(float* __restrict__ buf, uint32_t stride, const float* __restrict__ img, uint32_t img_rows,
+                                                          uint64_t lanes, float* sink) {
+  const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= lanes) return;
+  uint64_t h = id * 0x9E3779B97F4A7C15ull;
+  h ^= h >> 29; h *= 0x94D049BB133111EBull; h ^= h >> 32;
+  float4* row = reinterpret_cast<float4*>(buf + (id * stride + h % stride) * 40);
+  float4 v[10], p[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) v[k] = row[k];
+  if (img) {
+    const float4* pr = reinterpret_cast<const float4*>(img + ((h >> 20) % img_rows) * 40);
+#pragma unroll
+    for (int k = 0; k < 10; k++) p[k] = pr[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 10; k++) p[k] = make_float4(1.f, 1.f, 1.f, 1.f);
+  }
+#pragma unroll
+  for (int k = 0; k < 10; k++) { v[k].x += p[k].x; v[k].y += p[k].y; v[k].z += p[k].z; v[k].w += p[k].w; row[k] = v[k]; }
+}
+int lane_main() {
+  float* sink; CK(hipMalloc(&sink, 4));
+  {
+    const uint64_t rows = 64268767, bytes = rows * 160;
+    float *buf, *img; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 0, bytes));
+    const uint32_t img_rows = 1296 * 968;
+    CK(hipMalloc(&img, (size_t)img_rows * 160)); CK(hipMemset(img, 0, (size_t)img_rows * 160));
+    for (uint32_t stride : {96u, 12u, 4u, 1u}) {
+      const uint64_t lanes = rows / stride;
+      for (int with_img = 0; with_img < 2; with_img++) {
+        const float t = timeit([&] { hipLaunchKernelGGL(k_lane_rows_sparse, dim3((lanes + 255) / 256), dim3(256), 0, 0, buf, stride,
+                                                        with_img ? img : (const float*)nullptr, img_rows, lanes, sink); }, 10);
+        printf("ascending 160-B accumulator rows, one in %2u of 64 M read-modify-written%s: %6.1f us for %8llu rows = %5.2f G rows/s, %5.2f TB/s useful\n",
+               stride, with_img ? " + a hashed 160-B row of a 200 MB image read" : "                                            ", t * 1e3,
+               (unsigned long long)lanes, lanes / 1e9 / (t * 1e-3), lanes * (with_img ? 480.0 : 320.0) / 1e12 / (t * 1e-3));
+      }
+    }
+    CK(hipFree(buf)); CK(hipFree(img));
+  }
+  for (uint64_t mb : {800ull, 4800ull, 20000ull}) {       // cfg4's accumulator, cfg4t's, four 5 GB images beside it
+    const uint64_t bytes = mb << 20;
+    float* buf; CK(hipMalloc(&buf, bytes)); CK(hipMemset(buf, 0, bytes));
+    const uint64_t rows = bytes / 160;
+    const uint32_t lanes = 5000000, steps = 4;
+    const double total = (double)lanes * steps * 160.0;
+    const float tr = timeit([&] { hipLaunchKernelGGL(k_lane_rows<false>, dim3(lanes / 256), dim3(256), 0, 0, buf, rows, steps, sink); }, 5);
+    const float tw = timeit([&] { hipLaunchKernelGGL(k_lane_rows<true>, dim3(lanes / 256), dim3(256), 0, 0, buf, rows, steps, sink); }, 5);
+    printf("per-lane 160-B rows at hashed positions, footprint %5llu MB: read %5.2f TB/s (%.1f G rows/s)   read-modify-write %5.2f TB/s r+w (%.1f G rows/s)\n",
+           (unsigned long long)mb, total / 1e12 / (tr * 1e-3), lanes * (double)steps / 1e9 / (tr * 1e-3), 2.0 * total / 1e12 / (tw * 1e-3),
+           lanes * (double)steps / 1e9 / (tw * 1e-3));
+    CK(hipFree(buf));
+  }
+  return 0;
+}
+
 int gather_main() {
   // scattered 600-byte rows: footprint 12 GB and 42 GB (eight cfg5 images), 2 / 4 / 8 rows in flight per wave, 8 waves per SIMD worth of workgroups
   float* sink; CK(hipMalloc(&sink, 4));
@@ -110,6 +191,7 @@ int gather_main() {
 
 int main(int argc, char** argv) {
   if (argc > 1 && argv[1][0] == 'g') return gather_main();
+  if (argc > 1 && argv[1][0] == 'l') return lane_main();
   const uint64_t maxb = 12ull << 30;
   float* buf; CK(hipMalloc(&buf, maxb)); CK(hipMemset(buf, 0, maxb));
   float* sink; CK(hipMalloc(&sink, 4));
