@@ -288,3 +288,81 @@ def test_random_room_against_oracle(sm, oracle, seed):
         assert_fused_close(grouped.get(), want, rtol=1e-5, atol=1e-6)
     finally:
         oracle.set_accum_double(False)
+
+
+def _relief_mesh(rng, a, b):
+    """A jittered height field of 2 * a * b triangles (shared vertices: watertight edges), some of it folded over itself."""
+    from semantic_meshes_amd import synth
+    mesh = synth.grid_mesh(a, b, relief=float(rng.choice([0.15, 0.6, 2.0])))
+    v = mesh.vertices.copy()
+    s = 10.0 / a
+    v[:, :2] += rng.normal(0.0, 0.3 * s, (len(v), 2)).astype(np.float32)      # irregular triangles, some slivers
+    v[:, 2] += rng.normal(0.0, float(rng.choice([0.0, 0.5, 3.0])) * s, len(v)).astype(np.float32)
+    return v.astype(np.float32), mesh.faces.copy()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_dense_mesh_of_medium_triangles_against_oracle(sm, oracle, seed):
+    """Meshes of 33 000 - 100 000 triangles whose boxes are mostly 9 - 24 pixels wide (the decimated-scan regime,
+    eval-scannet/simplify_scannet_meshes.py:65-82): the rasteriser's waves hold 32 or 64 triangles and a lane walks its own box sub-box
+    by sub-box (raster.hip raster_frag_64), next to boxes beyond 24 pixels in the same wave (cooperative loop), triangles across the
+    near plane (cameras close to the surface) and huge ones.  Indices and depth bit-equal for triangle and texel renderers; fuse_views
+    (the views of a group in one rasteriser launch) against the float64 oracle."""
+    import types
+    from semantic_meshes_amd import synth
+    from semantic_meshes_amd.device import to_device
+    rng = np.random.default_rng(77000 + seed)
+    a, b = [(130, 128), (150, 110), (200, 100), (180, 120), (260, 130)][int(rng.integers(0, 5))]
+    verts, faces = _relief_mesh(rng, a, b)
+    rs = float(rng.uniform(0.5, 0.8))                 # the ring's radius; a quad then measures ~ 0.8 W / (a * rs) pixels
+    W = int(a * rs * float(rng.uniform(10.0, 18.0)) / 0.8)
+    H = int(W * float(rng.uniform(0.55, 0.8)))
+    C = int(rng.choice([5, 19, 40]))
+    kind = str(rng.choice(["sum", "summax", "mul"]))
+    mesh = types.SimpleNamespace(vertices=verts, faces=faces)
+    r = sm.render.triangles(mesh)
+    o = oracle.OracleRenderer(verts, faces)
+    oracle.set_threads(8)
+    P = len(faces)
+    cams = []
+    for view in range(3):
+        if view == 2 and rng.random() < 0.5:      # close to the surface, looking along it: everything from sub-pixel to clipped
+            eye = (float(rng.uniform(-4, 4)), float(rng.uniform(-2, 2)), float(rng.uniform(0.3, 1.0)))
+            target = (float(rng.uniform(-5, 5)), float(rng.uniform(-5, 5)), 0.0)
+            R, t = synth.look_at(eye, target, up=(0, 0, 1))
+            f = float(rng.uniform(0.5, 1.0)) * W
+            cams.append(sm.data.Camera(R, t, np.array([W, H]), np.array([f, f]), np.array([W / 2.0, H / 2.0])))
+        else:
+            cams.append(synth.ring_camera(int(rng.integers(0, 40)), 40, W, H, radius_scale=rs))
+    oidx = []
+    medium = 0
+    for cam in cams:
+        idx, depth = r.render(cam)
+        oi, od = o.render(cam)
+        np.testing.assert_array_equal(np.asarray(idx), oi)
+        np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), od.view(np.uint32))
+        oidx.append(oi)
+        medium = max(medium, r.render_stats(cam)[1][0])
+    assert medium > P // 4, "the scene was meant to consist of boxes over 8 x 8 pixels"
+    if seed % 2 == 0:       # the texel renderer over the same geometry (texel ids from the sub-box walk's barycentrics)
+        rt = sm.render.texels(mesh, cams, texels_per_pixel=0.2)
+        ot = oracle.OracleRenderer(verts, faces, cameras=cams, texels_per_pixel=0.2)
+        for cam in cams[:2]:
+            idx, depth = rt.render(cam)
+            oi, od = ot.render(cam)
+            np.testing.assert_array_equal(np.asarray(idx), oi)
+            np.testing.assert_array_equal(np.asarray(depth).view(np.uint32), od.view(np.uint32))
+    probs = [random_probs(rng, W, H, C, zero_fraction=0.1) for _ in cams]
+    if kind == "mul":
+        probs = [np.where(p.sum(-1, keepdims=True) > 0, np.maximum(p, 1e-3), 0).astype(np.float32) for p in probs]
+    agg = sm.fusion.MeshAggregator(P, C, kind)
+    agg.fuse_views(r, cams, [to_device(p) for p in probs])
+    oracle.set_accum_double(True)
+    try:
+        oagg = oracle.OracleAggregator(P, C, kind)
+        for oi, p in zip(oidx, probs):
+            oagg.add(oi, p)
+        assert_fused_close(agg.get(), oagg.get(), rtol=1e-5, atol=1e-6)
+    finally:
+        oracle.set_accum_double(False)
+        oracle.set_threads(1)

@@ -9,7 +9,7 @@ import test_gpu_fuzz as fz
 oracle.lib(); oracle.set_threads(1); oracle.set_accum_double(False)
 first, count = (int(sys.argv[1]) if len(sys.argv) > 1 else 100), (int(sys.argv[2]) if len(sys.argv) > 2 else 300)
 only = os.environ.get("SMESH_SWEEP_ONLY")            # e.g. "room": only the generators whose name contains it
-tests = [getattr(fz, n) for n in dir(fz) if n.startswith("test_random") and "forced_reorder" not in n and (not only or only in n)]   # (that one is a subprocess wrapper)
+tests = [getattr(fz, n) for n in dir(fz) if n.startswith("test_random") and "forced_reorder" not in n and (only in n if only else "dense" not in n)]   # (that one is a subprocess wrapper)
 fails, t0 = 0, time.time()
 for seed in range(first, first + count):
     for t in tests:
