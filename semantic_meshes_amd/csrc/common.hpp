@@ -143,6 +143,7 @@ struct TriFuseArgs {
   // texel primitives (k_fuse_texel) only
   const uint32_t* tex_first;  // [F] first texel id of each triangle
   const uint32_t* tex_res;    // [F] texel resolution r: the triangle owns r (r + 1) / 2 consecutive texels
+  const uint8_t* tex_kinds;   // [F] TriFrag::kind of every triangle, a byte each: a texel renderer leaves a record only where it is nonzero
   uint32_t* count;            // [P] scratch histogram, all zero between launches (big triangles only)
   double* acc_d;              // Mul + texel primitives: [P][C] sums of ONE view's terms, all zero between launches (big triangles only)
   int mid;                    // k_fuse_tri: nonzero = the launch's last workgroups (fuse_mid_entries) take the queued triangles with at most kMidBox pixels per view (the tail waves skip them)

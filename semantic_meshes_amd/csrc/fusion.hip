@@ -1524,7 +1524,7 @@ __global__ __launch_bounds__(kTexelBlock) void k_fuse_texel(TriFuseArgs a) {
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   uint32_t first = 0, cnt = 0;
-  if (f < a.F) rec = a.frags[f];
+  if (f < a.F && (!a.tex_kinds || a.tex_kinds[f] != 0)) rec = a.frags[f];   // (no record where the kind byte says "nothing")
   if (rec.kind == 1) {   // (the tables are not read for the triangles that emitted nothing)
     first = a.tex_first[f];
     const uint32_t res = a.tex_res[f];
@@ -2489,7 +2489,7 @@ static int ensure_acc_d(smesh_aggregator* a) {
   return SMESH_OK;
 }
 
-int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
+int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, const uint8_t* kinds, uint64_t F, const uint32_t* tex_first,
                                  const uint32_t* tex_res, const uint32_t* big_queue, const uint32_t* big_len,
                                  uint32_t big_capacity, const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t H) {
   DeviceCtx* ctx = a->ctx;
@@ -2503,7 +2503,7 @@ int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint
   t.blk_first = 0u; t.f_lo = 0u; t.f_hi = (uint32_t)F;
   t.dbg = 0; t.prim_id = nullptr; t.lds_pad = 0u;
   SMESH_TRY(ensure_acc_d(a));
-  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count; t.acc_d = a->acc_d;
+  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count; t.acc_d = a->acc_d; t.tex_kinds = kinds;
   const dim3 tgrid((uint32_t)div_up(F, kTexelBlock)), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave), tblock(kTexelBlock);
   // (no pass over the whole accumulator for Mul here: every texel kernel re-centres the rows it touches)
   {
@@ -2550,7 +2550,7 @@ int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const ui
   t.blk_first = 0u; t.f_lo = 0u; t.f_hi = (uint32_t)F;
   t.dbg = 0; t.prim_id = nullptr; t.lds_pad = 0u;
   SMESH_TRY(ensure_acc_d(a));
-  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count; t.acc_d = a->acc_d;
+  t.tex_first = tex_first; t.tex_res = tex_res; t.count = a->count; t.acc_d = a->acc_d; t.tex_kinds = nullptr;
   const dim3 tgrid((uint32_t)div_up(F, kTexelBlock)), bgrid(12u * (uint32_t)std::max(1, ctx->num_cus)), block(kWave), tblock(kTexelBlock);
   // (no pass over the whole accumulator for Mul here: every texel kernel re-centres the rows it touches)
   {

@@ -49,7 +49,7 @@ uint64_t smesh_aggregator_primitives(smesh_aggregator* a);
 int smesh_aggregator_join_exchange(smesh_aggregator* a);
 const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordered);
 bool smesh_aggregator_can_fuse_texels(smesh_aggregator* a, uint64_t P);
-int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, uint64_t F, const uint32_t* tex_first,
+int smesh_aggregator_fuse_texels(smesh_aggregator* a, const TriFrag* frags, const uint8_t* kinds, uint64_t F, const uint32_t* tex_first,
                                  const uint32_t* tex_res, const uint32_t* big_queue, const uint32_t* big_len,
                                  uint32_t big_capacity, const uint32_t* d_idx, const float* d_probs, const float* d_w, uint64_t H);
 int smesh_aggregator_fuse_texels_multi(smesh_aggregator* a, uint64_t F, const uint32_t* tex_first, const uint32_t* tex_res, uint32_t big_capacity,
@@ -281,8 +281,9 @@ struct RasterArgs {
                               //     records still hold fragments that lost the depth test (the fusion must check them)
   uint32_t big_capacity;
   TriFrag* frags;             // per-triangle fragment records for the triangle-order fusion (may be null)
-  uint8_t* kinds;             // texel renderers: the records' `kind` again, a byte per triangle (k_fuse_texel_multi reads these instead of
-                              // sixteen bytes per triangle and view to find the one triangle in eight that emitted anything); else null
+  uint8_t* kinds;             // texel renderers: the records' `kind`, a byte per triangle -- the fusion finds the one triangle in eight that
+                              // emitted anything from these instead of from sixteen bytes per triangle and view, and a record is
+                              // written only where the byte is nonzero; else null
   FragQueues q;               // fragment-queue path only
   uint32_t tpw;               // k_raster_frag: triangles per group of a wave (power of two <= 64)
   uint32_t groups;            // k_raster_frag: groups per wave (1; 2 with tpw = 64 when the launch has waves to spare)
@@ -523,7 +524,7 @@ __global__ void k_raster_small(RasterArgs a) {
       rec.mask = mask;
     }
   }
-  if (a.frags) a.frags[f] = rec;
+  if (a.frags && (rec.kind != 0 || !a.kinds)) a.frags[f] = rec;
   if (a.kinds) a.kinds[f] = (uint8_t)rec.kind;
 }
 
@@ -740,7 +741,9 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
     const unsigned long long mask = emit_cover(a, t, f, pid, t.x0, t.y0, cover, sub);
     if (mask) rec.kind = 1;
     if (rec.kind == 1) rec.mask = mask;
-    if (a.frags && f < a.F) a.frags[f] = rec;
+    // texel renderers (a.kinds): seven triangles in eight emit nothing in a cfg4 view -- those leave their kind byte only, and every
+    // reader of a texel renderer's records asks the byte first (cfg4: 5 050 -> 5 210 views/s)
+    if (a.frags && f < a.F && (rec.kind != 0 || !a.kinds)) a.frags[f] = rec;
     if (a.kinds && f < a.F) a.kinds[f] = (uint8_t)rec.kind;
   }
   // ---- boxes over 8 x 8 up to kLaneBox x kLaneBox: this lane's sub-boxes, one per round (wave-uniform trip count) -- where the wave
@@ -1743,7 +1746,7 @@ static int fuse_rendered(smesh_renderer* r, smesh_aggregator* a, int slot, const
     smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, r->prim_id != nullptr), "render-records");
   } else if (r->texels && smesh_aggregator_can_fuse_texels(a, r->num_primitives)) {
     // texel primitives: a triangle owns its texel rows, its lane read-modify-writes them without atomics
-    SMESH_TRY(smesh_aggregator_fuse_texels(a, r->side[slot].frags, r->F, r->tex_first, r->tex_res, r->side[slot].big_queue,
+    SMESH_TRY(smesh_aggregator_fuse_texels(a, r->side[slot].frags, r->side[slot].kinds, r->F, r->tex_first, r->tex_res, r->side[slot].big_queue,
                                            r->side[slot].big_count, r->big_capacity, d_idx, d_probs, d_w, H));
     smesh_note_fuse("k_fuse_texel", "render-records");
   } else {
