@@ -287,6 +287,10 @@ struct RasterArgs {
   FragQueues q;               // fragment-queue path only
   uint32_t tpw;               // k_raster_frag: triangles per group of a wave (power of two <= 64)
   uint32_t groups;            // k_raster_frag: groups per wave (1; 2 with tpw = 64 when the launch has waves to spare)
+  uint32_t wg_push;           // k_raster_frag: nonzero = the workgroup's four waves share each atomic on the view's queues (views of mostly medium
+                              // triangles: every wave pushes, and increments of ONE counter pass the L2 at ~5 ns each); 0 = one per wave
+  uint32_t spread;            // k_raster_frag: nonzero = a triangle takes kSpread consecutive lanes, one per 8 x 8 sub-box of its (at most
+                              // kLaneBox x kLaneBox) box; tpw = 64 / kSpread (raster_frag_wave)
   int dbg;                    // development ablation (SMESH_RDBG) of k_raster_frag: 1 = no stores, 2 = setup only, 4 = + coverage,
                               // 8 = + slot reservation, 16 = grouping without the reservation atomics
 };
@@ -706,41 +710,114 @@ __device__ __forceinline__ unsigned long long emit_cover(const RasterArgs& a, co
 // when f < a.F); `sub`: the wave's sub-queue in every tile.
 constexpr int kLaneBox = 24;
 constexpr int kLaneBoxMin = 20;
+constexpr int kSpread = (kLaneBox / 8) * (kLaneBox / 8);   // lanes per triangle in a spread wave: one per sub-box
+constexpr int kSpreadTris = 64 / kSpread;                  // triangles per spread wave
+// `part`: -1, or (spread waves, raster_frag_wave) which of the triangle's sub-boxes this lane walks; the lane with part 0 is the triangle's
+// owner (its record, its queue entries, the small box, the cooperative loop), the others only walk.
+// MODE (an instance of the kernels per mode: the code of the other modes costs the small-triangle instance registers it does not
+// have -- k_raster_frag_group is held to 96 for five waves per SIMD): bit 0 = RasterArgs::wg_push, bit 1 = RasterArgs::spread.
+template <int MODE>
 __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64_t f, const int32_t i0, const int32_t i1, const int32_t i2,
-                                               const uint32_t sub) {
+                                               const uint32_t sub, const int part_in = -1) {
+  constexpr bool kWgPush = (MODE & 1) != 0, kSpreadMode = (MODE & 2) != 0;
   const int lane = threadIdx.x & 63;
+  const int part = kSpreadMode ? part_in : -1;
+  const bool owner = part <= 0;
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   Tri t;
   t.x0 = 0; t.y0 = 0; t.x1 = -1; t.y1 = -1;
   unsigned long long cover = 0ull;
-  bool medium = false, lanebox = false;
+  int CX0 = 0, CY0 = 0;          // origin of the (at most 8 x 8) box `cover` describes
+  bool medium = false, lanebox = false, small = false;
+  bool q_big = false, q_mid = false, q_huge = false;   // this lane's triangle goes into the view's queues (below, one atomic per wave and queue)
   const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // value written to the index image
   const int have = f < a.F ? load_tri_ex(a, f, t, i0, i1, i2) : 0;   // 2: crosses the near plane (t holds only its screen box)
   if (have) {
     const int bw = t.x1 - t.x0 + 1, bh = t.y1 - t.y0 + 1;
     rec.x0 = (uint16_t)t.x0; rec.y0 = (uint16_t)t.y0;
+    CX0 = t.x0; CY0 = t.y0;
     if (bw > 8 || bh > 8 || have == 2) {
-      const uint32_t slot = atomicAdd(a.big_count, 1u);          // every such triangle: the fusion walks this queue
-      if (slot < a.big_capacity) a.big_queue[slot] = (uint32_t)f;
-      push_mid(a, f, bw * bh);
+      q_big = owner;                                             // every such triangle: the fusion walks this queue
+      q_mid = owner && bw * bh <= kMidBox;                       // (push_mid's list)
       rec.kind = 2;
       rec.mask = (unsigned long long)(uint32_t)t.x1 | ((unsigned long long)(uint32_t)t.y1 << 16);
-      if (bw <= kLaneBox && bh <= kLaneBox && have == 1) lanebox = true;     // rasterised below by this lane, sub-box by sub-box
-      else if (bw <= kMedium && bh <= kMedium && have == 1) medium = true;   // rasterised below by the whole wave
-      else {                                                     // rasterised by the tile workgroups it overlaps
-        const uint32_t hs = atomicAdd(a.big_count + 2, 1u);
-        if (hs < a.big_capacity) a.huge_queue[hs] = (uint32_t)f;
-      }
-    } else if (!(SMESH_ABL(a.dbg) & 2)) {
+      if (bw <= kLaneBox && bh <= kLaneBox && have == 1) {       // rasterised by lanes, sub-box by sub-box
+        if (part < 0) lanebox = true;                            // ... this lane, one sub-box per round (below)
+        else {                                                   // ... the triangle's kSpread lanes, one sub-box each, now
+          constexpr int kSub = kLaneBox / 8;
+          CX0 = t.x0 + 8 * (part / kSub); CY0 = t.y0 + 8 * (part % kSub);
+          const int sw = min(t.x1 - CX0 + 1, 8), sh = min(t.y1 - CY0 + 1, 8);
+          if (sw > 0 && sh > 0 && !(SMESH_ABL(a.dbg) & 2)) cover = walk_box(t, CX0, CY0, sw, sh);
+        }
+      } else if (!owner) {
+      } else if (bw <= kMedium && bh <= kMedium && have == 1) medium = true;   // rasterised below by the whole wave
+      else q_huge = true;                                        // rasterised by the tile workgroups it overlaps
+    } else if (owner && !(SMESH_ABL(a.dbg) & 2)) {
+      small = true;
       cover = walk_box(t, t.x0, t.y0, bw, bh);
     }
   }
-  if (SMESH_ABL(a.dbg) & 4) { if (a.frags && f < a.F) { rec.mask = cover; a.frags[f] = rec; } return; }   // ablation: setup + coverage only
+  // The queues of the view: ONE atomic per wave and queue -- or per workgroup (a.wg_push), where most triangles are queued: increments
+  // of one counter pass the L2 one by one at ~5 ns each, and one view of a 40 000-triangle mesh in spread waves spent 73 of its
+  // 132 us on 11 000 of them.
   {
-    const unsigned long long mask = emit_cover(a, t, f, pid, t.x0, t.y0, cover, sub);
-    if (mask) rec.kind = 1;
+    __shared__ uint32_t s_push[kWgPush ? 3 : 1][6];     // per queue: the counts of the four waves, then the workgroup's base
+    const int wv = (int)(threadIdx.x >> 6);
+    (void)wv; (void)s_push;
+    uint32_t* const counter[3] = {a.big_count, a.big_count + 3, a.big_count + 2};
+    const bool want[3] = {q_big, q_mid, q_huge};
+    uint32_t slot[3];
+    if constexpr (kWgPush) {
+      unsigned long long m[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        m[q] = __ballot(want[q]);
+        if (lane == 0) s_push[q][wv] = (uint32_t)__popcll(m[q]);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0u) {            // (three independent atomics, in flight together; their addresses are scalars)
+        uint32_t total[3], base[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int q = 0; q < 3; q++) total[q] = s_push[q][0] + s_push[q][1] + s_push[q][2] + s_push[q][3];
+        if (total[0]) base[0] = atomicAdd(a.big_count, total[0]);
+        if (total[1]) base[1] = atomicAdd(a.big_count + 3, total[1]);
+        if (total[2]) base[2] = atomicAdd(a.big_count + 2, total[2]);
+#pragma unroll
+        for (int q = 0; q < 3; q++) s_push[q][4] = base[q];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        uint32_t before = s_push[q][4];
+        for (int w = 0; w < wv; w++) before += s_push[q][w];
+        slot[q] = want[q] ? before + (uint32_t)__popcll(m[q] & ((1ull << lane) - 1ull)) : 0xFFFFFFFFu;
+      }
+      __syncthreads();                    // (the next group of a looping wave writes its counts)
+    } else {
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const unsigned long long m = __ballot(want[q]);
+        slot[q] = 0xFFFFFFFFu;
+        if (m == 0ull) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(counter[q], (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (want[q]) slot[q] = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      }
+    }
+    if (q_big && slot[0] < a.big_capacity) a.big_queue[slot[0]] = (uint32_t)f;
+    if (q_mid && slot[1] < a.big_capacity) a.big_queue[(uint64_t)a.big_capacity + slot[1]] = (uint32_t)f;
+    if (q_huge && slot[2] < a.big_capacity) a.huge_queue[slot[2]] = (uint32_t)f;
+  }
+  if (SMESH_ABL(a.dbg) & 4) { if (a.frags && f < a.F && owner) { rec.mask = cover; a.frags[f] = rec; } return; }   // ablation: setup + coverage only
+  {
+    const unsigned long long mask = emit_cover(a, t, f, pid, CX0, CY0, cover, sub);
+    if (mask && small) rec.kind = 1;
     if (rec.kind == 1) rec.mask = mask;
+  }
+  if (owner) {
     // texel renderers (a.kinds): seven triangles in eight emit nothing in a cfg4 view -- those leave their kind byte only, and every
     // reader of a texel renderer's records asks the byte first (cfg4: 5 050 -> 5 210 views/s)
     if (a.frags && f < a.F && (rec.kind != 0 || !a.kinds)) a.frags[f] = rec;
@@ -799,9 +876,13 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
     const uint32_t sb0 = (uint32_t)bi((int)rb0), sb1 = (uint32_t)bi((int)rb1), sb2 = (uint32_t)bi((int)rb2),
                    sb3 = (uint32_t)bi((int)rb3), sb4 = (uint32_t)bi((int)rb4), sb5 = (uint32_t)bi((int)rb5);
     const int bh = Y1 - Y0 + 1, area = (X1 - X0 + 1) * bh;
+    // i / bh as a multiplication: exact for bh <= kMedium = 64 and i < 2^26 (i * (m - 2^32 / bh) / 2^32 < 1 / bh); the two integer
+    // divisions per sample were a third of the loop's instructions
+    const uint32_t bh_rcp = bh > 1 ? 0xFFFFFFFFu / (uint32_t)bh + 1u : 0u;   // (bh = 1: the multiplier would be 2^32)
     for (int i = lane; i < area + lane; i += 64) {   // every lane runs the same number of steps (readlane inside)
       const bool in_box = i < area;
-      const int x = X0 + (in_box ? i / bh : 0), y = Y0 + (in_box ? i % bh : 0);
+      const int col = bh > 1 ? (int)__umulhi((uint32_t)i, bh_rcp) : i;
+      const int x = X0 + (in_box ? col : 0), y = Y0 + (in_box ? i - col * bh : 0);
       const double px = (double)x + 0.5, py = (double)y + 0.5;
       const double w0 = __builtin_fma(e0A, px, __builtin_fma(e0B, py, e0C));
       const double w1 = __builtin_fma(e1A, px, __builtin_fma(e1B, py, e1C));
@@ -847,9 +928,22 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
 // them -- removes a third (cfg2) to three quarters (cfg4) of the wave instructions and was measured SLOWER in rounds 2 and 5:
 // cfg2 33.1 -> 38.0 us per view for the raster stage, cfg4 4 777 -> 4 615 views/s.  The kernel waits for memory round trips, not for
 // issue slots; NOTES/round5.md.)
-template <bool LOOP>
+template <bool LOOP, int MODE>
 __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint64_t wave_id) {
   const int lane = threadIdx.x & 63;
+  if constexpr ((MODE & 2) != 0) {
+    // Spread waves (round 5): where most boxes are 9 .. kLaneBox pixels wide and the launch has few triangles (one view of a decimated
+    // scan: 40 000 triangles are 625 waves of 64), a triangle takes kSpread consecutive lanes, one per 8 x 8 sub-box -- seven triangles a
+    // wave, every lane setting up its triangle for itself, ONE coverage walk and one pass of reservations and stores per wave instead
+    // of up to nine rounds.  Same fragments.
+    const int tri = lane / kSpread;
+    uint64_t fs = wave_id * (uint64_t)kSpreadTris + (uint64_t)tri;
+    if (tri >= kSpreadTris || fs >= a.F) fs = a.F;
+    int32_t s0 = 0, s1 = 0, s2 = 0;
+    if (fs < a.F) { s0 = a.faces[3 * fs + 0]; s1 = a.faces[3 * fs + 1]; s2 = a.faces[3 * fs + 2]; }
+    raster_frag_64<MODE>(a, fs, s0, s1, s2, (uint32_t)wave_id & (kQSub - 1), lane % kSpread);
+    return;
+  } else {
   const uint32_t G = LOOP ? a.groups : 1u;
   uint64_t f = lane < (int)a.tpw ? wave_id * G * a.tpw + lane : a.F;
   int32_t n0 = 0, n1 = 0, n2 = 0;
@@ -858,14 +952,17 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
     const int32_t i0 = n0, i1 = n1, i2 = n2;
     const uint64_t fn = f + 64u;          // (G > 1 only with 64 triangles per group)
     if (g + 1 < G && fn < a.F) { n0 = a.faces[3 * fn + 0]; n1 = a.faces[3 * fn + 1]; n2 = a.faces[3 * fn + 2]; }
-    raster_frag_64(a, f, i0, i1, i2, (uint32_t)(wave_id * G + g) & (kQSub - 1));
+    raster_frag_64<MODE>(a, f, i0, i1, i2, (uint32_t)(wave_id * G + g) & (kQSub - 1));
     f = fn < a.F ? fn : a.F;
+  }
   }
 }
 
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_raster_frag(RasterArgs a) {
-  raster_frag_wave<false>(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+  raster_frag_wave<false, MODE>(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 }
+int raster_mode(const RasterArgs& a) { return (a.spread ? 3 : a.wg_push ? 1 : 0); }   // (spread views are views of medium triangles: wg_push too)
 
 // Several views in one launch: blocks [v * blocks_per_view, (v + 1) * blocks_per_view) rasterise view v.
 struct RasterGroup {
@@ -874,9 +971,10 @@ struct RasterGroup {
   uint32_t tile_end[kMaxGroup];   // ... whose tiles are blocks [tile_end[v-1], tile_end[v])
   uint32_t n, blocks_per_view;
 };
+template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_raster_frag_group(RasterGroup g) {
   const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
-  raster_frag_wave<true>(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
+  raster_frag_wave<true, MODE>(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
 }
 // The largest triangles (box over kMedium x kMedium) and the triangles that cross the near plane (clip_piece), between k_raster_frag
 // and k_tile_resolve: one workgroup per screen tile scans their queue, keeps those whose box overlaps the tile and shades the
@@ -1125,7 +1223,7 @@ struct smesh_renderer {
   int32_t* faces = nullptr;        // int32[F*3]
   // Host-side summary of the mesh (create_common): the box of its vertices and its longest edge -- what no_huge_possible() needs to
   // prove, per camera, that the queue of k_raster_huge stays empty.  valid = every vertex finite, at least one usable face.
-  struct Bounds { bool valid = false; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, max_edge = 0; } bounds;
+  struct Bounds { bool valid = false; double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0}, max_edge = 0, mean_edge = 0; } bounds;
   uint32_t* prim_id = nullptr;     // [F] primitive id per triangle position, when the triangles were re-ordered (else null)
   // What a render in flight needs besides the per-triangle records, per view slot: smesh_fuse_views rasterises up to
   // kMaxGroup views in the same launches (slots beyond 0 are allocated on first use); every other entry point uses slot 0.
@@ -1306,7 +1404,33 @@ CameraArgs camera_args(const smesh_camera_t* cam) {
 }
 
 // Kernel arguments of a render of a W x H view with scratch set `vs`, leaving its records in side `side` (queues: a.q).
-RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int side, uint64_t W, uint64_t H, int nviews = 1) {
+// An ESTIMATE (a tuning input, never a proof: every path rasterises every triangle correctly) of the screen size in pixels of a typical
+// edge of the mesh for this camera: the mean edge at the depth of the centre of the mesh's box.  0: no estimate.
+double typical_edge_pixels(const smesh_renderer* r, const smesh_camera_t* cam) {
+  const smesh_renderer::Bounds& b = r->bounds;
+  if (!b.valid || !(b.mean_edge > 0.0)) return 0.0;
+  double z = cam->translation[2];
+  for (int d = 0; d < 3; d++) z += (double)cam->rotation[6 + d] * 0.5 * (b.lo[d] + b.hi[d]);
+  if (!(z > 1e-3)) return 0.0;
+  const double e = b.mean_edge * std::max(std::fabs(cam->focal[0]), std::fabs(cam->focal[1])) / z;
+  return std::isfinite(e) ? e : 0.0;
+}
+// Spread waves (raster_frag_wave) for this launch?  SMESH_RASTER_SPREAD=0 / 1 forces; else for ONE view whose typical edge measures
+// 10.5 .. 19 pixels (boxes of 9 .. 24).  1080p, one render() at a time, ms (lanes walking their own boxes in rounds / spread waves;
+// NOTES/round5.md 11): 25 600 triangles 0.129 / 0.092, 40 000 0.146 / 0.084, 62 500 0.128 / 0.095 -- 19 600 (a fifth of the boxes
+// beyond 24 pixels) 0.100 / 0.122, 90 000 (half of them within 8) 0.092 / 0.100.  The views of a group fill the chip with waves of 32
+// or 64 triangles: 40 000 triangles 0.080 / 0.085 per view, 90 000 0.077 / 0.113.
+bool want_spread(const smesh_renderer* r, const smesh_camera_t* cam, int nviews) {
+  static const int knob = getenv("SMESH_RASTER_SPREAD") ? atoi(getenv("SMESH_RASTER_SPREAD")) : -1;
+  if (knob == 0 || !cam) return false;
+  if (knob == 1) return true;
+  if (nviews > 1) return false;
+  const double e = typical_edge_pixels(r, cam);
+  return e >= 10.5 && e <= 19.0;
+}
+
+RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int side, uint64_t W, uint64_t H, int nviews = 1,
+                       const smesh_camera_t* cam = nullptr) {
   RasterArgs a;
   a.faces = r->faces; a.verts = r->verts; a.sv = vs.sv; a.tex_res = r->texels ? r->tex_res : nullptr; a.tex_first = r->tex_first;
   a.prim_id = r->prim_id;
@@ -1328,6 +1452,12 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   const uint64_t launch_views = fine ? (uint64_t)std::max(1, nviews) : 1u;
   while (a.tpw > 1 && launch_views * r->F / a.tpw < min_waves) a.tpw >>= 1;
   a.groups = 1;  // (frag_groups() decides per launch)
+  a.spread = 0u;
+  {   // (SMESH_RASTER_WG_PUSH=0 / 1 forces)
+    static const int knob = getenv("SMESH_RASTER_WG_PUSH") ? atoi(getenv("SMESH_RASTER_WG_PUSH")) : -1;
+    a.wg_push = knob >= 0 ? (uint32_t)(knob != 0) : (cam && typical_edge_pixels(r, cam) >= 5.0 ? 1u : 0u);
+  }
+  if (want_spread(r, cam, nviews)) { a.spread = (uint32_t)kSpread; a.tpw = (uint32_t)kSpreadTris; }
   return a;
 }
 
@@ -1365,13 +1495,20 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 16, st));
   }
   if (r->F) {
-    RasterArgs a = raster_args(r, vs, side, W, H);
+    RasterArgs a = raster_args(r, vs, side, W, H, 1, cam);
     a.cam = ca;
     const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
     int qs = SMESH_OK;
     if (raster_path() == RasterPath::Frag && ensure_queues(r, vs, W, H, st, &qs)) {
       a.q = vs.fq;
-      hipLaunchKernelGGL(k_raster_frag, dim3((uint32_t)div_up(div_up(r->F, a.tpw), 4)), dim3(256), 0, st, a);
+      {
+        const dim3 grid((uint32_t)div_up(div_up(r->F, a.tpw), 4));
+        switch (raster_mode(a)) {
+          case 3:  hipLaunchKernelGGL(k_raster_frag<3>, grid, dim3(256), 0, st, a); break;
+          case 1:  hipLaunchKernelGGL(k_raster_frag<1>, grid, dim3(256), 0, st, a); break;
+          default: hipLaunchKernelGGL(k_raster_frag<0>, grid, dim3(256), 0, st, a); break;
+        }
+      }
       SMESH_HIP(hipGetLastError());
       const uint32_t ntiles = (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
       if (!no_huge_possible(r, cam)) hipLaunchKernelGGL(k_raster_huge, dim3(std::min<uint32_t>(ntiles, 2u * (uint32_t)ctx->num_cus)), dim3(256), 0, st, a, ntiles);
@@ -1466,6 +1603,7 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     pg.sv[v] = vs.sv;
     pg.big_count[v] = r->side[side_base + v].big_count;
     rg.view[v] = raster_args(r, vs, side_base + v, W, H, n);
+    rg.view[v].wg_push = raster_args(r, vs, side_base + v, W, H, 1, &cams[v]).wg_push;
     rg.view[v].cam = pg.cam[v];
     rg.view[v].q = vs.fq;
     rg.idx[v] = static_cast<uint32_t*>(r->fused[side_base + v].ptr);
@@ -1475,6 +1613,15 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   pg.verts = r->verts; pg.V = r->V;
   pg.n = (uint32_t)n;
   rg.n = (uint32_t)n;
+  {   // spread waves: one decision for the launch (its views share the grid): where at least half of the views ask for them
+    int votes = 0;
+    for (int v = 0; v < n; v++) votes += want_spread(r, &cams[v], n) ? 1 : 0;
+    if (2 * votes >= n && votes > 0)
+      for (int v = 0; v < n; v++) { rg.view[v].spread = (uint32_t)kSpread; rg.view[v].tpw = (uint32_t)kSpreadTris; }
+    int push_votes = 0;
+    for (int v = 0; v < n; v++) push_votes += rg.view[v].wg_push ? 1 : 0;
+    for (int v = 0; v < n; v++) rg.view[v].wg_push = 2 * push_votes >= n && push_votes > 0 ? 1u : 0u;
+  }
   for (int v = 0; v < n; v++) rg.view[v].groups = frag_groups(r->F, n, rg.view[0].tpw);
   rg.blocks_per_view = (uint32_t)div_up(div_up(r->F, rg.view[0].tpw * rg.view[0].groups), 4);
   ProfScope prof(ctx, SMESH_PROF_RASTER, st);
@@ -1482,7 +1629,15 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   SMESH_HIP(hipGetLastError());
   // (experiment knob: an LDS pad caps the rasteriser's workgroups per CU when it runs beside a fusion launch -- group pipeline)
   static const unsigned raster_pad = getenv("SMESH_RASTER_LDS_PAD") ? (unsigned)atoi(getenv("SMESH_RASTER_LDS_PAD")) : 0u;
-  hipLaunchKernelGGL(k_raster_frag_group, dim3((uint32_t)n * rg.blocks_per_view), dim3(256), (st == ctx->raster_stream ? raster_pad : 0u), st, rg);
+  {
+    const dim3 grid((uint32_t)n * rg.blocks_per_view);
+    const unsigned pad = st == ctx->raster_stream ? raster_pad : 0u;
+    switch (raster_mode(rg.view[0])) {     // (one mode per launch: render_group_into made the views agree)
+      case 3:  hipLaunchKernelGGL(k_raster_frag_group<3>, grid, dim3(256), pad, st, rg); break;
+      case 1:  hipLaunchKernelGGL(k_raster_frag_group<1>, grid, dim3(256), pad, st, rg); break;
+      default: hipLaunchKernelGGL(k_raster_frag_group<0>, grid, dim3(256), pad, st, rg); break;
+    }
+  }
   SMESH_HIP(hipGetLastError());
   bool huge_needed = false;   // (no_huge_possible: a proof that the queue of every view of the group stays empty)
   for (int v = 0; v < n; v++) huge_needed = huge_needed || !no_huge_possible(r, &cams[v]);
@@ -1551,7 +1706,8 @@ void mesh_bounds(const float* v, uint64_t V, const int32_t* f, uint64_t F, smesh
       lo[d] = std::min(lo[d], x); hi[d] = std::max(hi[d], x);
     }
   if (!finite) return;
-  double m2 = 0.0;
+  double m2 = 0.0, sum_edges = 0.0;
+  uint64_t edges = 0;
   for (uint64_t i = 0; i < F; i++) {
     const int32_t a = f[3 * i], c = f[3 * i + 1], e = f[3 * i + 2];
     if (a < 0 || c < 0 || e < 0 || (uint64_t)a >= V || (uint64_t)c >= V || (uint64_t)e >= V) continue;   // (load_tri drops such faces)
@@ -1560,8 +1716,11 @@ void mesh_bounds(const float* v, uint64_t V, const int32_t* f, uint64_t F, smesh
       const float* q = p[k]; const float* w = p[(k + 1) % 3];
       const double dx = (double)q[0] - w[0], dy = (double)q[1] - w[1], dz = (double)q[2] - w[2];
       m2 = std::max(m2, dx * dx + dy * dy + dz * dz);
+      sum_edges += std::sqrt(dx * dx + dy * dy + dz * dz);
+      edges++;
     }
   }
+  b.mean_edge = edges ? sum_edges / (double)edges : 0.0;
   for (int d = 0; d < 3; d++) { b.lo[d] = lo[d]; b.hi[d] = hi[d]; }
   b.max_edge = std::sqrt(m2);
   b.valid = std::isfinite(b.max_edge);

@@ -7,7 +7,10 @@ from semantic_meshes_amd import _lib, fusion, render, synth
 
 W, H, C = 1920, 1080, 19
 probs = synth.device_probs(W, H, C, 123, 0.02)
-for a, b in [(1000, 500), (700, 350), (500, 250), (300, 150), (200, 100), (100, 50), (30, 15)]:
+meshes = [(1000, 500), (700, 350), (500, 250), (300, 150), (200, 100), (100, 50), (30, 15)]
+if len(sys.argv) > 1:      # e.g. 200x100,300x150
+    meshes = [tuple(int(x) for x in m.split("x")) for m in sys.argv[1].split(",")]
+for a, b in meshes:
     mesh = synth.grid_mesh(a, b)
     cams = [synth.ring_camera(k, 8, W, H) for k in range(8)]
     r = render.triangles(mesh)
