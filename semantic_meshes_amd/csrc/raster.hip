@@ -1982,6 +1982,11 @@ int smesh_renderer_create_texels(const float* vertices, uint64_t V, const int32_
   smesh_renderer* r = nullptr;
   SMESH_TRY(create_common(vertices, V, hf.data(), F, device, &r));
   r->texels = true;
+  // (side 0 was made before the renderer knew what it was: its kind bytes now)
+  if (!r->side[0].kinds && dev_malloc(reinterpret_cast<void**>(&r->side[0].kinds), std::max<uint64_t>(F, 16)) != hipSuccess) {
+    smesh_renderer_destroy(r);
+    return fail(SMESH_ERR_RUNTIME, "texel renderer: allocation of the kind bytes failed");
+  }
   r->h_faces = std::move(hf);
   r->h_res.assign(F, 0);
   r->h_first.assign(F, 0);
