@@ -750,9 +750,10 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
           const int sw = min(t.x1 - CX0 + 1, 8), sh = min(t.y1 - CY0 + 1, 8);
           if (sw > 0 && sh > 0 && !(SMESH_ABL(a.dbg) & 2)) cover = walk_box(t, CX0, CY0, sw, sh);
         }
-      } else if (!owner) {
-      } else if (bw <= kMedium && bh <= kMedium && have == 1) medium = true;   // rasterised below by the whole wave
-      else q_huge = true;                                        // rasterised by the tile workgroups it overlaps
+      } else if (owner) {                                        // (the other lanes of a spread triangle have nothing to do with it)
+        if (bw <= kMedium && bh <= kMedium && have == 1) medium = true;   // rasterised below by the whole wave
+        else q_huge = true;                                      // rasterised by the tile workgroups it overlaps
+      }
     } else if (owner && !(SMESH_ABL(a.dbg) & 2)) {
       small = true;
       cover = walk_box(t, t.x0, t.y0, bw, bh);
