@@ -972,8 +972,10 @@ struct RasterGroup {
   uint32_t tile_end[kMaxGroup];   // ... whose tiles are blocks [tile_end[v-1], tile_end[v])
   uint32_t n, blocks_per_view;
 };
+// (five waves per SIMD -- 96 registers -- for the small-triangle instance; the instances for views of medium triangles may take 128: at 96
+// they spill, and their waves are long)
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_raster_frag_group(RasterGroup g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? 4 : 5, 5))) void k_raster_frag_group(RasterGroup g) {
   const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
   raster_frag_wave<true, MODE>(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
 }
