@@ -655,7 +655,8 @@ def test_render_fragment_queue_overflow(sm, oracle, monkeypatch, cap):
 
 
 @pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE=strip", "SMESH_FUSE_WIDE=0",
-                                  "SMESH_RASTER_PAIRS=0", "SMESH_FUSE_PAIRS=0", "SMESH_GROUP_PIPELINE=0", "SMESH_TEXEL_MULTI=0"])
+                                  "SMESH_RASTER_PAIRS=0", "SMESH_FUSE_PAIRS=0", "SMESH_GROUP_PIPELINE=0", "SMESH_TEXEL_MULTI=0",
+                                  "SMESH_RASTER_SPREAD=1", "SMESH_RASTER_WG_PUSH=1"])
 def test_alternative_paths_in_subprocess(knob):
     """These knobs are read once per process: re-run the render / fuse_view parity tests with the direct rasteriser
     (global 64-bit atomicMin per fragment), with the group pipeline off (the default since round 5 is on), and with the generic
@@ -673,6 +674,10 @@ def test_alternative_paths_in_subprocess(knob):
         sel = "fuse_views" if k.endswith("PAIRS") else sel + " or fuse_views"
     if k == "SMESH_RASTER":
         sel += " or near_plane or room"      # the direct rasteriser clips at the near plane too
+    if k in ("SMESH_RASTER_SPREAD", "SMESH_RASTER_WG_PUSH"):
+        # the rasteriser's modes for views of medium triangles, forced on every view (spread waves: a triangle on nine lanes; the
+        # view's queues filled by one atomic per workgroup): every kind of triangle through them, single views and groups
+        sel += " or near_plane or medium or fuse_views or degenerate"
     if k in ("SMESH_GROUP_PIPELINE", "SMESH_TEXEL_MULTI"):
         sel = "fuse_views"
     # the many-instance multi-view tests only where the knob reaches them (each subprocess pays ~10 s of start-up as it is)
