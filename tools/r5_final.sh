@@ -13,7 +13,7 @@ for mode in "" "--no-group-pipeline"; do
   rm -rf $out/prof_$tag
 done
 python bench.py --workload cfg4 > $out/bench_cfg4.json 2> $out/cfg4.err
-python bench.py --workload cfg4t --no-pmc > $out/bench_cfg4t.json 2> $out/cfg4t.err
+python bench.py --workload cfg4t > $out/bench_cfg4t.json 2> $out/cfg4t.err
 python bench.py --workload cfg5 > $out/bench_cfg5.json 2> $out/cfg5.err
 python tools/mesh_density_sweep.py 2>&1 | grep -v amdgpu.ids > $out/mesh_density_sweep.txt
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 1 --steps 20 --warmup 5 --no-host-path > $out/launched_world1.json 2> $out/launched.err
