@@ -102,7 +102,7 @@ __device__ __forceinline__ ScreenVertex project_point(const CameraArgs& cam, con
 
 __device__ __forceinline__ void project_vertex(const float* __restrict__ verts, uint64_t V, const CameraArgs& cam,
                                                ScreenVertex* __restrict__ sv, uint32_t* __restrict__ big_count, const uint64_t i) {
-  if (i == 0) { big_count[0] = 0u; big_count[1] = 0u; big_count[2] = 0u; big_count[3] = 0u; }   // [1]: "the per-triangle masks are not final" flag
+  if (i == 0) { big_count[0] = 0u; big_count[1] = 0u; big_count[2] = 0u; big_count[3] = 0u; big_count[4] = 0u; big_count[5] = 0u; }   // [1]: "the per-triangle masks are not final" flag
   if (i >= V) return;
   sv[i] = project_point(cam, verts[3 * i + 0], verts[3 * i + 1], verts[3 * i + 2]);
 }
@@ -126,7 +126,8 @@ struct ProjectGroup {
 __global__ void k_project_vertices_group(ProjectGroup g) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i == 0)
-    for (uint32_t v = 0; v < g.n; v++) { g.big_count[v][0] = 0u; g.big_count[v][1] = 0u; g.big_count[v][2] = 0u; g.big_count[v][3] = 0u; }
+    for (uint32_t v = 0; v < g.n; v++)
+      for (int k = 0; k < 6; k++) g.big_count[v][k] = 0u;      // ([4]: length of the view's list of medium triangles, RasterArgs::med_queue)
   if (i >= g.V) return;
   const float X = g.verts[3 * i + 0], Y = g.verts[3 * i + 1], Z = g.verts[3 * i + 2];
   for (uint32_t v = 0; v < g.n; v++) g.sv[v][i] = project_point(g.cam[v], X, Y, Z);
@@ -287,6 +288,11 @@ struct RasterArgs {
   FragQueues q;               // fragment-queue path only
   uint32_t tpw;               // k_raster_frag: triangles per group of a wave (power of two <= 64)
   uint32_t groups;            // k_raster_frag: groups per wave (1; 2 with tpw = 64 when the launch has waves to spare)
+  uint32_t* med_queue;        // k_raster_frag, balanced (below): the view's list of triangles for the cooperative loop, [big_capacity];
+                              // its length: big_count[4]
+  uint32_t balance;           // k_raster_frag (wg_push instances): nonzero = the triangles a wave would walk one at a time (boxes beyond the
+                              // lanes' reach, up to kMedium) go to med_queue and k_raster_medium walks that list with the whole
+                              // chip: a view from inside the scene has them all in a few waves (the near part of the mesh)
   uint32_t wg_push;           // k_raster_frag: nonzero = the workgroup's four waves share each atomic on the view's queues (views of mostly medium
                               // triangles: every wave pushes, and increments of ONE counter pass the L2 at ~5 ns each); 0 = one per wave
   uint32_t spread;            // k_raster_frag: nonzero = a triangle takes kSpread consecutive lanes, one per 8 x 8 sub-box of its (at most
@@ -714,6 +720,84 @@ constexpr int kSpread = (kLaneBox / 8) * (kLaneBox / 8);   // lanes per triangle
 constexpr int kSpreadTris = 64 / kSpread;                  // triangles per spread wave
 // `part`: -1, or (spread waves, raster_frag_wave) which of the triangle's sub-boxes this lane walks; the lane with part 0 is the triangle's
 // owner (its record, its queue entries, the small box, the cooperative loop), the others only walk.
+// The cooperative walk of one triangle by a whole wave, in two pieces used by raster_frag_64 (the triangle's owner lane broadcasts it)
+// and by k_raster_medium (every lane set the triangle up for itself).
+// Queue bases of the (at most 3 x 2) tile sub-rectangles of the box of `t`: the whole sub-rectangle is reserved with one atomic per tile.
+__device__ __forceinline__ void coop_reserve(const RasterArgs& a, const Tri& t, const uint32_t sub, uint32_t (&rb)[6]) {
+  const int tX0 = t.x0 / kQW, tY0 = t.y0 / kQH;
+  const int ntx = t.x1 / kQW - tX0 + 1, nty = t.y1 / kQH - tY0 + 1;
+  auto reserve = [&](int j) -> uint32_t {
+    if (j >= ntx * nty) return 0u;
+    const int jx = tX0 + j / nty, jy = tY0 + j % nty;
+    const int wx = min(t.x1, jx * kQW + kQW - 1) - max(t.x0, jx * kQW) + 1, hy = min(t.y1, jy * kQH + kQH - 1) - max(t.y0, jy * kQH) + 1;
+    return atomicAdd(&a.q.count[((uint32_t)jx * a.q.tiles_y + (uint32_t)jy) * kQSub + sub], (uint32_t)(wx * hy));
+  };
+#pragma unroll
+  for (int j = 0; j < 6; j++) rb[j] = reserve(j);     // in flight together
+}
+// The triangle of lane `src` (its set-up `t`, its reservations `rb`, triangle number f / index value pid in that lane), all 64 lanes on its box.
+__device__ __forceinline__ void coop_walk(const RasterArgs& a, const Tri& t, const uint32_t (&rb)[6], const int src, const uint64_t fsrc,
+                                          const uint32_t psrc, const uint32_t sub) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t rb0 = rb[0], rb1 = rb[1], rb2 = rb[2], rb3 = rb[3], rb4 = rb[4], rb5 = rb[5];
+    auto bi = [&](int v) -> int { return __builtin_amdgcn_readlane(v, src); };
+    auto bd = [&](double v) -> double { return __hiloint2double(bi(__double2hiint(v)), bi(__double2loint(v))); };
+    const int X0 = bi(t.x0), X1 = bi(t.x1), Y0 = bi(t.y0), Y1 = bi(t.y1);
+    const double e0A = bd(t.e0.A), e0B = bd(t.e0.B), e0C = bd(t.e0.C);
+    const double e1A = bd(t.e1.A), e1B = bd(t.e1.B), e1C = bd(t.e1.C);
+    const double e2A = bd(t.e2.A), e2B = bd(t.e2.B), e2C = bd(t.e2.C);
+    const double iz0 = bd(t.iz0), iz1 = bd(t.iz1), iz2 = bd(t.iz2);
+    const int c0 = bi(t.cls0), c1 = bi(t.cls1), c2 = bi(t.cls2);
+    const uint32_t fb = (uint32_t)bi((int)(uint32_t)fsrc);      // (the owner lane's triangle: lanes need not hold consecutive ones, see raster_frag_wave)
+    const uint32_t fbid = (uint32_t)bi((int)psrc);
+    uint32_t tfirst = 0u, tres = 0u;
+    if (a.tex_res) { tfirst = a.tex_first[fb]; tres = a.tex_res[fb]; }
+    const int tX0 = X0 / kQW, tY0 = Y0 / kQH, nty = Y1 / kQH - tY0 + 1;
+    const uint32_t sb0 = (uint32_t)bi((int)rb0), sb1 = (uint32_t)bi((int)rb1), sb2 = (uint32_t)bi((int)rb2),
+                   sb3 = (uint32_t)bi((int)rb3), sb4 = (uint32_t)bi((int)rb4), sb5 = (uint32_t)bi((int)rb5);
+    const int bh = Y1 - Y0 + 1, area = (X1 - X0 + 1) * bh;
+    // i / bh as a multiplication: exact for bh <= kMedium = 64 and i < 2^26 (i * (m - 2^32 / bh) / 2^32 < 1 / bh); the two integer
+    // divisions per sample were a third of the loop's instructions
+    const uint32_t bh_rcp = bh > 1 ? 0xFFFFFFFFu / (uint32_t)bh + 1u : 0u;   // (bh = 1: the multiplier would be 2^32)
+    for (int i = lane; i < area + lane; i += 64) {   // every lane runs the same number of steps (readlane inside)
+      const bool in_box = i < area;
+      const int col = bh > 1 ? (int)__umulhi((uint32_t)i, bh_rcp) : i;
+      const int x = X0 + (in_box ? col : 0), y = Y0 + (in_box ? i - col * bh : 0);
+      const double px = (double)x + 0.5, py = (double)y + 0.5;
+      const double w0 = __builtin_fma(e0A, px, __builtin_fma(e0B, py, e0C));
+      const double w1 = __builtin_fma(e1A, px, __builtin_fma(e1B, py, e1C));
+      const double w2 = __builtin_fma(e2A, px, __builtin_fma(e2B, py, e2C));
+      const bool cov = edge_accepts(w0, c0) && edge_accepts(w1, c1) && edge_accepts(w2, c2);
+      unsigned long long key = kNullKey;
+      if (in_box && cov) {
+        const double num = (w0 + w1) + w2;
+        const double den = __builtin_fma(w2, iz2, __builtin_fma(w1, iz1, w0 * iz0));
+        const float zf = (float)(num / den);
+        if (zf > 0.0f && isfinite(zf)) {
+          uint32_t prim = fbid;
+          if (a.tex_res) prim = tfirst + texel_of(tres, w1 / num, w2 / num);
+          key = ((unsigned long long)__float_as_uint(zf) << 32) | prim;
+        }
+      }
+      // slot of this sample inside its tile's sub-rectangle
+      const int jx = x / kQW, jy = y / kQH;
+      const int xlo = max(X0, jx * kQW), ylo = max(Y0, jy * kQH), hy = min(Y1, jy * kQH + kQH - 1) - ylo + 1;
+      const int jt = (jx - tX0) * nty + (jy - tY0);
+      const uint32_t tb = jt == 0 ? sb0 : jt == 1 ? sb1 : jt == 2 ? sb2 : jt == 3 ? sb3 : jt == 4 ? sb4 : sb5;
+      const uint32_t slot = tb + (uint32_t)((x - xlo) * hy + (y - ylo));
+      const uint32_t tile = (uint32_t)jx * a.q.tiles_y + (uint32_t)jy;
+      if (!in_box || (SMESH_ABL(a.dbg) & 1)) continue;
+      if (slot < a.q.cap) {
+        const uint64_t e = ((uint64_t)tile * kQSub + sub) * a.q.cap + slot;
+        a.q.key[e] = key;
+        a.q.pix[e] = (uint16_t)((x - jx * kQW) * kQH + (y - jy * kQH));
+      } else if (key != kNullKey) {
+        atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
+        atomicOr(&a.q.flag[tile], 1u);
+      }
+    }
+}
+
 // MODE (an instance of the kernels per mode: the code of the other modes costs the small-triangle instance registers it does not
 // have -- k_raster_frag_group is held to 96 for five waves per SIMD): bit 0 = RasterArgs::wg_push, bit 1 = RasterArgs::spread.
 template <int MODE>
@@ -845,79 +929,51 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   // 3 x 2 tiles; in each the whole sub-rectangle is reserved with one atomic (a sample's slot is its position in
   // the sub-rectangle) and samples the triangle does not cover store the null key -- no per-fragment bookkeeping.
   // All reservations of the wave are issued first, by the owner lanes: one memory round trip, not one per triangle.
-  uint32_t rb0 = 0u, rb1 = 0u, rb2 = 0u, rb3 = 0u, rb4 = 0u, rb5 = 0u;   // queue bases of this lane's (<= 3 x 2) sub-rectangles
-  if (medium && !(SMESH_ABL(a.dbg) & 1)) {
-    const int tX0 = t.x0 / kQW, tY0 = t.y0 / kQH;
-    const int ntx = t.x1 / kQW - tX0 + 1, nty = t.y1 / kQH - tY0 + 1;
-    auto reserve = [&](int j) -> uint32_t {
-      if (j >= ntx * nty) return 0u;
-      const int jx = tX0 + j / nty, jy = tY0 + j % nty;
-      const int wx = min(t.x1, jx * kQW + kQW - 1) - max(t.x0, jx * kQW) + 1, hy = min(t.y1, jy * kQH + kQH - 1) - max(t.y0, jy * kQH) + 1;
-      return atomicAdd(&a.q.count[((uint32_t)jx * a.q.tiles_y + (uint32_t)jy) * kQSub + sub], (uint32_t)(wx * hy));
-    };
-    rb0 = reserve(0); rb1 = reserve(1); rb2 = reserve(2); rb3 = reserve(3); rb4 = reserve(4); rb5 = reserve(5);   // in flight together
+  // (balanced instances: those triangles go to the view's list instead and ANY wave walks them, below)
+  uint32_t rb[6] = {0u, 0u, 0u, 0u, 0u, 0u};   // queue bases of this lane's (<= 3 x 2) sub-rectangles
+  if constexpr (kWgPush) {
+    if (a.balance) {
+      // balanced: the triangle joins the view's list instead (one reservation per wave), k_raster_medium walks the list with the
+      // whole chip -- a view from inside the scene has all its medium triangles in a few waves (the near part of the mesh)
+      const unsigned long long m = __ballot(medium);
+      if (m != 0ull && !(SMESH_ABL(a.dbg) & 1)) {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(a.big_count + 4, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (medium) a.med_queue[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)f;    // (< big_capacity: a triangle is listed once)
+      }
+      return;
+    }
   }
+  if (medium && !(SMESH_ABL(a.dbg) & 1)) coop_reserve(a, t, sub, rb);     // all reservations of the wave first: one memory round trip
   unsigned long long todo = __ballot(medium);
   while (todo) {
     const int src = __ffsll((long long)todo) - 1;
     todo &= todo - 1ull;
-    auto bi = [&](int v) -> int { return __builtin_amdgcn_readlane(v, src); };
-    auto bd = [&](double v) -> double { return __hiloint2double(bi(__double2hiint(v)), bi(__double2loint(v))); };
-    const int X0 = bi(t.x0), X1 = bi(t.x1), Y0 = bi(t.y0), Y1 = bi(t.y1);
-    const double e0A = bd(t.e0.A), e0B = bd(t.e0.B), e0C = bd(t.e0.C);
-    const double e1A = bd(t.e1.A), e1B = bd(t.e1.B), e1C = bd(t.e1.C);
-    const double e2A = bd(t.e2.A), e2B = bd(t.e2.B), e2C = bd(t.e2.C);
-    const double iz0 = bd(t.iz0), iz1 = bd(t.iz1), iz2 = bd(t.iz2);
-    const int c0 = bi(t.cls0), c1 = bi(t.cls1), c2 = bi(t.cls2);
-    const uint32_t fb = (uint32_t)bi((int)(uint32_t)f);      // (the owner lane's triangle: lanes need not hold consecutive ones, see raster_frag_wave)
-    const uint32_t fbid = (uint32_t)bi((int)pid);
-    uint32_t tfirst = 0u, tres = 0u;
-    if (a.tex_res) { tfirst = a.tex_first[fb]; tres = a.tex_res[fb]; }
-    const int tX0 = X0 / kQW, tY0 = Y0 / kQH, nty = Y1 / kQH - tY0 + 1;
-    const uint32_t sb0 = (uint32_t)bi((int)rb0), sb1 = (uint32_t)bi((int)rb1), sb2 = (uint32_t)bi((int)rb2),
-                   sb3 = (uint32_t)bi((int)rb3), sb4 = (uint32_t)bi((int)rb4), sb5 = (uint32_t)bi((int)rb5);
-    const int bh = Y1 - Y0 + 1, area = (X1 - X0 + 1) * bh;
-    // i / bh as a multiplication: exact for bh <= kMedium = 64 and i < 2^26 (i * (m - 2^32 / bh) / 2^32 < 1 / bh); the two integer
-    // divisions per sample were a third of the loop's instructions
-    const uint32_t bh_rcp = bh > 1 ? 0xFFFFFFFFu / (uint32_t)bh + 1u : 0u;   // (bh = 1: the multiplier would be 2^32)
-    for (int i = lane; i < area + lane; i += 64) {   // every lane runs the same number of steps (readlane inside)
-      const bool in_box = i < area;
-      const int col = bh > 1 ? (int)__umulhi((uint32_t)i, bh_rcp) : i;
-      const int x = X0 + (in_box ? col : 0), y = Y0 + (in_box ? i - col * bh : 0);
-      const double px = (double)x + 0.5, py = (double)y + 0.5;
-      const double w0 = __builtin_fma(e0A, px, __builtin_fma(e0B, py, e0C));
-      const double w1 = __builtin_fma(e1A, px, __builtin_fma(e1B, py, e1C));
-      const double w2 = __builtin_fma(e2A, px, __builtin_fma(e2B, py, e2C));
-      const bool cov = edge_accepts(w0, c0) && edge_accepts(w1, c1) && edge_accepts(w2, c2);
-      unsigned long long key = kNullKey;
-      if (in_box && cov) {
-        const double num = (w0 + w1) + w2;
-        const double den = __builtin_fma(w2, iz2, __builtin_fma(w1, iz1, w0 * iz0));
-        const float zf = (float)(num / den);
-        if (zf > 0.0f && isfinite(zf)) {
-          uint32_t prim = fbid;
-          if (a.tex_res) prim = tfirst + texel_of(tres, w1 / num, w2 / num);
-          key = ((unsigned long long)__float_as_uint(zf) << 32) | prim;
-        }
-      }
-      // slot of this sample inside its tile's sub-rectangle
-      const int jx = x / kQW, jy = y / kQH;
-      const int xlo = max(X0, jx * kQW), ylo = max(Y0, jy * kQH), hy = min(Y1, jy * kQH + kQH - 1) - ylo + 1;
-      const int jt = (jx - tX0) * nty + (jy - tY0);
-      const uint32_t tb = jt == 0 ? sb0 : jt == 1 ? sb1 : jt == 2 ? sb2 : jt == 3 ? sb3 : jt == 4 ? sb4 : sb5;
-      const uint32_t slot = tb + (uint32_t)((x - xlo) * hy + (y - ylo));
-      const uint32_t tile = (uint32_t)jx * a.q.tiles_y + (uint32_t)jy;
-      if (!in_box || (SMESH_ABL(a.dbg) & 1)) continue;
-      if (slot < a.q.cap) {
-        const uint64_t e = ((uint64_t)tile * kQSub + sub) * a.q.cap + slot;
-        a.q.key[e] = key;
-        a.q.pix[e] = (uint16_t)((x - jx * kQW) * kQH + (y - jy * kQH));
-      } else if (key != kNullKey) {
-        atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
-        atomicOr(&a.q.flag[tile], 1u);
-      }
-    }
+    coop_walk(a, t, rb, src, f, pid, sub);
   }
+}
+
+// The view's list of medium triangles (RasterArgs::med_queue, filled by the balanced instances of k_raster_frag), a triangle per wave
+// and turn: every lane sets the triangle up for itself -- the same loads and arithmetic as its owner lane's, the same bits -- lane 0
+// reserves its tiles' sub-rectangles, the wave walks its box.
+__device__ __forceinline__ void raster_medium_wave(const RasterArgs& a, const uint32_t wave, const uint32_t nwaves) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t n = min(a.big_count[4], a.big_capacity);
+  for (uint32_t i = wave; i < n; i += nwaves) {
+    const uint32_t g = a.med_queue[i];
+    if (g >= a.F) continue;
+    const int32_t g0 = a.faces[3 * (uint64_t)g + 0], g1 = a.faces[3 * (uint64_t)g + 1], g2 = a.faces[3 * (uint64_t)g + 2];
+    Tri t;
+    if (load_tri_ex(a, g, t, g0, g1, g2) != 1) continue;            // (never: its owner lane found it drawable)
+    uint32_t rb[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    if (lane == 0) coop_reserve(a, t, i & (kQSub - 1), rb);
+    coop_walk(a, t, rb, 0, g, a.prim_id ? a.prim_id[g] : g, i & (kQSub - 1));
+  }
+}
+__global__ __launch_bounds__(256) void k_raster_medium(RasterArgs a) {
+  raster_medium_wave(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6);
 }
 
 // One wave = a.groups x a.tpw consecutive triangles (tpw: 64 for large meshes; fewer for small ones, so that the cooperative
@@ -960,7 +1016,7 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_raster_frag(RasterArgs a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? 4 : 5, 5))) void k_raster_frag(RasterArgs a) {
   raster_frag_wave<false, MODE>(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 }
 int raster_mode(const RasterArgs& a) { return (a.spread ? 3 : a.wg_push ? 1 : 0); }   // (spread views are views of medium triangles: wg_push too)
@@ -978,6 +1034,10 @@ template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? 4 : 5, 5))) void k_raster_frag_group(RasterGroup g) {
   const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
   raster_frag_wave<true, MODE>(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
+}
+__global__ __launch_bounds__(256) void k_raster_medium_group(RasterGroup g, uint32_t blocks_per_view) {
+  const uint32_t v = blockIdx.x / blocks_per_view;   // block-uniform
+  raster_medium_wave(g.view[v], ((blockIdx.x - v * blocks_per_view) * blockDim.x + threadIdx.x) >> 6, (blocks_per_view * blockDim.x) >> 6);
 }
 // The largest triangles (box over kMedium x kMedium) and the triangles that cross the near plane (clip_piece), between k_raster_frag
 // and k_tile_resolve: one workgroup per screen tile scans their queue, keeps those whose box overlaps the tile and shades the
@@ -1233,6 +1293,7 @@ struct smesh_renderer {
   struct ViewScratch {
     ScreenVertex* sv = nullptr;      // projected vertices [V]
     uint32_t* huge_queue = nullptr;  // [big_capacity] triangles larger than kMedium x kMedium
+    uint32_t* med_queue = nullptr;   // [big_capacity] RasterArgs::med_queue
     unsigned long long* keys = nullptr;   // global key image (direct path; overflow of the fragment queues)
     uint64_t keys_pixels = 0;
     FragQueues fq;                   // fragment-queue path: per-tile queues, sized for the largest image seen
@@ -1418,6 +1479,23 @@ double typical_edge_pixels(const smesh_renderer* r, const smesh_camera_t* cam) {
   const double e = b.mean_edge * std::max(std::fabs(cam->focal[0]), std::fabs(cam->focal[1])) / z;
   return std::isfinite(e) ? e : 0.0;
 }
+// How unevenly the mesh's triangles are sized in this view: farthest over nearest camera-space depth of the corners of the mesh's box
+// (+inf: the camera is inside or beside it).  An estimate like typical_edge_pixels: it only chooses between paths.  A ring camera
+// around BASELINE's meshes: 3 - 4; a camera above the surface looking along it: +inf.  1080p, one render(): 90 000 triangles from inside
+// 0.433 ms with the triangles a wave walks one at a time left to their waves, 0.205 through k_raster_medium; the same mesh from
+// outside 0.092 / 0.092, 10 000 triangles from outside 0.100 / 0.103 (eight views per launch: 0.079 / 0.087).
+double depth_spread(const smesh_renderer* r, const smesh_camera_t* cam) {
+  const smesh_renderer::Bounds& b = r->bounds;
+  if (!b.valid) return 1.0;
+  double zmin = INFINITY, zmax = -INFINITY;
+  for (int c = 0; c < 8; c++) {
+    double z = cam->translation[2];
+    for (int d = 0; d < 3; d++) z += (double)cam->rotation[6 + d] * ((c >> d) & 1 ? b.hi[d] : b.lo[d]);
+    zmin = std::min(zmin, z); zmax = std::max(zmax, z);
+  }
+  if (!(zmax > 0.0)) return 1.0;          // (behind the camera altogether)
+  return zmin > 1e-3 * zmax ? zmax / zmin : INFINITY;
+}
 // Spread waves (raster_frag_wave) for this launch?  SMESH_RASTER_SPREAD=0 / 1 forces; else for ONE view whose typical edge measures
 // 10.5 .. 19 pixels (boxes of 9 .. 24).  1080p, one render() at a time, ms (lanes walking their own boxes in rounds / spread waves;
 // NOTES/round5.md 11): 25 600 triangles 0.129 / 0.092, 40 000 0.146 / 0.084, 62 500 0.128 / 0.095 -- 19 600 (a fifth of the boxes
@@ -1440,6 +1518,11 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   a.keys = vs.keys; a.F = r->F; a.V = r->V; a.W = (uint32_t)W; a.H = (uint32_t)H;
   a.big_queue = r->side[side].big_queue; a.big_count = r->side[side].big_count; a.big_capacity = r->big_capacity;
   a.huge_queue = vs.huge_queue;
+  a.med_queue = vs.med_queue;
+  {   // SMESH_RASTER_BALANCE=0 / 1 forces; else for views from inside or close to the scene (depth_spread)
+    static const int knob = getenv("SMESH_RASTER_BALANCE") ? atoi(getenv("SMESH_RASTER_BALANCE")) : -1;
+    a.balance = (vs.med_queue && (knob >= 0 ? knob != 0 : (cam && depth_spread(r, cam) > 6.0))) ? 1u : 0u;
+  }
   a.frags = r->side[side].frags;
   a.kinds = r->side[side].kinds;
   { static const int rdbg = SMESH_ABL_ENV("SMESH_RDBG"); a.dbg = rdbg; }
@@ -1495,7 +1578,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
                        r->side[side].big_count);
     SMESH_HIP(hipGetLastError());
   } else {
-    SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 16, st));
+    SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 32, st));
   }
   if (r->F) {
     RasterArgs a = raster_args(r, vs, side, W, H, 1, cam);
@@ -1511,6 +1594,8 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
           case 1:  hipLaunchKernelGGL(k_raster_frag<1>, grid, dim3(256), 0, st, a); break;
           default: hipLaunchKernelGGL(k_raster_frag<0>, grid, dim3(256), 0, st, a); break;
         }
+        if (raster_mode(a) != 0 && a.balance)     // the list the balanced instances left: four waves per SIMD's worth of waves walk it
+          hipLaunchKernelGGL(k_raster_medium, dim3(4u * (uint32_t)std::max(1, ctx->num_cus)), dim3(256), 0, st, a);
       }
       SMESH_HIP(hipGetLastError());
       const uint32_t ntiles = (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
@@ -1541,6 +1626,7 @@ hipError_t alloc_scratch(smesh_renderer* r, int i) {
   hipError_t e = hipSuccess;
   if (!vs.sv) e = dev_malloc(reinterpret_cast<void**>(&vs.sv), std::max<uint64_t>(r->V * sizeof(ScreenVertex), 16));
   if (e == hipSuccess && !vs.huge_queue) e = dev_malloc(reinterpret_cast<void**>(&vs.huge_queue), (size_t)r->big_capacity * 4);
+  if (e == hipSuccess && !vs.med_queue) e = dev_malloc(reinterpret_cast<void**>(&vs.med_queue), (size_t)r->big_capacity * 4);
   return e;
 }
 
@@ -1606,7 +1692,7 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     pg.sv[v] = vs.sv;
     pg.big_count[v] = r->side[side_base + v].big_count;
     rg.view[v] = raster_args(r, vs, side_base + v, W, H, n);
-    rg.view[v].wg_push = raster_args(r, vs, side_base + v, W, H, 1, &cams[v]).wg_push;
+    { const RasterArgs own = raster_args(r, vs, side_base + v, W, H, 1, &cams[v]); rg.view[v].wg_push = own.wg_push; rg.view[v].balance = own.balance; }
     rg.view[v].cam = pg.cam[v];
     rg.view[v].q = vs.fq;
     rg.idx[v] = static_cast<uint32_t*>(r->fused[side_base + v].ptr);
@@ -1624,6 +1710,9 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     int push_votes = 0;
     for (int v = 0; v < n; v++) push_votes += rg.view[v].wg_push ? 1 : 0;
     for (int v = 0; v < n; v++) rg.view[v].wg_push = 2 * push_votes >= n && push_votes > 0 ? 1u : 0u;
+    int balance_votes = 0;
+    for (int v = 0; v < n; v++) balance_votes += rg.view[v].balance ? 1 : 0;
+    for (int v = 0; v < n; v++) rg.view[v].balance = 2 * balance_votes >= n && balance_votes > 0 ? 1u : 0u;
   }
   for (int v = 0; v < n; v++) rg.view[v].groups = frag_groups(r->F, n, rg.view[0].tpw);
   rg.blocks_per_view = (uint32_t)div_up(div_up(r->F, rg.view[0].tpw * rg.view[0].groups), 4);
@@ -1639,6 +1728,10 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
       case 3:  hipLaunchKernelGGL(k_raster_frag_group<3>, grid, dim3(256), pad, st, rg); break;
       case 1:  hipLaunchKernelGGL(k_raster_frag_group<1>, grid, dim3(256), pad, st, rg); break;
       default: hipLaunchKernelGGL(k_raster_frag_group<0>, grid, dim3(256), pad, st, rg); break;
+    }
+    if (raster_mode(rg.view[0]) != 0 && rg.view[0].balance) {
+      const uint32_t per_view = std::max(64u, 4u * (uint32_t)std::max(1, ctx->num_cus) / (uint32_t)n);
+      hipLaunchKernelGGL(k_raster_medium_group, dim3((uint32_t)n * per_view), dim3(256), 0, st, rg, per_view);
     }
   }
   SMESH_HIP(hipGetLastError());
@@ -1688,10 +1781,10 @@ hipError_t alloc_side(smesh_renderer* r, int i) {
   smesh_renderer::Side& sd = r->side[i];
   if (sd.frags) return hipSuccess;
   hipError_t e = dev_malloc(reinterpret_cast<void**>(&sd.big_queue), (size_t)r->big_capacity * 8);   // (upper half: the medium triangles again, push_mid)
-  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&sd.big_count), 16);
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&sd.big_count), 32);
   if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&sd.frags), std::max<uint64_t>(r->F * sizeof(TriFrag), 16));
   if (e == hipSuccess && r->texels) e = dev_malloc(reinterpret_cast<void**>(&sd.kinds), std::max<uint64_t>(r->F, 16));
-  if (e == hipSuccess) e = hipMemsetAsync(sd.big_count, 0, 16, r->ctx->stream);
+  if (e == hipSuccess) e = hipMemsetAsync(sd.big_count, 0, 32, r->ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(r->ctx->stream);
   return e;
 }
@@ -1800,6 +1893,7 @@ int create_common(const float* vertices, uint64_t V, const int32_t* faces, uint6
   if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&r->vs[0].sv), std::max<uint64_t>(V * sizeof(ScreenVertex), 16));
   if (e == hipSuccess) e = alloc_side(r, 0);
   if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&r->vs[0].huge_queue), (size_t)r->big_capacity * 4);
+  if (e == hipSuccess) e = dev_malloc(reinterpret_cast<void**>(&r->vs[0].med_queue), (size_t)r->big_capacity * 4);
   if (e == hipSuccess && V) e = hipMemcpyAsync(r->verts, vertices, V * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess && F) e = hipMemcpyAsync(r->faces, faces, F * 12, hipMemcpyHostToDevice, ctx->stream);
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -2050,7 +2144,7 @@ int smesh_renderer_destroy(smesh_renderer_t* r) {
     for (void* p : {(void*)sd.big_queue, (void*)sd.big_count, (void*)sd.frags, (void*)sd.kinds})
       if (p) (void)dev_free(p);
   for (auto& vs : r->vs)
-    for (void* p : {(void*)vs.sv, (void*)vs.huge_queue, (void*)vs.keys, (void*)vs.fq.key, (void*)vs.fq.pix, (void*)vs.fq.count, (void*)vs.fq.flag})
+    for (void* p : {(void*)vs.sv, (void*)vs.huge_queue, (void*)vs.med_queue, (void*)vs.keys, (void*)vs.fq.key, (void*)vs.fq.pix, (void*)vs.fq.count, (void*)vs.fq.flag})
       if (p) (void)dev_free(p);
   for (auto& im : r->images) { (void)dev_free(im.idx); (void)dev_free(im.depth); }
   r->own_idx.release();
