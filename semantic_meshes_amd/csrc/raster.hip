@@ -1506,6 +1506,7 @@ bool want_spread(const smesh_renderer* r, const smesh_camera_t* cam, int nviews)
   if (knob == 0 || !cam) return false;
   if (knob == 1) return true;
   if (nviews > 1) return false;
+  if (depth_spread(r, cam) > 6.0) return false;     // (a view from inside: the estimate says nothing about most of its triangles)
   const double e = typical_edge_pixels(r, cam);
   return e >= 10.5 && e <= 19.0;
 }
