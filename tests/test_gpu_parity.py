@@ -656,7 +656,7 @@ def test_render_fragment_queue_overflow(sm, oracle, monkeypatch, cap):
 
 @pytest.mark.parametrize("knob", ["SMESH_RASTER=direct", "SMESH_FUSE=strip", "SMESH_FUSE_WIDE=0",
                                   "SMESH_RASTER_PAIRS=0", "SMESH_FUSE_PAIRS=0", "SMESH_GROUP_PIPELINE=0", "SMESH_TEXEL_MULTI=0",
-                                  "SMESH_RASTER_SPREAD=1", "SMESH_RASTER_WG_PUSH=1"])
+                                  "SMESH_RASTER_SPREAD=1", "SMESH_RASTER_WG_PUSH=1", "SMESH_RASTER_BALANCE=1 SMESH_RASTER_WG_PUSH=1"])
 def test_alternative_paths_in_subprocess(knob):
     """These knobs are read once per process: re-run the render / fuse_view parity tests with the direct rasteriser
     (global 64-bit atomicMin per fragment), with the group pipeline off (the default since round 5 is on), and with the generic
@@ -664,8 +664,9 @@ def test_alternative_paths_in_subprocess(knob):
     import os
     import subprocess
     import sys
-    k, v = knob.split("=")
-    env = dict(os.environ, **{k: v})
+    pairs = [kv.split("=") for kv in knob.split()]
+    k, v = pairs[0]
+    env = dict(os.environ, **{kk: vv for kk, vv in pairs})
     here = os.path.dirname(os.path.abspath(__file__))
     sel = "render_small_scene or render_cfg1 or overlap or mixed_triangle or texel or fuse_view_cfg2"
     if k != "SMESH_FUSE":
@@ -674,7 +675,7 @@ def test_alternative_paths_in_subprocess(knob):
         sel = "fuse_views" if k.endswith("PAIRS") else sel + " or fuse_views"
     if k == "SMESH_RASTER":
         sel += " or near_plane or room"      # the direct rasteriser clips at the near plane too
-    if k in ("SMESH_RASTER_SPREAD", "SMESH_RASTER_WG_PUSH"):
+    if k in ("SMESH_RASTER_SPREAD", "SMESH_RASTER_WG_PUSH", "SMESH_RASTER_BALANCE"):     # (BALANCE: every cooperatively walked triangle through k_raster_medium)
         # the rasteriser's modes for views of medium triangles, forced on every view (spread waves: a triangle on nine lanes; the
         # view's queues filled by one atomic per workgroup): every kind of triangle through them, single views and groups
         sel += " or near_plane or medium or fuse_views or degenerate"
