@@ -292,7 +292,9 @@ struct RasterArgs {
                               // its length: big_count[4]
   uint32_t balance;           // k_raster_frag (wg_push instances): nonzero = the triangles a wave would walk one at a time (boxes beyond the
                               // lanes' reach, up to kMedium) go to med_queue and k_raster_medium walks that list with the whole
-                              // chip: a view from inside the scene has them all in a few waves (the near part of the mesh)
+                              // chip: a view from inside the scene has them all in a few waves (the near part of the mesh);
+                              // 2 (one view per launch) = so do the triangles the lanes would walk in rounds (boxes of 9 ..
+                              // kLaneBox pixels; from the far end of med_queue, count in big_count[5]): seven per wave and turn
   uint32_t wg_push;           // k_raster_frag: nonzero = the workgroup's four waves share each atomic on the view's queues (views of mostly medium
                               // triangles: every wave pushes, and increments of ONE counter pass the L2 at ~5 ns each); 0 = one per wave
   uint32_t spread;            // k_raster_frag: nonzero = a triangle takes kSpread consecutive lanes, one per 8 x 8 sub-box of its (at most
@@ -802,11 +804,11 @@ __device__ __forceinline__ void coop_walk(const RasterArgs& a, const Tri& t, con
 // have -- k_raster_frag_group is held to 96 for five waves per SIMD): bit 0 = RasterArgs::wg_push, bit 1 = RasterArgs::spread.
 template <int MODE>
 __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64_t f, const int32_t i0, const int32_t i1, const int32_t i2,
-                                               const uint32_t sub, const int part_in = -1) {
+                                               const uint32_t sub, const int part_in = -1, const bool listed = false) {
   constexpr bool kWgPush = (MODE & 1) != 0, kSpreadMode = (MODE & 2) != 0;
   const int lane = threadIdx.x & 63;
   const int part = kSpreadMode ? part_in : -1;
-  const bool owner = part <= 0;
+  const bool owner = part <= 0 && !listed;    // (listed: a triangle from the view's list, k_raster_medium -- its owner lane left its record and queue entries)
   TriFrag rec;
   rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
   Tri t;
@@ -911,6 +913,21 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   // ---- boxes over 8 x 8 up to kLaneBox x kLaneBox: this lane's sub-boxes, one per round (wave-uniform trip count) -- where the wave
   // holds enough of them: a round costs what a whole small-triangle pass costs (~2 200 instructions) however many lanes take part,
   // the cooperative loop ~350 - 450 per triangle, so a wave with fewer than kLaneBoxMin such triangles hands them to that loop
+  if constexpr (kWgPush && !kSpreadMode) {
+    if (a.balance >= 2u) {
+      // balanced, one view per launch: these triangles join the view's list too (from its far end; count in big_count[5]) and k_raster_medium walks them
+      // seven to a wave, a lane per sub-box -- the waves of the middle distance of a view from inside held 64 of them each
+      const unsigned long long m = __ballot(lanebox);
+      if (m != 0ull && !(SMESH_ABL(a.dbg) & 1)) {
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0u;
+        if (lane == leader) base = atomicAdd(a.big_count + 5, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, leader);
+        if (lanebox) a.med_queue[a.big_capacity - 1u - (base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)))] = (uint32_t)f;
+      }
+      lanebox = false;
+    }
+  }
   if ((int)__popcll(__ballot(lanebox)) < kLaneBoxMin) { medium = medium || lanebox; lanebox = false; }
   if (__ballot(lanebox) != 0ull && !(SMESH_ABL(a.dbg) & 1)) {
     constexpr int kSub = kLaneBox / 8;
@@ -970,6 +987,19 @@ __device__ __forceinline__ void raster_medium_wave(const RasterArgs& a, const ui
     uint32_t rb[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     if (lane == 0) coop_reserve(a, t, i & (kQSub - 1), rb);
     coop_walk(a, t, rb, 0, g, a.prim_id ? a.prim_id[g] : g, i & (kQSub - 1));
+  }
+  // ... and the listed triangles with boxes of 9 .. kLaneBox pixels (from the far end of the list), seven per wave and turn: a spread wave
+  constexpr int kLanes = kSpread, kTris = kSpreadTris;
+  const uint32_t nl = min(a.big_count[5], a.big_capacity);
+  const uint32_t turns = (nl + (uint32_t)kTris - 1u) / (uint32_t)kTris;
+  for (uint32_t i = wave; i < turns; i += nwaves) {
+    const int tri = lane / kLanes;
+    const uint32_t e = i * (uint32_t)kTris + (uint32_t)tri;
+    uint64_t fs = a.F;
+    if (tri < kTris && e < nl) fs = a.med_queue[a.big_capacity - 1u - e];
+    int32_t s0 = 0, s1 = 0, s2 = 0;
+    if (fs < a.F) { s0 = a.faces[3 * fs + 0]; s1 = a.faces[3 * fs + 1]; s2 = a.faces[3 * fs + 2]; }
+    raster_frag_64<2>(a, fs, s0, s1, s2, i & (kQSub - 1), lane % kLanes, true);
   }
 }
 __global__ __launch_bounds__(256) void k_raster_medium(RasterArgs a) {
@@ -1522,7 +1552,7 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   a.med_queue = vs.med_queue;
   {   // SMESH_RASTER_BALANCE=0 / 1 forces; else for views from inside or close to the scene (depth_spread)
     static const int knob = getenv("SMESH_RASTER_BALANCE") ? atoi(getenv("SMESH_RASTER_BALANCE")) : -1;
-    a.balance = (vs.med_queue && (knob >= 0 ? knob != 0 : (cam && depth_spread(r, cam) > 6.0))) ? 1u : 0u;
+    a.balance = (vs.med_queue && (knob >= 0 ? knob != 0 : (cam && depth_spread(r, cam) > 6.0))) ? (nviews > 1 ? 1u : 2u) : 0u;
   }
   a.frags = r->side[side].frags;
   a.kinds = r->side[side].kinds;
@@ -1713,7 +1743,7 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     for (int v = 0; v < n; v++) rg.view[v].wg_push = 2 * push_votes >= n && push_votes > 0 ? 1u : 0u;
     int balance_votes = 0;
     for (int v = 0; v < n; v++) balance_votes += rg.view[v].balance ? 1 : 0;
-    for (int v = 0; v < n; v++) rg.view[v].balance = 2 * balance_votes >= n && balance_votes > 0 ? 1u : 0u;
+    for (int v = 0; v < n; v++) rg.view[v].balance = 2 * balance_votes >= n && balance_votes > 0 ? (n > 1 ? 1u : 2u) : 0u;
   }
   for (int v = 0; v < n; v++) rg.view[v].groups = frag_groups(r->F, n, rg.view[0].tpw);
   rg.blocks_per_view = (uint32_t)div_up(div_up(r->F, rg.view[0].tpw * rg.view[0].groups), 4);
