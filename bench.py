@@ -294,6 +294,73 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
             "what": "add(device copy of a render, device probs), one call per view, %d views, host-timed" % views}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` with N > 1 and no launcher (no RANK in the environment): this process becomes the launcher -- N
+    ranks of this very command line, one per GPU (RANK = LOCAL_RANK = device, WORLD_SIZE = N, rendezvous on 127.0.0.1), exactly the
+    environment `python -m torch.distributed.run --nproc-per-node N` would have given them.  Rank 0 prints the one JSON line on this
+    process's stdout.  Fails loudly when the node has fewer than N GPUs (SMESH_BENCH_BACKEND=gloo, the test mode in which ranks share
+    GPUs, excepted).  Returns the exit status for the whole job."""
+    import signal
+    import socket
+    import subprocess
+    backend = os.environ.get("SMESH_BENCH_BACKEND", "nccl")
+    have = _lib.device_count()
+    if have < 1:
+        raise SystemExit("bench: no HIP device visible -- the product has no CPU path")
+    if have < n and backend != "gloo":
+        raise SystemExit("bench: --gpus %d but this node shows %d GPU(s); one rank per GPU (RCCL refuses two ranks on a device)" % (n, have))
+    # a base port with the rendezvous port and the native bootstrap's range (MASTER_PORT + 317 ...) free right now
+    port = None
+    for _ in range(64):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            cand = s.getsockname()[1]
+        if cand + 317 + 8 >= 65536:
+            continue
+        ok = True
+        for p in (cand, cand + 317):
+            try:
+                with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+                    s.bind(("127.0.0.1", p))
+            except OSError:
+                ok = False
+        if ok:
+            port = cand
+            break
+    if port is None:
+        raise SystemExit("bench: no free rendezvous port on 127.0.0.1")
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), GROUP_RANK="0",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SMESH_BENCH_SPAWNED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        # ranks other than 0 print nothing on stdout by contract; whatever they do print must not reach the driver's JSON parser
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr, start_new_session=False))
+    status = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0 and status == 0:
+                    status = rc if rc > 0 else 128 - rc
+                    print("bench: rank %d exited with status %d; stopping the other ranks" % (procs.index(p), rc), file=sys.stderr, flush=True)
+                    for q in pending:          # (exactly the processes started above, by PID)
+                        q.send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.send_signal(signal.SIGTERM)
+        status = 130
+    return status
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +391,13 @@ def main():
                     help="the K-step timed region (barrier, K steps, exchange, barrier) is run this many times; `value` is the MEDIAN region, "
                          "config.repeats / value_min / value_max say how far the others were")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be at least 1")
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # no launcher: be the launcher (VERDICT r5 next 2 -- a plain `python bench.py --gpus 8` used to run ONE rank and print n_gpus 1)
+        raise SystemExit(spawn_ranks(args.gpus))
+    if "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit("bench: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ.get("WORLD_SIZE", "1")))
     if args.group_pipeline is not None:
         _lib.check(_lib.lib().smesh_set_option(b"group_pipeline", 1 if args.group_pipeline else 0))
     gp = ctypes.c_int64(0)
@@ -612,6 +686,8 @@ def main():
         nranks_reported = int(nr.value)        # what the RCCL communicator itself spans
     elif dist is not None:
         nranks_reported = dist.get_world_size()
+    if nranks_reported != args.gpus:
+        raise SystemExit("bench: --gpus %d but the process group spans %d rank(s)" % (args.gpus, nranks_reported))
 
     fuse_kernel = _lib.lib().smesh_last_fuse_kernel().decode()
     k_ms, k_regions, k_launches, k_views = prof_read(device, _lib.PROF_FUSE_SCATTER)
@@ -697,7 +773,7 @@ def main():
                                                                                    ", %d texel primitives" % P if texels else "")),
             "value": round(world * args.steps / dt, 2),            # the MEDIAN of `repeats` timed regions
             "unit": "views/s",
-            "n_gpus": world,
+            "n_gpus": nranks_reported,          # what the communicator / process group spans (== --gpus, checked above)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 4),

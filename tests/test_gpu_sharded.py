@@ -264,6 +264,35 @@ def test_bench_line_of_a_two_rank_run(tmp_path, sm, exchange):
     assert "cpu_baseline" not in d and ((d["roofline"]["frac"] or 0) > 0 or exchange == "allreduce")   # (cut fusion launches are not bracketed)
 
 
+def test_bench_gpus_two_without_a_launcher_spawns_two_ranks(tmp_path, sm):
+    """`python bench.py --gpus 2` started PLAINLY (no torch.distributed.run, no RANK in the environment -- the way the driver starts
+    `--gpus 1`): the script is its own launcher (bench.spawn_ranks) and the line says two ranks -- n_gpus and config.nranks come from the
+    process group, not from the flag.  (this command used to run one rank and print n_gpus 1.)  On the one-GPU box
+    SMESH_BENCH_BACKEND=gloo lets the two ranks share the device; without it the script must refuse, loudly, to start two RCCL ranks
+    on one GPU."""
+    import json
+    from semantic_meshes_amd import _lib
+    env = dict(os.environ, SMESH_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SMESH_EXCHANGE"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--workload", "cfg1"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["nranks"] == 2 and d["steps"] == 12 and d["value"] > 0
+    assert d["config"]["allreduce_bytes"] == 4 * 10000 * 5 and d["config"]["exchange_parts"] == 4
+    if _lib.device_count() < 2:
+        env.pop("SMESH_BENCH_BACKEND")
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        assert out.returncode != 0 and "one rank per GPU" in out.stderr and '{"metric"' not in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
+    # a launcher whose world size contradicts --gpus is refused too
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", SMESH_BENCH_BACKEND="gloo")
+    out = subprocess.run(cmd, env=env2, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert out.returncode != 0 and "WORLD_SIZE=1" in out.stderr, out.stderr[-1500:]
+
+
 def test_fuse_views_ranged_equals_fuse_views_bit_for_bit(sm):
     """`fuse_views_ranged` (smesh_fuse_views_begin / _continue) cuts the job by accumulator row range: per row the same float32
     additions in the same order as `fuse_views` -- raw accumulators bit-equal for Sum, Summax and Mul, for part counts that do and do
