@@ -200,7 +200,7 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
   }
   if (n > 1) SMESH_RCCL(r, r->GroupStart());
   int status = SMESH_OK;
-  std::vector<char> reduced((size_t)n, 0);   // the collective of pair i was issued: its epilogue (Mul: float64 image -> (hi, lo) pairs) is due
+  std::vector<char> reduced((size_t)n, 0);   // pair i's exchange was begun (Mul: its rows now sit in the float64 image): its epilogue is due whatever happens next
   for (int i = 0; i < n && status == SMESH_OK; i++) {
     std::lock_guard<std::mutex> g(smesh_aggregator_mutex(aggs[i]));
     DeviceCtx* ctx = comms[i]->ctx;
@@ -217,10 +217,10 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
     const uint64_t P = smesh_aggregator_primitives(aggs[i]);
     if (status == SMESH_OK) status = smesh_aggregator_exchange_begin(aggs[i], 0, P, ctx->stream, &buf, &count, &f64);
     if (status != SMESH_OK || count == 0) continue;
+    reduced[(size_t)i] = 1;
     ProfScope prof(ctx, SMESH_PROF_EXCHANGE);
     const ncclResult_t e = r->AllReduce(buf, buf, (size_t)count, f64 ? ncclFloat64 : ncclFloat32, ncclSum, comms[i]->comm, ctx->stream);
     if (e != ncclSuccess) status = fail_rccl(r, e, "ncclAllReduce");
-    else reduced[(size_t)i] = 1;
   }
   if (n > 1) {
     const ncclResult_t e = r->GroupEnd();
@@ -228,14 +228,19 @@ int smesh_allreduce(smesh_comm_t* const* comms, smesh_aggregator_t* const* aggs,
   }
   // The epilogues go on the streams only now: inside a group a collective is put on its stream by ncclGroupEnd, so an epilogue
   // launched beside its ncclAllReduce call would run AHEAD of the reduction and write this device's own partial sums back
-  // (a grouped Mul all-reduce returned unreduced data without an error).
-  for (int i = 0; i < n && status == SMESH_OK; i++) {
+  // (a grouped Mul all-reduce returned unreduced data without an error).  They run for EVERY pair whose exchange was
+  // begun, also when another pair or ncclGroupEnd failed: a Mul aggregator left in its float64 image would be unusable;
+  // the first error is the one reported.
+  for (int i = 0; i < n; i++) {
     if (!reduced[(size_t)i]) continue;
     std::lock_guard<std::mutex> g(smesh_aggregator_mutex(aggs[i]));
     DeviceCtx* ctx = comms[i]->ctx;
     std::lock_guard<std::recursive_mutex> lock(ctx->mu);
-    if (hipSetDevice(ctx->device) != hipSuccess) { status = fail(SMESH_ERR_RUNTIME, "hipSetDevice failed"); break; }
-    status = smesh_aggregator_exchange_end(aggs[i], 0, smesh_aggregator_primitives(aggs[i]), ctx->stream);
+    if (hipSetDevice(ctx->device) != hipSuccess) { if (status == SMESH_OK) status = fail(SMESH_ERR_RUNTIME, "hipSetDevice failed"); continue; }
+    const std::string first = smesh_last_error();
+    const int e = smesh_aggregator_exchange_end(aggs[i], 0, smesh_aggregator_primitives(aggs[i]), ctx->stream);
+    if (status == SMESH_OK) status = e;
+    else (void)fail(status, first);          // (keep the first failure's message)
   }
   return status;
 }

@@ -79,7 +79,8 @@ void prof_note(DeviceCtx* ctx, int slot, uint64_t launches, uint64_t views);
 // Device memory of the library: hipMalloc / hipFree with a cache of still-mapped blocks in between (context.cpp: why).
 // dev_malloc allocates on the CURRENT device; the contents of a block are unspecified; dev_free returns when the device is idle.
 hipError_t dev_malloc(void** out, size_t bytes);
-hipError_t dev_free(void* p);
+hipError_t dev_free(void* p, bool foreign = false);   // foreign: the caller could see the block -- wait for the whole device
+uint64_t dev_cached_bytes(int device);
 void dev_trim(int device);
 void dev_cache_stats(uint64_t* live_blocks, uint64_t* cached_blocks, uint64_t* cached_bytes);
 

@@ -42,6 +42,12 @@ bool opt_group_pipeline() {
 static std::mutex g_ctx_mu;
 static std::vector<std::unique_ptr<DeviceCtx>> g_ctx;
 
+// The context of `device` if one exists already (never creates one).
+DeviceCtx* peek_ctx(int device) {
+  std::lock_guard<std::mutex> lock(g_ctx_mu);
+  return (device >= 0 && device < (int)g_ctx.size()) ? g_ctx[device].get() : nullptr;
+}
+
 int get_ctx(int device, DeviceCtx** out) {
   std::lock_guard<std::mutex> lock(g_ctx_mu);
   int n = 0;
@@ -119,15 +125,15 @@ ProfScope::~ProfScope() {
 // one process alone never does, and memory that stays mapped never does.  That was round 4's "unexplained failure": an eighth of a
 // class-vector image read as don't-care pixels.  So device blocks freed by the library's handles and by smesh_device_free go to a
 // per-process cache (still mapped) and are handed out again for requests of the same size class; smesh_device_trim() or the cap
-// (SMESH_ALLOC_CACHE_MB, default a quarter of the device's memory, at most 64 GiB; 0 = plain hipMalloc / hipFree) unmaps them.
-// dev_free keeps hipFree's ordering contract: it returns when the device is idle, so nothing queued still uses the block.
+// (SMESH_ALLOC_CACHE_MB per device, default a sixteenth of the device's memory, at most 8 GiB; 0 = plain hipMalloc / hipFree) unmaps them.
+// dev_free keeps hipFree's ordering contract for the work that can touch the block: nothing queued still uses it on return.
 namespace {
 struct DevBlock { int device; size_t bytes; };
 struct CachedBlock { void* ptr; int device; unsigned long long stamp; };
 std::mutex g_alloc_mu;
 std::unordered_map<void*, DevBlock> g_live;                 // handed out: size class of the block
 std::multimap<size_t, CachedBlock> g_cached;                // free, still mapped: size class -> block
-size_t g_cached_bytes = 0;
+std::map<int, size_t> g_cached_bytes;                       // per device: bytes held in g_cached
 unsigned long long g_alloc_stamp = 0;
 
 size_t size_class(size_t n) {
@@ -135,28 +141,49 @@ size_t size_class(size_t n) {
   const size_t g = n <= (1u << 20) ? (size_t)4096 : (size_t)2 << 20;
   return (n + g - 1) / g * g;
 }
-size_t cache_cap() {
-  static const size_t cap = [] {
-    if (const char* e = getenv("SMESH_ALLOC_CACHE_MB")) return (size_t)std::max(0ll, atoll(e)) << 20;
-    size_t free_b = 0, total = 0;
-    if (hipMemGetInfo(&free_b, &total) != hipSuccess) { (void)hipGetLastError(); total = (size_t)64 << 30; }
-    return std::min<size_t>(total / 4, (size_t)64 << 30);
-  }();
-  return cap;
-}
-// (g_alloc_mu held) really frees cached blocks, oldest first, until `need` more bytes fit under `cap`
-void evict_locked(size_t need, size_t cap) {
-  while (!g_cached.empty() && g_cached_bytes + need > cap) {
-    auto oldest = g_cached.begin();
-    for (auto it = g_cached.begin(); it != g_cached.end(); ++it)
-      if (it->second.stamp < oldest->second.stamp) oldest = it;
+// The cap is PER DEVICE (one cap sized from whichever device was current first was shared by all of them): what the
+// library reallocates again and again -- record sets, fragment queues, scratch, index planes, a cfg2-sized accumulator -- fits in a
+// few GiB; a destroyed 12 GB cfg5 accumulator is larger than the cap and really freed, so that other allocators of the process
+// (torch, cupy) find the memory.  smesh_device_trim() gives back the rest on request.
+size_t cache_cap(int device) {
+  static std::map<int, size_t> caps;          // (g_alloc_mu held)
+  auto it = caps.find(device);
+  if (it != caps.end()) return it->second;
+  size_t cap;
+  if (const char* e = getenv("SMESH_ALLOC_CACHE_MB")) cap = (size_t)std::max(0ll, atoll(e)) << 20;
+  else {
     int cur = 0;
     (void)hipGetDevice(&cur);
-    if (cur != oldest->second.device) (void)hipSetDevice(oldest->second.device);
-    (void)hipFree(oldest->second.ptr);
-    if (cur != oldest->second.device) (void)hipSetDevice(cur);
-    g_cached_bytes -= oldest->first;
-    g_cached.erase(oldest);
+    if (cur != device) (void)hipSetDevice(device);
+    size_t free_b = 0, total = 0;
+    if (hipMemGetInfo(&free_b, &total) != hipSuccess) { (void)hipGetLastError(); total = (size_t)64 << 30; }
+    if (cur != device) (void)hipSetDevice(cur);
+    cap = std::min<size_t>(total / 16, (size_t)8 << 30);
+  }
+  caps[device] = cap;
+  return cap;
+}
+void really_free_locked(std::multimap<size_t, CachedBlock>::iterator it) {
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (cur != it->second.device) (void)hipSetDevice(it->second.device);
+  (void)hipFree(it->second.ptr);
+  if (cur != it->second.device) (void)hipSetDevice(cur);
+  g_cached_bytes[it->second.device] -= it->first;
+  g_cached.erase(it);
+}
+// (g_alloc_mu held) really frees cached blocks of `device` (-1: any device), oldest first, until `need` more bytes fit under `cap`
+void evict_locked(int device, size_t need, size_t cap) {
+  for (;;) {
+    size_t held = 0;
+    if (device >= 0) held = g_cached_bytes[device];
+    else for (auto& kv : g_cached_bytes) held += kv.second;
+    if (held == 0 || held + need <= cap) return;
+    auto oldest = g_cached.end();
+    for (auto it = g_cached.begin(); it != g_cached.end(); ++it)
+      if ((device < 0 || it->second.device == device) && (oldest == g_cached.end() || it->second.stamp < oldest->second.stamp)) oldest = it;
+    if (oldest == g_cached.end()) return;
+    really_free_locked(oldest);
   }
 }
 }  // namespace
@@ -172,49 +199,71 @@ hipError_t dev_malloc(void** out, size_t bytes) {
     if (it->second.device != dev) continue;
     *out = it->second.ptr;
     g_live[*out] = DevBlock{dev, it->first};
-    g_cached_bytes -= it->first;
+    g_cached_bytes[dev] -= it->first;
     g_cached.erase(it);
     return hipSuccess;
   }
   e = hipMalloc(out, sz);
-  if (e != hipSuccess) {      // out of memory: give back what the cache holds and try once more
+  if (e != hipSuccess) {      // out of memory: give back what the cache holds on this device and try once more
     (void)hipGetLastError();
-    evict_locked(0, 0);
+    evict_locked(dev, 0, 0);
     e = hipMalloc(out, sz);
   }
   if (e == hipSuccess) g_live[*out] = DevBlock{dev, sz};
   return e;
 }
 
-hipError_t dev_free(void* p) {
+// `foreign`: the block was visible to the caller (smesh_device_malloc, exported planes) and may have been used on streams the
+// library knows nothing about -- wait for the whole device, as hipFree would.  Blocks only the library's handles ever touched
+// (scratch, queues, records, accumulators) are used on the library's three streams only: those are waited for, not other
+// frameworks' work on the device.  Either way it is the BLOCK'S device that is waited for, whichever is current.
+hipError_t dev_free(void* p, bool foreign) {
   if (!p) return hipSuccess;
-  // hipFree's contract, kept: when this returns nothing queued on the device uses the block any more
-  hipError_t e = hipDeviceSynchronize();
+  int owner = -1;
+  {
+    std::lock_guard<std::mutex> lock(g_alloc_mu);
+    auto it = g_live.find(p);
+    if (it != g_live.end()) owner = it->second.device;
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  if (owner >= 0 && owner != cur) (void)hipSetDevice(owner);
+  DeviceCtx* ctx = (owner >= 0 && !foreign) ? peek_ctx(owner) : nullptr;
+  hipError_t e = hipSuccess;
+  if (ctx) {
+    for (hipStream_t st : {ctx->raster_stream, ctx->stream, ctx->exchange_stream})
+      if (st && e == hipSuccess) e = hipStreamSynchronize(st);
+  } else {
+    e = hipDeviceSynchronize();
+  }
   if (e != hipSuccess) (void)hipGetLastError();
-  std::lock_guard<std::mutex> lock(g_alloc_mu);
-  auto it = g_live.find(p);
-  if (it == g_live.end()) return hipFree(p);      // (not one of ours)
-  const DevBlock b = it->second;
-  g_live.erase(it);
-  const size_t cap = cache_cap();
-  if (b.bytes > cap) return hipFree(p);
-  evict_locked(b.bytes, cap);
-  g_cached.emplace(b.bytes, CachedBlock{p, b.device, g_alloc_stamp++});
-  g_cached_bytes += b.bytes;
-  return hipSuccess;
+  hipError_t ret = hipSuccess;
+  {
+    std::lock_guard<std::mutex> lock(g_alloc_mu);
+    auto it = g_live.find(p);
+    if (it == g_live.end()) ret = hipFree(p);      // (not one of ours)
+    else {
+      const DevBlock b = it->second;
+      g_live.erase(it);
+      const size_t cap = cache_cap(b.device);
+      if (b.bytes > cap) ret = hipFree(p);
+      else {
+        evict_locked(b.device, b.bytes, cap);
+        g_cached.emplace(b.bytes, CachedBlock{p, b.device, g_alloc_stamp++});
+        g_cached_bytes[b.device] += b.bytes;
+      }
+    }
+  }
+  if (owner >= 0 && owner != cur) (void)hipSetDevice(cur);
+  return ret;
 }
 
 void dev_trim(int device) {
   std::lock_guard<std::mutex> lock(g_alloc_mu);
   for (auto it = g_cached.begin(); it != g_cached.end();) {
     if (device >= 0 && it->second.device != device) { ++it; continue; }
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    if (cur != it->second.device) (void)hipSetDevice(it->second.device);
-    (void)hipFree(it->second.ptr);
-    if (cur != it->second.device) (void)hipSetDevice(cur);
-    g_cached_bytes -= it->first;
-    it = g_cached.erase(it);
+    auto victim = it++;
+    really_free_locked(victim);
   }
 }
 
@@ -222,7 +271,13 @@ void dev_cache_stats(uint64_t* live_blocks, uint64_t* cached_blocks, uint64_t* c
   std::lock_guard<std::mutex> lock(g_alloc_mu);
   if (live_blocks) *live_blocks = g_live.size();
   if (cached_blocks) *cached_blocks = g_cached.size();
-  if (cached_bytes) *cached_bytes = g_cached_bytes;
+  if (cached_bytes) { *cached_bytes = 0; for (auto& kv : g_cached_bytes) *cached_bytes += kv.second; }
+}
+uint64_t dev_cached_bytes(int device) {
+  std::lock_guard<std::mutex> lock(g_alloc_mu);
+  uint64_t n = 0;
+  for (auto& kv : g_cached_bytes) if (device < 0 || kv.first == device) n += kv.second;
+  return n;
 }
 
 int Scratch::reserve(size_t need) {
@@ -497,16 +552,14 @@ int smesh_device_free(int device, void* ptr) {
   DeviceCtx* ctx;
   SMESH_TRY(get_ctx(device, &ctx));
   SMESH_HIP(hipSetDevice(device));
-  SMESH_HIP(dev_free(ptr));      // (waits for the device, like hipFree; the block stays mapped for the next request of its size)
+  SMESH_HIP(dev_free(ptr, /*foreign=*/true));      // (waits for the device, like hipFree; the block stays mapped for the next request of its size)
   return SMESH_OK;
 }
 
 // Unmaps the device blocks the library keeps for reuse on `device` (-1: every device).  `cached_bytes` (may be NULL) receives what
 // was being held.  Nothing else changes: live handles keep their memory.
 int smesh_device_trim(int device, uint64_t* cached_bytes) {
-  uint64_t held = 0;
-  dev_cache_stats(nullptr, nullptr, &held);
-  if (cached_bytes) *cached_bytes = held;
+  if (cached_bytes) *cached_bytes = dev_cached_bytes(device);
   if (device >= 0) {
     DeviceCtx* ctx;
     SMESH_TRY(get_ctx(device, &ctx));

@@ -2362,10 +2362,12 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   uint64_t scratch_stride = N;   // per-view scratch images of the big-triangle waves
   int G = 1;
   const int wide_chunks = (fuse_wide_enabled() && a->C >= 128 && a->C <= 1024) ? (a->C <= 256 ? 1 : a->C <= 512 ? 2 : 4) : 0;   // k_fuse_tri_wide
-  // rows (and their next pixels) in flight per wave: 4 for rows of up to 256 classes (Mul: its per-view partial sums in double are 32 more registers), 2 beyond
-  static const int wide_b_env = getenv("SMESH_WIDE_B") ? atoi(getenv("SMESH_WIDE_B")) : 0;   // (experiment knob: 2 / 4 / 8)
-  // (cfg5, Sum, views/s: 2 rows in flight and 8 waves per SIMD 509, 4 rows and 5 waves 496, 8 rows -- 284 registers, one wave -- 130)
-  const int wide_b = wide_b_env ? wide_b_env : (a->kind == SMESH_AGG_MUL ? 4 : 2);
+  // rows (and their next pixels) in flight per wave: 2 (Sum / Summax at any width: cfg5 views/s with 2 rows and 8 waves per SIMD 509, 4 rows
+  // and 5 waves 496, 8 rows -- 284 registers, one wave -- 130); Mul with rows of up to 256 classes: 4 (measured in round 4); Mul beyond:
+  // 2 (its per-view partial sums in double over two chunks are 64 more registers -- ADVICE r5: the dispatch used to pick <K, 2, 4>).
+  // SMESH_WIDE_B = 2 / 4 / 8 forces (experiment knob; other values are ignored).
+  static const int wide_b_env = [] { const int v = getenv("SMESH_WIDE_B") ? atoi(getenv("SMESH_WIDE_B")) : 0; return (v == 2 || v == 4 || v == 8) ? v : 0; }();
+  const int wide_b = wide_b_env ? wide_b_env : ((a->kind == SMESH_AGG_MUL && wide_chunks == 1) ? 4 : 2);
   if (!specialised) {
     while ((((a->C + G - 1) / G + 3u) & ~3u) > (uint32_t)kSliceAny) G *= 2;   // lanes per accumulator row (can_fuse_triangles: G <= 64)
     // the big-triangle waves park per-pixel weights (and arg-max) here

@@ -699,6 +699,11 @@ bool image_records_build_group(DeviceCtx* ctx, ImageRecords* const* recs, const 
       // the set was last used by passes A / B and not cleared: start from zero
       if (hipMemsetAsync(r.frags, 0, block_bytes(P ? P : 1), st) != hipSuccess) { *status = fail(SMESH_ERR_RUNTIME, "image records: clear failed"); return true; }
     }
+  }
+  // every record set exists and is cleared: only now do the sets change state (a failed allocation for image i used to
+  // leave images 0 .. i-1 with flipped tags and nothing launched, so that the next build met stale records carrying its own tag)
+  for (int i = 0; i < n; i++) {
+    ImageRecords& r = *recs[i];
     r.moments = true;
     r.clean = false;
     g.im[i] = RecImage{d_idx[i], nullptr, nullptr, r.mom, r.frags, r.big4, r.big_queue, r.big_count, r.tag};

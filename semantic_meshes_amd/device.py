@@ -167,6 +167,17 @@ class DeviceBuffer:
         return DeviceArray(self.ptr + offset_bytes, shape, dtype, self.device, owner=self)
 
 
+def trim(device=-1):
+    """Unmap the device blocks the library keeps for reuse on `device` (-1: every device) and return how many bytes that was
+    (`smesh_device_trim`).  Blocks the library's handles release stay mapped in a per-process cache (freshly mapped memory is where
+    kernel writes were seen to go missing on a GPU shared by several processes; csrc/context.cpp) -- at most a sixteenth of the
+    device's memory / 8 GiB per device (SMESH_ALLOC_CACHE_MB).  Call this before handing the GPU's memory to another allocator of
+    the same process (torch, cupy) that needs the last gigabytes: live handles keep theirs, only idle blocks go."""
+    held = ctypes.c_uint64(0)
+    _lib.check(_lib.lib().smesh_device_trim(int(device), ctypes.byref(held)))
+    return int(held.value)
+
+
 def _free_pinned(ptr):
     try:
         _lib.lib().smesh_host_free(ctypes.c_void_p(ptr))

@@ -361,3 +361,23 @@ print("capsules ok")
     env = {k: v for k, v in os.environ.items() if k != "SMESH_RENDER_CAPSULES"}
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "capsules ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_device_block_cache_is_bounded_and_trimmable(sm):
+    """the cache of still-mapped device blocks (csrc/context.cpp) is capped PER DEVICE at a sixteenth of its memory
+    (at most 8 GiB) -- a block larger than that is really freed, so another allocator of the process finds the memory -- and
+    `device.trim()` hands back the rest on request; a small block is recycled at the same address."""
+    from semantic_meshes_amd import device as smdev
+    smdev.trim()
+    small = smdev.DeviceBuffer(3 << 20)
+    p0 = small.ptr
+    del small
+    again = smdev.DeviceBuffer(3 << 20)
+    assert again.ptr == p0                        # recycled, not re-mapped
+    del again
+    held = smdev.trim(0)
+    assert held >= (3 << 20)
+    assert smdev.trim(0) == 0                     # nothing left to give back
+    big = smdev.DeviceBuffer(9 << 30)             # beyond the cap: must not stay mapped after the free
+    del big
+    assert smdev.trim(0) < (9 << 30)
