@@ -465,6 +465,7 @@ def main():
         renderer = render.triangles(mesh, device=device)
     P = renderer.getPrimitivesNum()
     agg = fusion.MeshAggregator(primitives=P, classes=C, device=device)
+    agg.defer = False     # `--views-per-call 1` means one library call per view (the Python layer would otherwise group fuse_view calls by eight)
 
     # ---- inputs resident in HBM before the timed region: one distinct probs image per view -------------
     # (cfg2: 210 x 157.6 MB = 33 GB.  Larger workloads cycle through as many images as fit in ~120 GB of HBM.)

@@ -269,5 +269,15 @@ def device_count():
     return n.value
 
 
+_flush_hooks = []      # callables(device): work the Python layer has accepted but not yet handed to the library (fusion.py: deferred views)
+
+
+def flush_pending(device=None):
+    """Hand every deferred view (MeshAggregator.add / fuse_view, fusion.py) of `device` (None: all devices) to the library now."""
+    for hook in list(_flush_hooks):
+        hook(device)
+
+
 def synchronize(device=0):
+    flush_pending(device)
     check(lib().smesh_synchronize(device))

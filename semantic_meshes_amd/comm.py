@@ -173,6 +173,7 @@ class Communicator:
 
     def reduce_scalars(self, values, op="sum"):
         """Blocking reduction of a few host floats over all ranks (`op` sum | max)."""
+        _lib.flush_pending(self.device)      # (the collective queues behind everything on the library stream: deferred views included)
         vals = [float(v) for v in values]
         buf = (ctypes.c_double * len(vals))(*vals)
         _lib.check(_lib.lib().smesh_comm_allreduce_f64(self._h, buf, len(vals), {"sum": 0, "max": 2}[op]))

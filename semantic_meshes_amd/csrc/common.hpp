@@ -155,6 +155,8 @@ struct TriFuseArgs {
   uint32_t blk_first;
   uint32_t f_lo, f_hi;
   uint32_t lds_pad;           // host side only: dynamic LDS of the eight-view k_fuse_tri launch (caps its workgroups per CU beside the rasteriser, fusion_multi8.hip)
+  uint32_t xcd_chunk = 0;     // k_fuse_tri_wide: nonzero = the triangle blocks are dealt to the XCDs (block b runs on XCD b % 8) in runs of xcd_chunk
+                              // consecutive blocks (an experiment knob, SMESH_WIDE_XCD); 0 = blocks in dispatch order
 };
 
 // What k_fuse_tri needs to know about ONE of the views it fuses in a launch (the per-view part of TriFuseArgs), and NV of them.

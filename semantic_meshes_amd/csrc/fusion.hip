@@ -1156,7 +1156,13 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
   __shared__ ViewState S;
   const int l = threadIdx.x;
   const uint32_t C = a.C;
-  const uint64_t f0 = ((uint64_t)a.blk_first + blockIdx.x) * kWave;   // (blk_first: fusion by triangle range; 0 otherwise)
+  uint32_t blk = blockIdx.x;
+  if (a.xcd_chunk) {                   // (TriFuseArgs::xcd_chunk: runs of that many consecutive triangle blocks per XCD)
+    const uint32_t sq = blk >> 3, q = sq / a.xcd_chunk;
+    blk = (q * 8u + (blk & 7u)) * a.xcd_chunk + (sq - q * a.xcd_chunk);
+    if (blk >= a.tri_blocks) return;   // block-uniform
+  }
+  const uint64_t f0 = ((uint64_t)a.blk_first + blk) * kWave;   // (blk_first: fusion by triangle range; 0 otherwise)
   const uint64_t f = f0 + l;
   const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;   // primitive id (index image value, accumulator row)
   unsigned long long win[8];
@@ -2417,6 +2423,13 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
   }
   const dim3 grid(t.tri_blocks + big_waves + mid_waves), block(kWave);
   const dim3 tgrid(t.tri_blocks), bgrid(big_waves);                        // any-C paths: big triangles in a second launch
+  {   // k_fuse_tri_wide: the triangle blocks dealt to the XCDs in runs of SMESH_WIDE_XCD consecutive blocks (default 0: dispatch order).
+      // Measured at cfg5 (round 6): one run per XCD -- an eighth of the mesh each -- 506 -> 268 views/s: the eighths are not equally
+      // visible in a view and the launch waits for the XCDs that hold the visible ones.
+    static const uint32_t wide_xcd = getenv("SMESH_WIDE_XCD") ? (uint32_t)std::max(0, atoi(getenv("SMESH_WIDE_XCD"))) : 0u;
+    t.xcd_chunk = (wide_chunks && t.tri_blocks >= 64u) ? wide_xcd : 0u;
+  }
+  const dim3 wgrid(t.xcd_chunk ? 8u * (uint32_t)div_up(t.tri_blocks, 8u * t.xcd_chunk) * t.xcd_chunk : t.tri_blocks);
   if (!specialised && part == 0) SMESH_TRY(mul_recentre(a));   // (a pass over ALL rows: never beside the exchange of a finished range)
   {
     ProfScope prof(ctx, SMESH_PROF_FUSE_SCATTER);
@@ -2433,12 +2446,12 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
     }
 #define SMESH_FW(K)                                                                            \
     switch (wide_chunks) {                                                                     \
-      case 1:  if (wide_b == 8) hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 8>), tgrid, block, 0, st, t, tv, nviews);   \
-               else if (wide_b == 2) hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 2>), tgrid, block, 0, st, t, tv, nviews); \
-               else hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 4>), tgrid, block, 0, st, t, tv, nviews); break; \
-      case 2:  if (wide_b >= 4) hipLaunchKernelGGL((k_fuse_tri_wide<K, 2, 4>), tgrid, block, 0, st, t, tv, nviews);   \
-               else hipLaunchKernelGGL((k_fuse_tri_wide<K, 2, 2>), tgrid, block, 0, st, t, tv, nviews); break; \
-      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4, 2>), tgrid, block, 0, st, t, tv, nviews); break; \
+      case 1:  if (wide_b == 8) hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 8>), wgrid, block, 0, st, t, tv, nviews);   \
+               else if (wide_b == 2) hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 2>), wgrid, block, 0, st, t, tv, nviews); \
+               else hipLaunchKernelGGL((k_fuse_tri_wide<K, 1, 4>), wgrid, block, 0, st, t, tv, nviews); break; \
+      case 2:  if (wide_b >= 4) hipLaunchKernelGGL((k_fuse_tri_wide<K, 2, 4>), wgrid, block, 0, st, t, tv, nviews);   \
+               else hipLaunchKernelGGL((k_fuse_tri_wide<K, 2, 2>), wgrid, block, 0, st, t, tv, nviews); break; \
+      default: hipLaunchKernelGGL((k_fuse_tri_wide<K, 4, 2>), wgrid, block, 0, st, t, tv, nviews); break; \
     }
 #define SMESH_FT(K)                                                                           \
     switch (tri_ct) {                                                                         \

@@ -299,6 +299,9 @@ struct RasterArgs {
                               // triangles: every wave pushes, and increments of ONE counter pass the L2 at ~5 ns each); 0 = one per wave
   uint32_t spread;            // k_raster_frag: nonzero = a triangle takes kSpread consecutive lanes, one per 8 x 8 sub-box of its (at most
                               // kLaneBox x kLaneBox) box; tpw = 64 / kSpread (raster_frag_wave)
+  uint32_t idx_optional;      // k_tile_resolve: nonzero = the index plane is wanted only by the fusion's fallback paths (smesh_fuse_view(s) of a
+                              // triangle renderer in its own face order: k_fuse_tri* read the plane for queued triangles -- big_count[0] -- and
+                              // when the masks need checking -- big_count[1]): a view with neither does not write it (8.3 MB per 1080p view)
   int dbg;                    // development ablation (SMESH_RDBG) of k_raster_frag: 1 = no stores, 2 = setup only, 4 = + coverage,
                               // 8 = + slot reservation, 16 = grouping without the reservation atomics
 };
@@ -640,6 +643,10 @@ __device__ __forceinline__ unsigned long long walk_box(const Tri& t, const int X
 // The covered samples `cover` (bit dx * 8 + dy) of the 8 x 8 box at (X0, Y0) go to the fragment queues: slot reservation in the (at
 // most 2 x 2) tiles the box overlaps -- lanes grouped by their first tile, ONE atomic per (wave, tile) -- then depth per covered
 // sample and the stores.  WHOLE WAVE must call (lanes without samples pass cover = 0).  Returns the mask of the samples that got a key.
+// TEX (compile time, = a.tex_res != nullptr): with a run-time test the compiler computed the two divisions of the texel's barycentric
+// coordinates for every fragment of every renderer and selected afterwards -- three FP64 divisions per fragment instead of one,
+// a tenth of k_raster_frag's vector instructions at cfg2 (round 6).
+template <bool TEX>
 __device__ __forceinline__ unsigned long long emit_cover(const RasterArgs& a, const Tri& t, const uint64_t f, const uint32_t pid,
                                                          const int X0, const int Y0, unsigned long long cover, const uint32_t sub) {
   const int lane = threadIdx.x & 63;
@@ -685,7 +692,7 @@ __device__ __forceinline__ unsigned long long emit_cover(const RasterArgs& a, co
     unsigned long long key = kNullKey;
     if (zf > 0.0f && isfinite(zf)) {
       uint32_t prim = pid;
-      if (a.tex_res) prim = a.tex_first[f] + texel_of(a.tex_res[f], w1 / num, w2 / num);
+      if constexpr (TEX) prim = a.tex_first[f] + texel_of(a.tex_res[f], w1 / num, w2 / num);
       key = ((unsigned long long)__float_as_uint(zf) << 32) | prim;
       mask |= 1ull << bit;
     }
@@ -703,6 +710,7 @@ __device__ __forceinline__ unsigned long long emit_cover(const RasterArgs& a, co
     } else if (key != kNullKey) {
       atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
       atomicOr(&a.q.flag[(tx0 + (hx ? 1u : 0u)) * a.q.tiles_y + ty0 + (hy ? 1u : 0u)], 1u);
+      a.big_count[1] = 1u;      // "check the masks" is known BEFORE the tile resolve starts (it decides there whether the index plane is written)
     }
   }
   return mask;
@@ -738,6 +746,7 @@ __device__ __forceinline__ void coop_reserve(const RasterArgs& a, const Tri& t, 
   for (int j = 0; j < 6; j++) rb[j] = reserve(j);     // in flight together
 }
 // The triangle of lane `src` (its set-up `t`, its reservations `rb`, triangle number f / index value pid in that lane), all 64 lanes on its box.
+template <bool TEX>
 __device__ __forceinline__ void coop_walk(const RasterArgs& a, const Tri& t, const uint32_t (&rb)[6], const int src, const uint64_t fsrc,
                                           const uint32_t psrc, const uint32_t sub) {
   const int lane = threadIdx.x & 63;
@@ -753,7 +762,7 @@ __device__ __forceinline__ void coop_walk(const RasterArgs& a, const Tri& t, con
     const uint32_t fb = (uint32_t)bi((int)(uint32_t)fsrc);      // (the owner lane's triangle: lanes need not hold consecutive ones, see raster_frag_wave)
     const uint32_t fbid = (uint32_t)bi((int)psrc);
     uint32_t tfirst = 0u, tres = 0u;
-    if (a.tex_res) { tfirst = a.tex_first[fb]; tres = a.tex_res[fb]; }
+    if constexpr (TEX) { tfirst = a.tex_first[fb]; tres = a.tex_res[fb]; }
     const int tX0 = X0 / kQW, tY0 = Y0 / kQH, nty = Y1 / kQH - tY0 + 1;
     const uint32_t sb0 = (uint32_t)bi((int)rb0), sb1 = (uint32_t)bi((int)rb1), sb2 = (uint32_t)bi((int)rb2),
                    sb3 = (uint32_t)bi((int)rb3), sb4 = (uint32_t)bi((int)rb4), sb5 = (uint32_t)bi((int)rb5);
@@ -777,7 +786,7 @@ __device__ __forceinline__ void coop_walk(const RasterArgs& a, const Tri& t, con
         const float zf = (float)(num / den);
         if (zf > 0.0f && isfinite(zf)) {
           uint32_t prim = fbid;
-          if (a.tex_res) prim = tfirst + texel_of(tres, w1 / num, w2 / num);
+          if constexpr (TEX) prim = tfirst + texel_of(tres, w1 / num, w2 / num);
           key = ((unsigned long long)__float_as_uint(zf) << 32) | prim;
         }
       }
@@ -796,16 +805,18 @@ __device__ __forceinline__ void coop_walk(const RasterArgs& a, const Tri& t, con
       } else if (key != kNullKey) {
         atomicMin(&a.keys[key_index((uint32_t)x, (uint32_t)y, a.H)], key);
         atomicOr(&a.q.flag[tile], 1u);
+        a.big_count[1] = 1u;
       }
     }
 }
 
 // MODE (an instance of the kernels per mode: the code of the other modes costs the small-triangle instance registers it does not
-// have -- k_raster_frag_group is held to 96 for five waves per SIMD): bit 0 = RasterArgs::wg_push, bit 1 = RasterArgs::spread.
+// have -- k_raster_frag_group is held to 96 for five waves per SIMD): bit 0 = RasterArgs::wg_push, bit 1 = RasterArgs::spread,
+// bit 2 = texel primitives (RasterArgs::tex_res != nullptr; emit_cover).
 template <int MODE>
 __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64_t f, const int32_t i0, const int32_t i1, const int32_t i2,
                                                const uint32_t sub, const int part_in = -1, const bool listed = false) {
-  constexpr bool kWgPush = (MODE & 1) != 0, kSpreadMode = (MODE & 2) != 0;
+  constexpr bool kWgPush = (MODE & 1) != 0, kSpreadMode = (MODE & 2) != 0, kTex = (MODE & 4) != 0;
   const int lane = threadIdx.x & 63;
   const int part = kSpreadMode ? part_in : -1;
   const bool owner = part <= 0 && !listed;    // (listed: a triangle from the view's list, k_raster_medium -- its owner lane left its record and queue entries)
@@ -900,7 +911,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   }
   if (SMESH_ABL(a.dbg) & 4) { if (a.frags && f < a.F && owner) { rec.mask = cover; a.frags[f] = rec; } return; }   // ablation: setup + coverage only
   {
-    const unsigned long long mask = emit_cover(a, t, f, pid, CX0, CY0, cover, sub);
+    const unsigned long long mask = emit_cover<kTex>(a, t, f, pid, CX0, CY0, cover, sub);
     if (mask && small) rec.kind = 1;
     if (rec.kind == 1) rec.mask = mask;
   }
@@ -937,7 +948,7 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
       const bool on = bw > 0 && bh > 0;
       if (__ballot(on) == 0ull) continue;
       const unsigned long long cv = on ? walk_box(t, X0, Y0, bw, bh) : 0ull;
-      (void)emit_cover(a, t, f, pid, on ? X0 : 0, on ? Y0 : 0, cv, sub);
+      (void)emit_cover<kTex>(a, t, f, pid, on ? X0 : 0, on ? Y0 : 0, cv, sub);
     }
   }
 
@@ -968,13 +979,14 @@ __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64
   while (todo) {
     const int src = __ffsll((long long)todo) - 1;
     todo &= todo - 1ull;
-    coop_walk(a, t, rb, src, f, pid, sub);
+    coop_walk<kTex>(a, t, rb, src, f, pid, sub);
   }
 }
 
 // The view's list of medium triangles (RasterArgs::med_queue, filled by the balanced instances of k_raster_frag), a triangle per wave
 // and turn: every lane sets the triangle up for itself -- the same loads and arithmetic as its owner lane's, the same bits -- lane 0
 // reserves its tiles' sub-rectangles, the wave walks its box.
+template <bool TEX>
 __device__ __forceinline__ void raster_medium_wave(const RasterArgs& a, const uint32_t wave, const uint32_t nwaves) {
   const int lane = threadIdx.x & 63;
   const uint32_t n = min(a.big_count[4], a.big_capacity);
@@ -986,7 +998,7 @@ __device__ __forceinline__ void raster_medium_wave(const RasterArgs& a, const ui
     if (load_tri_ex(a, g, t, g0, g1, g2) != 1) continue;            // (never: its owner lane found it drawable)
     uint32_t rb[6] = {0u, 0u, 0u, 0u, 0u, 0u};
     if (lane == 0) coop_reserve(a, t, i & (kQSub - 1), rb);
-    coop_walk(a, t, rb, 0, g, a.prim_id ? a.prim_id[g] : g, i & (kQSub - 1));
+    coop_walk<TEX>(a, t, rb, 0, g, a.prim_id ? a.prim_id[g] : g, i & (kQSub - 1));
   }
   // ... and the listed triangles with boxes of 9 .. kLaneBox pixels (from the far end of the list), seven per wave and turn: a spread wave
   constexpr int kLanes = kSpread, kTris = kSpreadTris;
@@ -999,11 +1011,12 @@ __device__ __forceinline__ void raster_medium_wave(const RasterArgs& a, const ui
     if (tri < kTris && e < nl) fs = a.med_queue[a.big_capacity - 1u - e];
     int32_t s0 = 0, s1 = 0, s2 = 0;
     if (fs < a.F) { s0 = a.faces[3 * fs + 0]; s1 = a.faces[3 * fs + 1]; s2 = a.faces[3 * fs + 2]; }
-    raster_frag_64<2>(a, fs, s0, s1, s2, i & (kQSub - 1), lane % kLanes, true);
+    raster_frag_64<TEX ? 6 : 2>(a, fs, s0, s1, s2, i & (kQSub - 1), lane % kLanes, true);
   }
 }
+template <bool TEX>
 __global__ __launch_bounds__(256) void k_raster_medium(RasterArgs a) {
-  raster_medium_wave(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6);
+  raster_medium_wave<TEX>(a, (blockIdx.x * blockDim.x + threadIdx.x) >> 6, (gridDim.x * blockDim.x) >> 6);
 }
 
 // One wave = a.groups x a.tpw consecutive triangles (tpw: 64 for large meshes; fewer for small ones, so that the cooperative
@@ -1045,11 +1058,28 @@ __device__ __forceinline__ void raster_frag_wave(const RasterArgs& a, const uint
   }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? 4 : 5, 5))) void k_raster_frag(RasterArgs a) {
-  raster_frag_wave<false, MODE>(a, ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+// Block -> triangles, XCD-aware (round 6).  The dispatcher places block b on XCD b % 8 and every XCD has its own L2, so with blocks
+// taking consecutive triangles in dispatch order, the four or so blocks that share a line of projected vertices (neighbouring
+// triangles) sat on four different XCDs and each L2 fetched the line for itself: 25 MB of vertex reads per cfg2 view for a 12 MB
+// array (profiles/r06_pmc_raster_cfg2.txt).  Now the triangle blocks are dealt to the XCDs in RUNS of `run` consecutive blocks: the
+// s-th block an XCD x is given (s = b / 8) is triangle block (s / run) * 8 * run + x * run + s % run.  (One run per XCD -- an eighth
+// of the mesh each -- was measured slower, 198 -> 239 us per eight cfg2 views: the eighths of a mesh are not equally expensive in a
+// view, and the launch then waits for the slowest XCD.)  Blocks beyond the last triangle block leave at once.  A speed choice only:
+// any placement rasterises every triangle once.
+__device__ __forceinline__ uint32_t xcd_block(const uint32_t xcd, const uint32_t s, const uint32_t run) {
+  const uint32_t q = s / run;
+  return (q * 8u + xcd) * run + (s - q * run);
 }
-int raster_mode(const RasterArgs& a) { return (a.spread ? 3 : a.wg_push ? 1 : 0); }   // (spread views are views of medium triangles: wg_push too)
+// blocks per XCD (its sequence length) for `nblocks` triangle blocks in runs of `run`
+inline uint32_t xcd_slots(uint32_t nblocks, uint32_t run) { return (uint32_t)div_up(nblocks, 8u * run) * run; }
+
+template <int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 3) ? 4 : 5, 5))) void k_raster_frag(RasterArgs a, uint32_t nblocks, uint32_t chunk) {
+  const uint32_t tb = chunk ? xcd_block(blockIdx.x & 7u, blockIdx.x >> 3, chunk) : blockIdx.x;
+  if (tb >= nblocks) return;     // (block-uniform)
+  raster_frag_wave<false, MODE>(a, ((uint64_t)tb * blockDim.x + threadIdx.x) >> 6);
+}
+int raster_mode(const RasterArgs& a) { return (a.spread ? 3 : a.wg_push ? 1 : 0) | (a.tex_res ? 4 : 0); }   // (spread views are views of medium triangles: wg_push too)
 
 // Several views in one launch: blocks [v * blocks_per_view, (v + 1) * blocks_per_view) rasterise view v.
 struct RasterGroup {
@@ -1057,17 +1087,32 @@ struct RasterGroup {
   uint32_t* idx[kMaxGroup];       // k_tile_resolve_group: index plane of view v ...
   uint32_t tile_end[kMaxGroup];   // ... whose tiles are blocks [tile_end[v-1], tile_end[v])
   uint32_t n, blocks_per_view;
+  uint32_t chunk;                 // k_raster_frag_group: nonzero = XCD-aware placement (below): consecutive triangle blocks per run of an XCD
 };
 // (five waves per SIMD -- 96 registers -- for the small-triangle instance; the instances for views of medium triangles may take 128: at 96
 // they spill, and their waves are long)
+// Placement (g.chunk != 0): the triangle blocks go to the XCDs in runs (xcd_block), for EVERY view alike, and the views of a launch
+// take turns on an XCD -- blocks 8 k + x, k = 0, 1, 2 ... of the grid are (the XCD's s-th triangle block, view v) for k = s * n + v:
+// the n views' blocks over the same 256 triangles are dispatched back to back on the same XCD, so the triangles' vertex indices
+// (12 MB per cfg2 view) are fetched into that L2 once per launch, not once per view.
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(MODE ? 4 : 5, 5))) void k_raster_frag_group(RasterGroup g) {
-  const uint32_t v = blockIdx.x / g.blocks_per_view;   // block-uniform
-  raster_frag_wave<true, MODE>(g.view[v], ((uint64_t)(blockIdx.x - v * g.blocks_per_view) * blockDim.x + threadIdx.x) >> 6);
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 3) ? 4 : 5, 5))) void k_raster_frag_group(RasterGroup g) {
+  uint32_t v, tb;
+  if (g.chunk) {
+    const uint32_t k = blockIdx.x >> 3, sq = k / g.n;
+    v = k - sq * g.n;
+    tb = xcd_block(blockIdx.x & 7u, sq, g.chunk);
+    if (tb >= g.blocks_per_view) return;               // block-uniform
+  } else {
+    v = blockIdx.x / g.blocks_per_view;                // block-uniform
+    tb = blockIdx.x - v * g.blocks_per_view;
+  }
+  raster_frag_wave<true, MODE>(g.view[v], ((uint64_t)tb * blockDim.x + threadIdx.x) >> 6);
 }
+template <bool TEX>
 __global__ __launch_bounds__(256) void k_raster_medium_group(RasterGroup g, uint32_t blocks_per_view) {
   const uint32_t v = blockIdx.x / blocks_per_view;   // block-uniform
-  raster_medium_wave(g.view[v], ((blockIdx.x - v * blocks_per_view) * blockDim.x + threadIdx.x) >> 6, (blocks_per_view * blockDim.x) >> 6);
+  raster_medium_wave<TEX>(g.view[v], ((blockIdx.x - v * blocks_per_view) * blockDim.x + threadIdx.x) >> 6, (blocks_per_view * blockDim.x) >> 6);
 }
 // The largest triangles (box over kMedium x kMedium) and the triangles that cross the near plane (clip_piece), between k_raster_frag
 // and k_tile_resolve: one workgroup per screen tile scans their queue, keeps those whose box overlaps the tile and shades the
@@ -1201,6 +1246,9 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
       for (uint32_t i = sq_lane + kSpec * kGroup; i < n; i += kGroup) lost(q.key[qbase + i], q.pix[qbase + i]);
     }
   }
+  // (both counters are final: every queue push and every overflow happened in the launches before this one)
+  const bool want_planes = !a.idx_optional || a.big_count[0] != 0u || a.big_count[1] != 0u;
+  if (want_planes)
   for (int p = t; p < kQPixels; p += 256) {
     const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
     if (gx < W && gy < H) {
@@ -1453,6 +1501,21 @@ RasterPath raster_path() {
   return p;
 }
 
+// May a fuse_view(s) call leave out the index plane of a view that has no queued triangles and no overflow (RasterArgs::idx_optional)?
+// Only where the tile resolve clears the losers out of the records' masks itself: triangle primitives in the caller's face order,
+// fragment-queue path.  SMESH_RASTER_SKIP_PLANE=0 turns it off.
+bool plane_optional_allowed(const smesh_renderer* r) {
+  static const bool off = getenv("SMESH_RASTER_SKIP_PLANE") && atoi(getenv("SMESH_RASTER_SKIP_PLANE")) == 0;
+  return !off && !r->texels && !r->prim_id && raster_path() == RasterPath::Frag;
+}
+
+// Consecutive triangle blocks per run of an XCD (xcd_block).  SMESH_RASTER_XCD=n sets it; 0: blocks take consecutive triangles in
+// dispatch order, as until round 5.
+uint32_t raster_xcd_run() {
+  static const uint32_t run = getenv("SMESH_RASTER_XCD") ? (uint32_t)std::max(0, atoi(getenv("SMESH_RASTER_XCD"))) : 16u;
+  return run;
+}
+
 // Per-tile fragment queues (kQSub sub-queues each).  Capacity per tile: 16 fragments per pixel of the tile
 // (SMESH_FRAG_CAP overrides the capacity of a sub-queue; fragments beyond it fall back to the global key image), shrunk
 // if the whole set would exceed 8 GiB.  Returns false (queues unusable -> direct path) for images with so many tiles
@@ -1558,6 +1621,7 @@ RasterArgs raster_args(smesh_renderer* r, smesh_renderer::ViewScratch& vs, int s
   a.kinds = r->side[side].kinds;
   { static const int rdbg = SMESH_ABL_ENV("SMESH_RDBG"); a.dbg = rdbg; }
   a.q = FragQueues();
+  a.idx_optional = 0u;
   a.tpw = 64;   // small meshes: fewer triangles per wave, at least ~kMinWaves waves
   // Meshes of 32 768 triangles and more count the waves of the whole launch (`nviews` views) and are content with 1 024 of them: their
   // boxes over 8 x 8 are mostly the ones a lane walks itself, sub-box by sub-box (raster_frag_64), and a round of that costs the same
@@ -1590,7 +1654,7 @@ uint32_t frag_groups(uint64_t F, int views, uint32_t tpw) {
 }
 
 int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, float* d_depth, hipStream_t st = nullptr,
-                int side = 0) {
+                int side = 0, bool idx_optional = false) {
   DeviceCtx* ctx = r->ctx;
   r->last_render_side = side;
   if (!st) {
@@ -1614,19 +1678,28 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   if (r->F) {
     RasterArgs a = raster_args(r, vs, side, W, H, 1, cam);
     a.cam = ca;
+    a.idx_optional = idx_optional && plane_optional_allowed(r) ? 1u : 0u;
     const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
     int qs = SMESH_OK;
     if (raster_path() == RasterPath::Frag && ensure_queues(r, vs, W, H, st, &qs)) {
       a.q = vs.fq;
       {
-        const dim3 grid((uint32_t)div_up(div_up(r->F, a.tpw), 4));
+        const uint32_t nblocks = (uint32_t)div_up(div_up(r->F, a.tpw), 4);
+        const uint32_t chunk = nblocks >= 64u ? raster_xcd_run() : 0u;
+        const dim3 grid(chunk ? 8u * xcd_slots(nblocks, chunk) : nblocks);
         switch (raster_mode(a)) {
-          case 3:  hipLaunchKernelGGL(k_raster_frag<3>, grid, dim3(256), 0, st, a); break;
-          case 1:  hipLaunchKernelGGL(k_raster_frag<1>, grid, dim3(256), 0, st, a); break;
-          default: hipLaunchKernelGGL(k_raster_frag<0>, grid, dim3(256), 0, st, a); break;
+          case 7:  hipLaunchKernelGGL(k_raster_frag<7>, grid, dim3(256), 0, st, a, nblocks, chunk); break;
+          case 5:  hipLaunchKernelGGL(k_raster_frag<5>, grid, dim3(256), 0, st, a, nblocks, chunk); break;
+          case 4:  hipLaunchKernelGGL(k_raster_frag<4>, grid, dim3(256), 0, st, a, nblocks, chunk); break;
+          case 3:  hipLaunchKernelGGL(k_raster_frag<3>, grid, dim3(256), 0, st, a, nblocks, chunk); break;
+          case 1:  hipLaunchKernelGGL(k_raster_frag<1>, grid, dim3(256), 0, st, a, nblocks, chunk); break;
+          default: hipLaunchKernelGGL(k_raster_frag<0>, grid, dim3(256), 0, st, a, nblocks, chunk); break;
         }
-        if (raster_mode(a) != 0 && a.balance)     // the list the balanced instances left: four waves per SIMD's worth of waves walk it
-          hipLaunchKernelGGL(k_raster_medium, dim3(4u * (uint32_t)std::max(1, ctx->num_cus)), dim3(256), 0, st, a);
+        if ((raster_mode(a) & 3) != 0 && a.balance) {    // the list the balanced instances left: four waves per SIMD's worth of waves walk it
+          const dim3 mgrid(4u * (uint32_t)std::max(1, ctx->num_cus));
+          if (a.tex_res) hipLaunchKernelGGL(k_raster_medium<true>, mgrid, dim3(256), 0, st, a);
+          else hipLaunchKernelGGL(k_raster_medium<false>, mgrid, dim3(256), 0, st, a);
+        }
       }
       SMESH_HIP(hipGetLastError());
       const uint32_t ntiles = (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
@@ -1697,8 +1770,10 @@ int prepare_group_slots(smesh_renderer* r, const smesh_camera_t* cams, int n, hi
 
 // `side_base`: where the records and index planes go (side[side_base + v], fused[side_base + v]) when that is not the view slots'
 // own set (held views: the rasteriser scratch of slots base .. base + n - 1 is free again after the launches, the records stay).
-int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st, int base = 0, int side_base = -1) {
+int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st, int base = 0, int side_base = -1,
+                      bool idx_optional = false) {
   if (side_base < 0) side_base = base;
+  idx_optional = idx_optional && plane_optional_allowed(r);
   DeviceCtx* ctx = r->ctx;
   ProjectGroup pg;
   RasterGroup rg;
@@ -1726,6 +1801,7 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     { const RasterArgs own = raster_args(r, vs, side_base + v, W, H, 1, &cams[v]); rg.view[v].wg_push = own.wg_push; rg.view[v].balance = own.balance; }
     rg.view[v].cam = pg.cam[v];
     rg.view[v].q = vs.fq;
+    rg.view[v].idx_optional = idx_optional ? 1u : 0u;
     rg.idx[v] = static_cast<uint32_t*>(r->fused[side_base + v].ptr);
     tiles += (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
     rg.tile_end[v] = tiles;
@@ -1753,16 +1829,21 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
   // (experiment knob: an LDS pad caps the rasteriser's workgroups per CU when it runs beside a fusion launch -- group pipeline)
   static const unsigned raster_pad = getenv("SMESH_RASTER_LDS_PAD") ? (unsigned)atoi(getenv("SMESH_RASTER_LDS_PAD")) : 0u;
   {
-    const dim3 grid((uint32_t)n * rg.blocks_per_view);
+    rg.chunk = rg.blocks_per_view >= 64u ? raster_xcd_run() : 0u;
+    const dim3 grid(rg.chunk ? 8u * xcd_slots(rg.blocks_per_view, rg.chunk) * (uint32_t)n : (uint32_t)n * rg.blocks_per_view);
     const unsigned pad = st == ctx->raster_stream ? raster_pad : 0u;
     switch (raster_mode(rg.view[0])) {     // (one mode per launch: render_group_into made the views agree)
+      case 7:  hipLaunchKernelGGL(k_raster_frag_group<7>, grid, dim3(256), pad, st, rg); break;
+      case 5:  hipLaunchKernelGGL(k_raster_frag_group<5>, grid, dim3(256), pad, st, rg); break;
+      case 4:  hipLaunchKernelGGL(k_raster_frag_group<4>, grid, dim3(256), pad, st, rg); break;
       case 3:  hipLaunchKernelGGL(k_raster_frag_group<3>, grid, dim3(256), pad, st, rg); break;
       case 1:  hipLaunchKernelGGL(k_raster_frag_group<1>, grid, dim3(256), pad, st, rg); break;
       default: hipLaunchKernelGGL(k_raster_frag_group<0>, grid, dim3(256), pad, st, rg); break;
     }
-    if (raster_mode(rg.view[0]) != 0 && rg.view[0].balance) {
+    if ((raster_mode(rg.view[0]) & 3) != 0 && rg.view[0].balance) {
       const uint32_t per_view = std::max(64u, 4u * (uint32_t)std::max(1, ctx->num_cus) / (uint32_t)n);
-      hipLaunchKernelGGL(k_raster_medium_group, dim3((uint32_t)n * per_view), dim3(256), 0, st, rg, per_view);
+      if (rg.view[0].tex_res) hipLaunchKernelGGL(k_raster_medium_group<true>, dim3((uint32_t)n * per_view), dim3(256), 0, st, rg, per_view);
+      else hipLaunchKernelGGL(k_raster_medium_group<false>, dim3((uint32_t)n * per_view), dim3(256), 0, st, rg, per_view);
     }
   }
   SMESH_HIP(hipGetLastError());
@@ -2290,7 +2371,9 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   }
   uint32_t* d_idx = static_cast<uint32_t*>(r->fused[slot].ptr);
   r->last_idx[slot] = nullptr; r->rec_valid[slot] = false;   // the records of a render_device() on this side are being overwritten
-  SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, ctx->stream, slot));   // the fusion only consumes the index plane
+  // (the fusion only consumes the index plane -- and the triangle-order kernels not even that, where the view has no queued triangles)
+  const bool tri_path = !r->texels && smesh_aggregator_can_fuse_triangles(a, r->F);
+  SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, ctx->stream, slot, tri_path));
   SMESH_TRY(fuse_rendered(r, a, slot, d_idx, probs, weights, memkind, W, H));
   r->fused_seq++;
   return SMESH_OK;
@@ -2310,9 +2393,10 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
   DeviceCtx* ctx = r->ctx;
   if (smesh_aggregator_ctx(a) != ctx) return fail(SMESH_ERR_INVALID, "renderer and aggregator live on different devices");
   static const bool pairs_off = getenv("SMESH_FUSE_PAIRS") && atoi(getenv("SMESH_FUSE_PAIRS")) == 0;
-  bool pairable;
+  bool pairable, tri_path;
   {
     std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
+    tri_path = !r->texels && smesh_aggregator_can_fuse_triangles(a, r->F);   // (fuse_rendered / the group's fusion take k_fuse_tri*: RasterArgs::idx_optional)
     pairable = !pairs_off && memkind == SMESH_MEM_DEVICE && !r->texels && r->F != 0 && smesh_aggregator_can_fuse_triangles(a, r->F) &&
                smesh_aggregator_can_fuse_pair(a);
   }
@@ -2366,13 +2450,13 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
         r->main_pending = false;
       }
       if (!r->bank_used[bank ^ 1]) SMESH_TRY(prepare_group_slots(r, &cams[i], gn, ctx->raster_stream, (bank ^ 1) * kMaxGroup));
-      SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->raster_stream, base));
+      SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->raster_stream, base, -1, tri_path));
       SMESH_HIP(hipEventRecord(r->ev_bank_rendered[bank], ctx->raster_stream));
       SMESH_HIP(hipStreamWaitEvent(ctx->stream, r->ev_bank_rendered[bank], 0));
       r->bank_used[bank] = true;
       r->raster_pending = true;
     } else if (grouped) {
-      SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->stream));
+      SMESH_TRY(render_group_into(r, &cams[i], gn, ctx->stream, 0, -1, tri_path));
     } else {   // images too large for kMaxGroup sets of fragment queues, direct rasteriser, or SMESH_RASTER_PAIRS=0: one view at a time
       gn = 2;
       SMESH_HIP(alloc_side(r, 1));
@@ -2383,7 +2467,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
           SMESH_TRY(r->fused[v].reserve(N * 8));
         }
         r->last_idx[v] = nullptr; r->rec_valid[v] = false;   // the records of a render_device() on this side are being overwritten
-        SMESH_TRY(render_into(r, &cams[i + v], static_cast<uint32_t*>(r->fused[v].ptr), /*d_depth=*/nullptr, ctx->stream, v));
+        SMESH_TRY(render_into(r, &cams[i + v], static_cast<uint32_t*>(r->fused[v].ptr), /*d_depth=*/nullptr, ctx->stream, v, tri_path));
       }
     }
     // texel renderers: the views of the group in ONE fusion launch (a triangle's texel rows make one round trip for all of them)
@@ -2517,7 +2601,7 @@ int smesh_fuse_views_begin(smesh_renderer_t* r, smesh_aggregator_t* a, const sme
   }
   static const int group_max = getenv("SMESH_RASTER_GROUP") ? std::min(kMaxGroup, std::max(2, atoi(getenv("SMESH_RASTER_GROUP")))) : kMaxGroup;
   for (int i = 0; i < h.n; i += group_max)
-    SMESH_TRY(render_group_into(r, &cams[i], std::min(group_max, h.n - i), ctx->stream, 0, kSlots + i));
+    SMESH_TRY(render_group_into(r, &cams[i], std::min(group_max, h.n - i), ctx->stream, 0, kSlots + i, /*idx_optional: ranged => k_fuse_tri* */ true));
   SMESH_TRY(fuse_held_part(r, a, 0));
   smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, false), "render-records");
   r->fused_seq += n;

@@ -34,6 +34,8 @@ class DeviceArray:
         self._rendered_by = None       # render(): the renderer whose latest output this is (MeshAggregator.add fast path)
         self._exported = False         # handed to another framework: the contents may have been changed behind our back
 
+    unrun = False                      # (render.py: a plane of a render() that has not been rasterised yet says True)
+
     def __del__(self):
         cb, self._on_release = getattr(self, "_on_release", None), None
         if cb is not None:

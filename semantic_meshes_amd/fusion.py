@@ -10,9 +10,9 @@ import threading
 import numpy as np
 
 from . import _lib
-from .device import DeviceArray, describe, release_to, result_empty
-
 import os
+
+from .device import DeviceArray, describe, release_to, result_empty
 
 _IDX_CODES = {np.dtype(np.uint32): _lib.IDX_U32, np.dtype(np.int32): _lib.IDX_I32,
               np.dtype(np.uint64): _lib.IDX_U64, np.dtype(np.int64): _lib.IDX_I64}
@@ -20,6 +20,22 @@ _IDX_CODES = {np.dtype(np.uint32): _lib.IDX_U32, np.dtype(np.int32): _lib.IDX_I3
 
 def _c64(vals):
     return (ctypes.c_int64 * len(vals))(*vals)
+
+
+GROUP_VIEWS = 8                                                     # views per deferred group (= the library's views per launch)
+DEFER_VIEWS = os.environ.get("SMESH_DEFER_VIEWS", "1") != "0"       # default of MeshAggregator.defer
+
+import weakref                                                       # noqa: E402
+_aggregators = weakref.WeakSet()
+
+
+def _flush_device(device=None):
+    for a in list(_aggregators):
+        if (device is None or a.device == device) and a._pending:
+            a.flush()
+
+
+_lib._flush_hooks.append(_flush_device)
 
 
 class _MeshAggregator:
@@ -31,9 +47,66 @@ class _MeshAggregator:
         h = ctypes.c_void_p()
         _lib.check(_lib.lib().smesh_aggregator_create(self.primitives, self.classes, _lib.AGG_KINDS[kind],
                                                      self.images_equal_weight, self.device, ctypes.byref(h)))
-        self._h = h
+        self._handle = h
         self._inflight = []     # (completion token, [objects]) of asynchronous calls whose device inputs may still be being read
         self._inflight_lock = threading.Lock()   # (the harness adds from a worker thread while the main thread may call get())
+        # Deferred views (round 6): add() of a not-yet-rasterised render() plane and fuse_view(), with class vectors in this library's own
+        # device arrays, are taken into a group of up to eight views that go to the library as ONE smesh_fuse_views call -- the views
+        # share their rasteriser launches and each accumulator row makes one round trip for all of them: the batch entry point's
+        # throughput behind the reference's per-view loop (colorize_cityscapes_mesh.py:54-67).  Same sums in the same order.  The group
+        # is handed over on the eighth view, at anything else that uses the aggregator (`_h`), at `flush()`, at `_lib.synchronize()`.
+        self._pending = []      # [(renderer, CameraPOD, W, H, probs array, weights array or None)]
+        self._pending_lock = threading.RLock()
+        self.defer = DEFER_VIEWS
+        _aggregators.add(self)
+
+    @property
+    def _h(self):
+        """The library handle -- for a call that is about to use it: every deferred view is handed over first."""
+        if self._pending:
+            self.flush()
+        return self._handle
+
+    def flush(self):
+        """Hand the deferred views (see __init__) to the library now.  Asynchronous like fuse_views: nothing is waited for."""
+        with self._pending_lock:
+            todo, self._pending = self._pending, []
+            if not todo:
+                return
+            renderer = todo[0][0]
+            n = len(todo)
+            pods = (_lib.CameraPOD * n)(*[t[1] for t in todo])
+            pptr = (ctypes.c_void_p * n)(*[t[4].ptr for t in todo])
+            wptr = None
+            if todo[0][5] is not None:
+                wptr = (ctypes.c_void_p * n)(*[t[5].ptr for t in todo])
+            _lib.check(_lib.lib().smesh_fuse_views(renderer._h, self._handle, pods, n, pptr, wptr, _lib.MEM_DEVICE))
+            # (the class vectors are this library's own arrays: freed behind its streams, no completion token needed)
+
+    def _deferrable(self, probs_image, weights_image, W, H):
+        """May a view with these inputs wait for its group?  Only with inputs nobody else can write to behind our back: this library's
+        own dense float32 device arrays that were never exported to another framework (anything else is consumed by the call itself,
+        in order: foreign device tensors may be re-used by their owner as soon as the call returns, host arrays likewise)."""
+        if not self.defer:
+            return False
+        ok = (type(probs_image) is DeviceArray and not probs_image._exported and probs_image.device == self.device
+              and probs_image.dtype == np.float32 and probs_image.shape == (W, H, self.classes)
+              and probs_image.strides == (H * self.classes, self.classes, 1))
+        if ok and weights_image is not None:
+            ok = (type(weights_image) is DeviceArray and not weights_image._exported and weights_image.device == self.device
+                  and weights_image.dtype == np.float32 and weights_image.shape == (W, H) and weights_image.strides == (H, 1))
+        return ok
+
+    def _defer(self, renderer, pod, W, H, probs_image, weights_image):
+        with self._pending_lock:
+            if self._pending:
+                first = self._pending[0]
+                # one group = one renderer, one image size, weights for all views or for none
+                if first[0] is not renderer or (first[2], first[3]) != (W, H) or (first[5] is None) != (weights_image is None):
+                    self.flush()
+            self._pending.append((renderer, pod, W, H, probs_image, weights_image))
+            if len(self._pending) >= GROUP_VIEWS:
+                self.flush()
 
     def _hold(self, keepalives):
         """The asynchronous entry points read DEVICE images after they return.  `release_to()` orders the stream `describe()` guessed for
@@ -60,7 +133,8 @@ class _MeshAggregator:
                 self._inflight.pop(0)
 
     def __del__(self):
-        h, self._h = getattr(self, "_h", None), None
+        h, self._handle = getattr(self, "_handle", None), None
+        self._pending = []      # (views nobody can ask the result of any more)
         if h is not None and h.value:
             try:
                 _lib.lib().smesh_aggregator_destroy(h)      # (waits for the device: every outstanding token is done afterwards)
@@ -80,6 +154,14 @@ class _MeshAggregator:
             own = dlpack.own_capsule_owner(primitive_image)
             if own is not None:
                 primitive_image = own
+        if (getattr(primitive_image, "unrun", False) and primitive_image._which == 0 and primitive_image.device == self.device
+                and self._deferrable(probs_image, weights_image, *primitive_image.shape)):
+            # render()'s index plane handed straight back, not rasterised yet (render.py: _LazyPlane): nobody has looked at it, so
+            # (camera, probs) joins the aggregator's group of deferred views and the plane is never produced
+            pend = primitive_image._pending
+            if pend.W and pend.H:
+                self._defer(pend.renderer, pend.pod, pend.W, pend.H, probs_image, weights_image)
+            return
         streams = []   # streams of other frameworks whose device arrays this call reads (ordered before and after, no host wait)
         ip, imem, ishape, idt, istr, k0 = describe(primitive_image, 2, "primitive image", self.device, streams)
         pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device, streams)
@@ -212,7 +294,9 @@ class _MeshAggregator:
         return self.classes >= int(os.environ.get("SMESH_ADD_RECORDS_MIN_C", "0"))
 
     def reset(self):
-        _lib.check(_lib.lib().smesh_aggregator_reset(self._h))
+        with self._pending_lock:
+            self._pending = []          # (deferred views whose sums would be cleared anyway)
+            _lib.check(_lib.lib().smesh_aggregator_reset(self._handle))
         self._drain()
 
     def get(self):
@@ -273,6 +357,10 @@ class _MeshAggregator:
     def fuse_view(self, renderer, camera, probs_image, weights_image=None):
         """render(camera) + add(indices, probs) in one call without the indices leaving the device."""
         W, H = camera.resolution
+        if (W > 0 and H > 0 and W <= 65536 and H <= 65536 and W * H < 0x7FFFFFFF // 4 and renderer.device == self.device
+                and self._deferrable(probs_image, weights_image, W, H)):
+            self._defer(renderer, _lib.CameraPOD.from_buffer_copy(camera._pod), W, H, probs_image, weights_image)
+            return
         streams = []
         pp, pmem, pshape, pdt, pstr, k1 = describe(probs_image, 3, "probs image", self.device, streams)
         if tuple(pshape) != (W, H, self.classes) or pdt != np.float32:

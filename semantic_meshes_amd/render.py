@@ -29,6 +29,87 @@ RETURN_CAPSULES = os.environ.get("SMESH_RENDER_CAPSULES", "0") == "1"   # render
 
 _live_renderers = weakref.WeakSet()   # MeshAggregator.add looks here for the render a foreign index image is a copy of
 
+# render() hands out planes that are rasterised on first USE (SMESH_LAZY_RENDER=0: at once, as until round 5).  The reference's loop is
+# `idx, depth = renderer.render(cam); aggregator.add(idx, probs)` (python/scripts/colorize_cityscapes_mesh.py:54-67): when the index
+# plane goes straight into add() nobody ever looks at it, and the aggregator can take (camera, probs) into a group of eight views
+# that share their launches (smesh_fuse_views) -- the batch entry point's throughput behind the per-view API.
+# Anything that looks at a plane -- np.asarray, .ptr, __cuda_array_interface__, DLPack, a capsule, add() with host or foreign images --
+# rasterises it first; the content is the same either way.
+LAZY_RENDER = os.environ.get("SMESH_LAZY_RENDER", "1") != "0"
+
+
+class _PendingRender:
+    """A render(camera) that has not been run yet; shared by its two planes."""
+
+    def __init__(self, renderer, camera):
+        import threading
+        self.renderer = renderer
+        self.pod = _lib.CameraPOD.from_buffer_copy(camera._pod)     # (the caller may change or drop its Camera)
+        self.W, self.H = camera.resolution
+        self.lock = threading.Lock()
+        self.done = False
+        self.ptrs = [0, 0]            # index plane, depth plane
+        self.dead = [False, False]    # the plane's array was dropped before the render ran
+
+    def run(self):
+        with self.lock:
+            if self.done:
+                return
+            r = self.renderer
+            pi, pd = ctypes.c_void_p(), ctypes.c_void_p()
+            _lib.check(_lib.lib().smesh_renderer_render_device(r._h, ctypes.byref(self.pod), ctypes.byref(pi), ctypes.byref(pd)))
+            self.ptrs = [pi.value, pd.value]
+            self.done = True
+            r._lazy_unrun = False
+            for which in (0, 1):
+                if self.dead[which]:
+                    self._release(which)
+
+    def _release(self, which):
+        h = self.renderer._h
+        if h is not None and h.value and self.ptrs[which]:
+            p = ctypes.c_void_p(self.ptrs[which])
+            _lib.lib().smesh_renderer_release_image(h, p if which == 0 else None, p if which == 1 else None)
+        self.ptrs[which] = 0
+
+    def drop(self, which):
+        with self.lock:
+            if self.done:
+                self._release(which)
+            else:
+                self.dead[which] = True
+
+
+class _LazyPlane(DeviceArray):
+    """One plane of a render() that runs on first use: reading `.ptr` (every consumer does) rasterises."""
+
+    def __init__(self, pending, which, dtype, device, owner):
+        self._pending = pending
+        self._which = which
+        DeviceArray.__init__(self, 0, (pending.W, pending.H), dtype, device, owner=owner)
+
+    @property
+    def ptr(self):
+        pd = self._pending
+        if not pd.done:
+            pd.run()
+        return pd.ptrs[self._which]
+
+    @ptr.setter
+    def ptr(self, value):      # (DeviceArray.__init__ assigns it)
+        pass
+
+    @property
+    def unrun(self):
+        return not self._pending.done
+
+    def __del__(self):
+        try:
+            self._pending.drop(self._which)
+        except Exception:
+            pass
+
+
 
 class _Renderer:
     """Common part of PlyRendererTriangles / PlyRendererTexels (Renderer.h:12-43)."""
@@ -38,6 +119,7 @@ class _Renderer:
         self.device = device
         self._primitives = None
         self._capsules = capsules     # what render() returns by default: None = this module's RETURN_CAPSULES (per renderer, not per process)
+        self._lazy_unrun = False      # a lazy render() was handed out and has not been rasterised (yet): render_stats' queue lengths are older
         _live_renderers.add(self)
 
     def __del__(self):
@@ -55,7 +137,7 @@ class _Renderer:
             self._primitives = int(n.value)
         return self._primitives
 
-    def render(self, camera, capsules=None):
+    def render(self, camera, capsules=None, lazy=None):
         """Rasterise the mesh for `camera`; returns `(primitive_indices, depth)`:
         uint32 (W,H) with background 0xFFFFFFFF and float32 (W,H) with background +inf, device-resident.
 
@@ -66,6 +148,22 @@ class _Renderer:
         if not isinstance(camera, Camera):
             raise TypeError("render() expects a semantic_meshes data.Camera")
         W, H = camera.resolution
+        if capsules is None:
+            capsules = RETURN_CAPSULES if self._capsules is None else self._capsules
+        if lazy is None:
+            lazy = LAZY_RENDER
+        if lazy and not capsules:
+            # (`lazy=False` / SMESH_LAZY_RENDER=0: rasterise now -- what a timing loop around render() alone wants)
+            if W <= 0 or H <= 0 or W > 65536 or H > 65536:       # (what the library's check_camera refuses, refused now)
+                raise ValueError("camera resolution must be in [1, 65536]")
+            if W * H >= 0x7FFFFFFF // 4:
+                raise ValueError("image too large")
+            pend = _PendingRender(self, camera)
+            indices = _LazyPlane(pend, 0, np.uint32, self.device, self)
+            indices._rendered_by = self
+            depth = _LazyPlane(pend, 1, np.float32, self.device, self)
+            self._lazy_unrun = True
+            return indices, depth
         pi, pd = ctypes.c_void_p(), ctypes.c_void_p()
         _lib.check(_lib.lib().smesh_renderer_render_device(self._h, ctypes.byref(camera._pod), ctypes.byref(pi), ctypes.byref(pd)))
         h = self._h
@@ -81,8 +179,7 @@ class _Renderer:
         indices = DeviceArray(pi.value, (W, H), np.uint32, self.device, owner=self, on_release=rel_i)
         indices._rendered_by = self   # add(indices, ...) can then reuse what this render left on the device
         depth = DeviceArray(pd.value, (W, H), np.float32, self.device, owner=self, on_release=rel_d)
-        if capsules is None:
-            capsules = RETURN_CAPSULES if self._capsules is None else self._capsules
+        self._lazy_unrun = False
         if capsules:
             return indices.capsule(), depth.capsule()
         return indices, depth
@@ -93,6 +190,11 @@ class _Renderer:
         box and longest edge that there is none), and after the last `render()` / `render_numpy()` the four queue lengths
         `[boxes over 8 x 8, queue overflow flag, of those huge or clipped, of those at most 256 box pixels]`.
         `self.last_big_stage_needed`: likewise for boxes over 8 x 8 pixels (what `fuse_views` leaves out where it is False)."""
+        if queues and self._lazy_unrun:
+            # the last render() has not been rasterised (its planes were not looked at, or went into a deferred add): the queue
+            # lengths the library holds are an older render's -- rasterise this camera now
+            _lib.flush_pending(self.device)
+            self.render(camera, capsules=False, lazy=False)
         needed = ctypes.c_int()
         q = (ctypes.c_uint32 * 4)()
         _lib.check(_lib.lib().smesh_renderer_render_stats(self._h, ctypes.byref(camera._pod), ctypes.byref(needed),

@@ -30,7 +30,7 @@ for a, b in meshes:
     out = []
     for name, fn in (("fuse_views", lambda: agg.fuse_views(r, cams, [probs] * 8)),
                      ("fuse_view", lambda: [agg.fuse_view(r, cam, probs) for cam in cams]),
-                     ("render", lambda: [r.render(cam) for cam in cams])):
+                     ("render", lambda: [r.render(cam, lazy=False) for cam in cams])):
         fn(); fn()
         _lib.synchronize(0)
         t0 = time.perf_counter()

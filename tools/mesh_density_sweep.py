@@ -35,7 +35,7 @@ for a, b in meshes:
     dv = (time.perf_counter() - t0) / (reps * len(cams))
     t0 = time.perf_counter()
     for cam in cams:
-        r.render(cam)
+        r.render(cam, lazy=False)
     _lib.synchronize(0)
     dr = (time.perf_counter() - t0) / len(cams)
     print("%8d triangles: fuse_view %8.3f ms/view   fuse_views (8 per call) %8.3f ms/view   (render alone %7.3f ms)" % (len(mesh.faces), 1e3 * dt, 1e3 * dv, 1e3 * dr), flush=True)

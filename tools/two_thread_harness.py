@@ -58,11 +58,15 @@ def main():
             agg.fuse_view(r, cam, probs[k % len(probs)])
 
     results = {}
-    for where, probs in (("device", dev), ("host", host)):
+    # `device`: the default -- render() planes rasterised on first use, views with the library's own device arrays deferred into groups of
+    # eight (fusion.py); `device/call`: the same loops with MeshAggregator.defer = False (every add() / fuse_view() is its own library
+    # call, as until round 5)
+    for where, probs, defer in (("device", dev, True), ("device/call", dev, False), ("host", host, True)):
         for name, fn in (("serial", serial), ("two threads", threaded), ("fuse_view", fused)):
             best, raws = None, []
             for rep in range(4):
                 agg = sm.fusion.MeshAggregator(P, C)
+                agg.defer = defer
                 _lib.synchronize(0)
                 t0 = time.perf_counter()
                 fn(agg, probs)
@@ -73,9 +77,11 @@ def main():
                 raws.append(agg.get_raw())
             same = all(np.array_equal(raws[0], x) for x in raws[1:])
             results[(where, name)] = (best, raws[0])
-            print("%-7s %-12s %8.3f ms per view  (%7.0f views/s)  repeats bit-equal: %s" % (where, name, best / views * 1e3, views / best, same), flush=True)
+            print("%-11s %-12s %8.3f ms per view  (%7.0f views/s)  repeats bit-equal: %s" % (where, name, best / views * 1e3, views / best, same), flush=True)
         a, b = results[(where, "serial")][1], results[(where, "two threads")][1]
-        print("%-7s two threads == serial bit for bit: %s" % (where, np.array_equal(a, b)), flush=True)
+        print("%-11s two threads == serial bit for bit: %s" % (where, np.array_equal(a, b)), flush=True)
+    print("device (deferred groups) == device/call (one library call per view) bit for bit: %s"
+          % np.array_equal(results[("device", "serial")][1], results[("device/call", "serial")][1]), flush=True)
 
 
 if __name__ == "__main__":
