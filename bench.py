@@ -237,7 +237,7 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
     finally:
         fusion._MeshAggregator.match_renders = keep
     bytes_per_view = 4 * W * H + 4 * W * H * C + 8 * C * T_mean
-    scatter_path, scatter_kernel = _lib.lib().smesh_last_add_path().decode(), _lib.lib().smesh_last_fuse_kernel().decode()
+    scatter_path, scatter_kernel = _lib.last_add_path(), _lib.last_fuse_kernel()
     # ... and the same images handed over as ONE batch (add_many: the record passes of the eight images in one launch each, one
     # k_fuse_tri<.., 8> launch): same sums, bit for bit
     batched = None
@@ -256,7 +256,7 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
             best = d if best is None else min(best, d)
         fusion._MeshAggregator.match_renders = keep2
         batched = {"ms_per_view": round(1e3 * best, 4), "frac": round(bytes_per_view / best / 1e9 / HBM_PEAK_GBS, 4),
-                   "path": _lib.lib().smesh_last_add_path().decode(),
+                   "path": _lib.last_add_path(),
                    "what": "add_many(%d device copies of renders, device probs): one call, best of 3, host-timed" % views}
         del bagg
     except Exception as e:
@@ -277,14 +277,14 @@ def foreign_images(renderer, P, cams, probs, W, H, C, T_mean, device, views=8):
             kernels = set()
             for k, img in enumerate(copies):
                 agg.add(img, probs[k % len(probs)])
-                kernels.add(_lib.lib().smesh_last_fuse_kernel().decode())
+                kernels.add(_lib.last_fuse_kernel())
             _lib.synchronize(device)
             dtm = (time.perf_counter() - t0) / nm
             best = dtm if best is None else min(best, dtm)
             del planes, copies
         matched = {"ms_per_view": round(1e3 * best, 4), "kernels": sorted(kernels),
                    "frac": round(bytes_per_view / best / 1e9 / HBM_PEAK_GBS, 4),
-                   "path": _lib.lib().smesh_last_add_path().decode(),
+                   "path": _lib.last_add_path(),
                    "what": "add(device copy of an EXPORTED render, device probs), content matching allowed "
                            "(taken only where the image records are off: SMESH_ADD_RECORDS_MIN_C / texel renderers), %d views" % nm}
     except Exception as e:
@@ -690,7 +690,7 @@ def main():
     if nranks_reported != args.gpus:
         raise SystemExit("bench: --gpus %d but the process group spans %d rank(s)" % (args.gpus, nranks_reported))
 
-    fuse_kernel = _lib.lib().smesh_last_fuse_kernel().decode()
+    fuse_kernel = _lib.last_fuse_kernel()
     k_ms, k_regions, k_launches, k_views = prof_read(device, _lib.PROF_FUSE_SCATTER)
     entered = ctypes.c_uint64(0)       # regions of the dominant kernel the timed loop went through, bracketed or not
     _lib.check(_lib.lib().smesh_profile_regions(device, _lib.PROF_FUSE_SCATTER, ctypes.byref(entered)))

@@ -8,7 +8,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsmesh_hip.so")
+LIB_PATH = os.environ.get("SMESH_LIB_PATH") or os.path.join(_HERE, "csrc", "libsmesh_hip.so")   # (SMESH_LIB_PATH: a development build, e.g. `make ABLATION=1` in a copy of csrc/)
 
 OK, ERR_INVALID, ERR_RUNTIME, ERR_NODEVICE = 0, 1, 2, 3
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -276,6 +276,19 @@ def flush_pending(device=None):
     """Hand every deferred view (MeshAggregator.add / fuse_view, fusion.py) of `device` (None: all devices) to the library now."""
     for hook in list(_flush_hooks):
         hook(device)
+
+
+def last_fuse_kernel():
+    """Name of the fusion kernel the calling thread's last add / fuse call used (`smesh_last_fuse_kernel`) -- deferred views
+    (fusion.py) are handed to the library first, so that "last call" means the caller's last call."""
+    flush_pending()
+    return lib().smesh_last_fuse_kernel().decode()
+
+
+def last_add_path():
+    """Which path the calling thread's last add() took (`smesh_last_add_path`); deferred views are handed over first."""
+    flush_pending()
+    return lib().smesh_last_add_path().decode()
 
 
 def synchronize(device=0):

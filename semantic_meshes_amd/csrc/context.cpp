@@ -9,6 +9,7 @@
 #include <map>
 #include <memory>
 #include <unordered_map>
+#include <vector>
 
 namespace smesh {
 
@@ -65,6 +66,9 @@ int get_ctx(int device, DeviceCtx** out) {
     hipDeviceProp_t prop;
     SMESH_HIP(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    // (Round 6 measured the two streams confined to disjoint sets of CUs -- hipExtStreamCreateWithCUMask, 4 or 5 of every 8 CUs for the
+    // rasteriser -- so that the group pipeline's two kernels would not share CUs: 15 442 / 15 499 views/s against 15 370 with masks
+    // that interleave inside an XCD, 9 000 - 11 000 with masks that give whole XCDs away.  Not kept.)
     SMESH_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     SMESH_HIP(hipStreamCreateWithFlags(&ctx->raster_stream, hipStreamNonBlocking));
     {

@@ -812,7 +812,9 @@ __device__ __forceinline__ void coop_walk(const RasterArgs& a, const Tri& t, con
 
 // MODE (an instance of the kernels per mode: the code of the other modes costs the small-triangle instance registers it does not
 // have -- k_raster_frag_group is held to 96 for five waves per SIMD): bit 0 = RasterArgs::wg_push, bit 1 = RasterArgs::spread,
-// bit 2 = texel primitives (RasterArgs::tex_res != nullptr; emit_cover).
+// bit 2 = texel primitives (RasterArgs::tex_res != nullptr; emit_cover).  (Round 6 also built instances whose lanes project their
+// triangles' vertices themselves -- no vertex stage, no 24-byte record per vertex and view: k_raster_frag_group 195 -> 242 us per eight
+// cfg2 views for 24 us of vertex stage saved, cfg4 668 -> 814 for 106; not kept.)
 template <int MODE>
 __device__ __forceinline__ void raster_frag_64(const RasterArgs& a, const uint64_t f, const int32_t i0, const int32_t i1, const int32_t i2,
                                                const uint32_t sub, const int part_in = -1, const bool listed = false) {
@@ -1073,13 +1075,16 @@ __device__ __forceinline__ uint32_t xcd_block(const uint32_t xcd, const uint32_t
 // blocks per XCD (its sequence length) for `nblocks` triangle blocks in runs of `run`
 inline uint32_t xcd_slots(uint32_t nblocks, uint32_t run) { return (uint32_t)div_up(nblocks, 8u * run) * run; }
 
+// (Five waves per SIMD -- 96 registers -- for the small-triangle instances; built for six (80 registers, four of them spilled) the
+// grouped launch took 195.7 against 200.3 us per eight cfg2 views alone and LOST beside the fusion launch, 14 910 against 15 492 views/s;
+// for seven (72 registers, 48 spilled) 323 us.  Round 6.)
 template <int MODE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((MODE & 3) ? 4 : 5, 5))) void k_raster_frag(RasterArgs a, uint32_t nblocks, uint32_t chunk) {
   const uint32_t tb = chunk ? xcd_block(blockIdx.x & 7u, blockIdx.x >> 3, chunk) : blockIdx.x;
   if (tb >= nblocks) return;     // (block-uniform)
   raster_frag_wave<false, MODE>(a, ((uint64_t)tb * blockDim.x + threadIdx.x) >> 6);
 }
-int raster_mode(const RasterArgs& a) { return (a.spread ? 3 : a.wg_push ? 1 : 0) | (a.tex_res ? 4 : 0); }   // (spread views are views of medium triangles: wg_push too)
+int raster_mode(const RasterArgs& a) { return (a.spread ? 3 : a.wg_push ? 1 : 0) | (a.tex_res ? 4 : 0); }   // (spread views are views of medium triangles: wg_push too)   // (spread views are views of medium triangles: wg_push too)
 
 // Several views in one launch: blocks [v * blocks_per_view, (v + 1) * blocks_per_view) rasterise view v.
 struct RasterGroup {
@@ -1668,6 +1673,8 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
   SMESH_TRY(ensure_keys(vs, W, H, st));
   ProfScope prof(ctx, SMESH_PROF_RASTER, st);
   const CameraArgs ca = camera_args(cam);
+  RasterArgs a = raster_args(r, vs, side, W, H, 1, cam);
+  a.cam = ca;
   if (r->V) {
     hipLaunchKernelGGL(k_project_vertices, dim3((uint32_t)div_up(r->V, 256)), dim3(256), 0, st, r->verts, r->V, ca, vs.sv,
                        r->side[side].big_count);
@@ -1676,8 +1683,6 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 32, st));
   }
   if (r->F) {
-    RasterArgs a = raster_args(r, vs, side, W, H, 1, cam);
-    a.cam = ca;
     a.idx_optional = idx_optional && plane_optional_allowed(r) ? 1u : 0u;
     const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
     int qs = SMESH_OK;

@@ -46,7 +46,7 @@ class _PendingRender:
         self.renderer = renderer
         self.pod = _lib.CameraPOD.from_buffer_copy(camera._pod)     # (the caller may change or drop its Camera)
         self.W, self.H = camera.resolution
-        self.lock = threading.Lock()
+        self.lock = threading.RLock()     # (re-entrant: a sibling plane may be dropped by the collector while run() holds it)
         self.done = False
         self.ptrs = [0, 0]            # index plane, depth plane
         self.dead = [False, False]    # the plane's array was dropped before the render ran

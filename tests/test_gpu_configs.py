@@ -42,7 +42,7 @@ def test_fuse_views_group_of_eight_cfg2_full_size_bit_exact(sm, oracle):
     agg = sm.fusion.MeshAggregator(P, C)
     d_probs = [synth.device_probs(W, H, C, synth.probs_seed(1, k), zero_fraction=0.03) for k in views]
     agg.fuse_views(r, [cams[k] for k in views], d_probs)
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri"
+    assert sm._lib.last_fuse_kernel() == "k_fuse_tri"
     got = agg.get_raw()
     o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
     oagg = oracle.OracleAggregator(P, C)            # float32, single-threaded: the reference's own order of additions
@@ -143,7 +143,7 @@ def test_cfg4_texels_parity_on_a_240k_triangle_cut(sm, oracle):
         dp = synth.device_probs(W, H, C, synth.probs_seed(4, k), zero_fraction=0.03)
         agg.fuse_view(r, cam, dp)
         oagg.add(oidx[k], np.asarray(dp))
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_texel"
+    assert sm._lib.last_fuse_kernel() == "k_fuse_texel"
     # (not bit for bit: triangles with a box over 8 x 8 pixels are fused by a whole wave with float atomics on their own rows)
     np.testing.assert_allclose(agg.get_raw(), oagg.get_raw(), rtol=2e-6, atol=1e-7)
     assert_fused_close(agg.get(), oagg.get())
@@ -172,7 +172,7 @@ def test_cfg4_full_size_properties(sm):
     whole = sm.fusion.MeshAggregator(P, C)
     parts = [sm.fusion.MeshAggregator(P, C) for _ in views]
     whole.fuse_views(r, cams, probs)                                                             # grouped rasteriser launches
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_texel"
+    assert sm._lib.last_fuse_kernel() == "k_fuse_texel"
     for cam, p, part in zip(cams, probs, parts):
         part.fuse_view(r, cam, p)
     raw_sum = sum(part.get_raw().astype(np.float64) for part in parts)
@@ -215,7 +215,7 @@ def test_cfg4t_multi_texel_full_size_properties(sm):
     whole = sm.fusion.MeshAggregator(P, C)
     parts = [sm.fusion.MeshAggregator(P, C) for _ in views]
     whole.fuse_views(r, cams, probs)
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_texel"
+    assert sm._lib.last_fuse_kernel() == "k_fuse_texel"
     for cam, p, part in zip(cams, probs, parts):
         part.fuse_view(r, cam, p)
     # shard-sum identity on every fifth block of a million rows (the whole 4.8 GB accumulator in float64 is 10 GB of host memory)
@@ -247,7 +247,7 @@ def test_cfg5_class_count_and_resolution_parity_on_the_1m_triangle_mesh(sm, orac
     agg = sm.fusion.MeshAggregator(P, C)
     dp = synth.device_probs(W, H, C, synth.probs_seed(5, 17), zero_fraction=0.02)
     agg.fuse_view(r, cam, dp)
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri_wide"
+    assert sm._lib.last_fuse_kernel() == "k_fuse_tri_wide"
     oracle.set_threads(8)
     try:
         oidx, odepth = oracle.OracleRenderer(mesh.vertices, mesh.faces).render(cam)
@@ -286,7 +286,7 @@ def test_cfg5_full_size_properties(sm):
     whole = sm.fusion.MeshAggregator(P, C)
     parts = [sm.fusion.MeshAggregator(P, C) for _ in views]
     whole.fuse_views(r, cams, [probs, probs])
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri_wide"
+    assert sm._lib.last_fuse_kernel() == "k_fuse_tri_wide"
     for cam, part in zip(cams, parts):
         part.fuse_view(r, cam, probs)
     hp = None

@@ -185,6 +185,7 @@ def test_profile_counts_launches_and_views(sm):
     probs = [synth.device_probs(320, 240, C, 40 + k) for k in range(len(cams))]
     r = sm.render.triangles(mesh)
     agg = sm.fusion.MeshAggregator(P, C)
+    agg.defer = False          # (the library's counters per LIBRARY call: the Python layer must not group the fuse_view calls below)
     L = _lib.lib()
 
     def read():
@@ -238,7 +239,7 @@ def test_render_can_return_the_reference_s_dltensor_capsules(sm, oracle):
         np.testing.assert_array_equal(depth_t.cpu().numpy().view(np.uint32), odepth.view(np.uint32))
         probs = random_probs(rng, *cam.resolution, C)
         agg.add(idx_c, probs)                                             # the unconsumed capsule goes straight into add()
-        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri"
+        assert sm._lib.last_fuse_kernel() == "k_fuse_tri"
         oagg.add(oidx, probs)
         with pytest.raises(ValueError):
             agg.add(idx_c, probs)                                         # a capsule is consumed once
@@ -247,7 +248,7 @@ def test_render_can_return_the_reference_s_dltensor_capsules(sm, oracle):
     idx_c, _ = r.render(cams[0], capsules=True)
     idx_t = torch.utils.dlpack.from_dlpack(idx_c)
     agg.add(idx_t, to_dev(sm, random_probs(rng, *cams[0].resolution, C)))
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri"
+    assert sm._lib.last_fuse_kernel() == "k_fuse_tri"
 
 
 def to_dev(sm, a):
@@ -313,7 +314,7 @@ def test_permuted_device_probs_take_the_render_records_path(sm, oracle, C, res):
         assert not view.is_contiguous()
         idx, _ = r.render(cam)
         a.add(idx, view)
-        assert sm._lib.lib().smesh_last_add_path().decode() == ("scatter" if os.environ.get("SMESH_FUSE") == "strip" else "render-records")
+        assert sm._lib.last_add_path() == ("scatter" if os.environ.get("SMESH_FUSE") == "strip" else "render-records")
         b.fuse_view(r, cam, dense)
         oagg.add(np.asarray(idx), dense)
     sm._lib.synchronize(0)
@@ -344,7 +345,7 @@ for k, cam in enumerate(cams):
     assert type(idx).__name__ == "PyCapsule" and type(depth).__name__ == "PyCapsule"
     probs = np.asarray(synth.device_probs(160, 120, 5, 11 + k))
     agg.add(idx, probs)
-    assert _lib.lib().smesh_last_fuse_kernel().decode().startswith("k_fuse_tri")
+    assert _lib.last_fuse_kernel().startswith("k_fuse_tri")
     ref.fuse_view(r, cam, probs)
 assert np.array_equal(agg.get(), ref.get())
 # ... and that is a property of the renderers made under the reference's name, not a switch on the shared implementation module

@@ -553,7 +553,7 @@ def test_fuse_view_any_class_count_mixed_triangle_sizes(sm, oracle, kind, C):
             oagg.add(o.render(cam)[0], probs)
         import os
         if os.environ.get("SMESH_FUSE") != "strip":
-            assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
+            assert sm._lib.last_fuse_kernel() == (
                 "k_fuse_tri_wide" if C >= 128 and os.environ.get("SMESH_FUSE_WIDE") != "0" else "k_fuse_tri_any" if C > 48 else "k_fuse_tri")
         mul_tol = 1e-5   # (hi, lo) state in every triangle-order kernel; the generic scatter-add adds in float32 on the hi plane
         assert_fused_close(agg.get(), oagg.get(), rtol=1e-5 if kind != "mul" else mul_tol)
@@ -747,7 +747,7 @@ def test_fuse_view_texels_small_triangles(sm, oracle, kind, C):
         agg.fuse_view(r, cam, probs, weights)
         oagg.add(o.render(cam)[0], probs, weights)
     if os.environ.get("SMESH_FUSE") != "strip":
-        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_texel"
+        assert sm._lib.last_fuse_kernel() == "k_fuse_texel"
         if kind != "mul":
             np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
     assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
@@ -805,8 +805,8 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle, monkeypatch, con
     P, C = len(mesh.faces), 19
     rng = np.random.default_rng(5)
     r = sm.render.triangles(mesh)
-    last = lambda: sm._lib.lib().smesh_last_fuse_kernel().decode()
-    path = lambda: sm._lib.lib().smesh_last_add_path().decode()
+    last = lambda: sm._lib.last_fuse_kernel()
+    path = lambda: sm._lib.last_add_path()
     agg = sm.fusion.MeshAggregator(P, C, "sum", 0.5)
     o = oracle.OracleRenderer(mesh.vertices, mesh.faces)
     oagg = oracle.OracleAggregator(P, C, "sum", 0.5)
@@ -829,7 +829,7 @@ def test_add_after_render_takes_triangle_order_path(sm, oracle, monkeypatch, con
     # 1. the last six renders are still recognised (the harness queues up to three views between its render and its add
     #    thread, eval_scannet.py:189-238); a seventh-oldest one is not: its per-triangle records are gone -> generic path
     probs = random_probs(rng, *cams[0].resolution, C)
-    kept = [r.render(cams[k])[0] for k in range(7)]
+    kept = [r.render(cams[k], lazy=False)[0] for k in range(7)]     # (rasterised NOW, in this order: a lazy plane would be rendered when add() looks at it)
     agg.add(kept[0], probs)
     assert path() == generic
     oagg.add(o.render(cams[0])[0], probs)
@@ -897,7 +897,7 @@ def test_harness_shaped_loop_takes_triangle_order_path(sm, oracle):
                 if item is None:
                     return
                 agg.add(*item)
-                kernels.append(sm._lib.lib().smesh_last_fuse_kernel().decode())
+                kernels.append(sm._lib.last_fuse_kernel())
         except Exception as e:   # surfaced by the main thread
             errors.append(e)
 
@@ -965,7 +965,7 @@ def test_shuffled_face_order_is_reordered_internally(sm, oracle, C):
         agg.fuse_view(r, cam, probs)
         oagg.add(oidx, probs)
     if os.environ.get("SMESH_FUSE") != "strip":
-        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == (
+        assert sm._lib.last_fuse_kernel() == (
             "k_fuse_tri" if C == 19 else "k_fuse_tri_wide" if os.environ.get("SMESH_FUSE_WIDE") != "0" else "k_fuse_tri_any")
         np.testing.assert_array_equal(agg.get_raw().view(np.uint32), oagg.get_raw().view(np.uint32))
     assert_fused_close(agg.get(), oagg.get(), rtol=1e-5)
@@ -1238,7 +1238,7 @@ def test_fuse_views_pairs_equal_single_calls_bit_for_bit(sm, oracle, kind, C):
     finally:
         oracle.set_accum_double(False)
     if os.environ.get("SMESH_FUSE") != "strip":
-        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == "k_fuse_tri"
+        assert sm._lib.last_fuse_kernel() == "k_fuse_tri"
         np.testing.assert_array_equal(batch.get_raw().view(np.uint32), single.get_raw().view(np.uint32))
         if kind != "mul":
             np.testing.assert_array_equal(batch.get_raw().view(np.uint32), oraw.view(np.uint32))
@@ -1283,7 +1283,7 @@ def test_fuse_views_wide_rows_equal_single_calls_bit_for_bit(sm, oracle, kind, C
         oracle.set_accum_double(False)
     if os.environ.get("SMESH_FUSE") != "strip":
         wide = C >= 128 and os.environ.get("SMESH_FUSE_WIDE") != "0"
-        assert sm._lib.lib().smesh_last_fuse_kernel().decode() == ("k_fuse_tri_wide" if wide else "k_fuse_tri_any")
+        assert sm._lib.last_fuse_kernel() == ("k_fuse_tri_wide" if wide else "k_fuse_tri_any")
         if kind != "mul":      # (Mul: the hi plane is re-centred once per launch, so the grouping shows in the last bits)
             np.testing.assert_array_equal(batch.get_raw().view(np.uint32), single.get_raw().view(np.uint32))
             np.testing.assert_array_equal(batch.get_raw().view(np.uint32), oraw.view(np.uint32))
@@ -1317,7 +1317,7 @@ def test_fuse_views_texels_equal_single_calls_bit_for_bit(sm, oracle, kind, C, t
     dp, dw = [to_device(p) for p in probs[:4]], [to_device(w) for w in weights]
     dp = dp + dp[:3] + dp
     batch.fuse_views(r, cams, dp, dw)
-    assert sm._lib.lib().smesh_last_fuse_kernel().decode() in ("k_fuse_texel", "k_scatter_strip", "k_scatter_flat")   # (SMESH_FUSE=strip: Mul takes the float64-atomic flat path)
+    assert sm._lib.last_fuse_kernel() in ("k_fuse_texel", "k_scatter_strip", "k_scatter_flat")   # (SMESH_FUSE=strip: Mul takes the float64-atomic flat path)
     oracle.set_accum_double(kind == "mul")
     try:
         oagg = oracle.OracleAggregator(P, C, kind, 0.5)

@@ -77,7 +77,7 @@ for rep in range(repeats):
     agg = sm.fusion.MeshAggregator(P, C, kind)
     _, rows = smdist.fuse_views_sharded(renderer, agg, cams, probs_of_view, contiguous=(kind != "summax"), nparts=3)
     assert rows == (0, P)
-    kernel = _lib.lib().smesh_last_fuse_kernel().decode()
+    kernel = _lib.last_fuse_kernel()
     assert kernel.startswith("k_fuse_tri"), kernel            # the HIP triangle-order path ran on this rank's shard
     got, got_raw = agg.get(), agg.get_raw()
     # partial float32 sums added once instead of eight terms in order: 1e-5 for every aggregator (Mul's (hi, lo) pairs travel as float64)

@@ -25,7 +25,7 @@ def run(name, views, texels=False):
             agg.fuse_view(r, cam, probs)
         _lib.synchronize(0)
         dt = time.perf_counter() - t0
-        print("  pass %d: %.3f ms/view (%s)" % (rep, 1e3 * dt / len(cams), _lib.lib().smesh_last_fuse_kernel().decode()), flush=True)
+        print("  pass %d: %.3f ms/view (%s)" % (rep, 1e3 * dt / len(cams), _lib.last_fuse_kernel()), flush=True)
     idx = np.asarray(r.render(cams[0])[0])
     cov = idx != 0xFFFFFFFF
     assert idx[cov].max() < P

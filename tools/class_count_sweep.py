@@ -17,5 +17,5 @@ for C in (5, 13, 19, 21, 27, 32, 40, 41, 48, 49, 64, 100, 127, 150, 256):
     dt = (time.perf_counter() - t0) / len(cams)
     nbytes = 4.0 * W * H * C * 0.64 + 8.0 * C * 0.64e6   # visible probs rows + accumulator rows of ~0.64 M visible primitives
     print("C=%4d  %-16s %.3f ms/view  (~%.0f MB of rows -> %.2f TB/s incl. the rasteriser's 0.05 ms)" % (
-        C, _lib.lib().smesh_last_fuse_kernel().decode(), 1e3 * dt, nbytes / 1e6, nbytes / dt / 1e12), flush=True)
+        C, _lib.last_fuse_kernel(), 1e3 * dt, nbytes / 1e6, nbytes / dt / 1e12), flush=True)
     del probs, agg

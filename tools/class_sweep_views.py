@@ -17,4 +17,4 @@ for C in [int(x) for x in sys.argv[1:]]:
     for rep in range(3):
         agg.fuse_views(r, cams[:8], plist[:8]); agg.fuse_views(r, cams[8:], plist[8:])
     _lib.synchronize(0)
-    print("C = %3d: %.4f ms per view (%s, SMESH_FUSE_VIEWS=%s)" % (C, 1e3 * (time.perf_counter() - t0) / 48, _lib.lib().smesh_last_fuse_kernel().decode(), os.environ.get("SMESH_FUSE_VIEWS", "default")))
+    print("C = %3d: %.4f ms per view (%s, SMESH_FUSE_VIEWS=%s)" % (C, 1e3 * (time.perf_counter() - t0) / 48, _lib.last_fuse_kernel(), os.environ.get("SMESH_FUSE_VIEWS", "default")))

@@ -27,6 +27,7 @@ for a, b in meshes:
         cams.append(data.Camera(R, t, np.array([W, H]), np.array([0.8 * W, 0.8 * W]), np.array([W / 2.0, H / 2.0])))
     r = render.triangles(mesh)
     agg = fusion.MeshAggregator(len(mesh.faces), C)
+    agg.defer = False      # "fuse_view" = one library call per view; the Python layer's default groups such calls by eight (= the fuse_views column)
     out = []
     for name, fn in (("fuse_views", lambda: agg.fuse_views(r, cams, [probs] * 8)),
                      ("fuse_view", lambda: [agg.fuse_view(r, cam, probs) for cam in cams]),

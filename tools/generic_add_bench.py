@@ -29,5 +29,5 @@ N = W * H
 touched = int((agg.get_raw().sum(1) != 0).sum())
 bytes_per_view = 4 * N + 4 * N * C + 8 * C * touched
 print("%s: add() on foreign device images: %.3f ms/view, path %s, kernel %s, 8(d) bytes %.1f MB -> %.2f TB/s = %.2f of 8 TB/s" % (
-    name, 1e3 * dt, _lib.lib().smesh_last_add_path().decode(), _lib.lib().smesh_last_fuse_kernel().decode(), bytes_per_view / 1e6,
+    name, 1e3 * dt, _lib.last_add_path(), _lib.last_fuse_kernel(), bytes_per_view / 1e6,
     bytes_per_view / dt / 1e12, bytes_per_view / dt / 8e12), flush=True)

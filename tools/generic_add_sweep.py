@@ -26,4 +26,4 @@ for C in [int(c) for c in (sys.argv[1:] or "5 13 19 27 32 40 48 64 100 150".spli
         dt = (time.perf_counter() - t0) / len(images)
     out.append("C=%d %.3f" % (C, 1e3 * dt))
     del agg, probs
-print("%s (%s): ms/view %s" % (_lib.lib().smesh_last_add_path().decode(), _lib.lib().smesh_last_fuse_kernel().decode(), "  ".join(out)), flush=True)
+print("%s (%s): ms/view %s" % (_lib.last_add_path(), _lib.last_fuse_kernel(), "  ".join(out)), flush=True)

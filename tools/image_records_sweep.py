@@ -75,5 +75,5 @@ for seed in range(first, first + count):
     if rel > tol:
         fails += 1
         print("FAIL seed %d: %s %dx%d P=%d C=%d %s iew=%.1f rel %.3e path %s" % (seed, family, W, H, P, C, kind, iew, rel,
-              sm._lib.lib().smesh_last_add_path().decode()), flush=True)
+              sm._lib.last_add_path()), flush=True)
 print("%d scenes, %d failures, worst relative error (tight-tolerance scenes) %s, %.0f s" % (count, fails, worst, time.time() - t0), flush=True)

@@ -34,7 +34,7 @@ def main():
             kernels = set()
             for k, img in enumerate(images):
                 agg.add(img, bufs[k])
-                kernels.add(_lib.lib().smesh_last_fuse_kernel().decode())
+                kernels.add(_lib.last_fuse_kernel())
             _lib.synchronize(0)
             best = min(best, (time.perf_counter() - t0) / 6)
         print("%-24s %.4f ms per view  %s" % (label, 1e3 * best, sorted(kernels)), flush=True)

@@ -15,6 +15,7 @@ for a, b in meshes:
     cams = [synth.ring_camera(k, 8, W, H) for k in range(8)]
     r = render.triangles(mesh)
     agg = fusion.MeshAggregator(len(mesh.faces), C)
+    agg.defer = False      # "fuse_view" below = one library call per view (the Python layer would group them by eight: the fuse_views column)
     for cam in cams[:2]:
         agg.fuse_view(r, cam, probs)
     _lib.synchronize(0)

@@ -48,7 +48,7 @@ for seed in range(first, first + count):
     else:
         for cam, p, w in zip(cams, probs, weights):
             agg.fuse_view(r, cam, p, w)
-    kernel = sm._lib.lib().smesh_last_fuse_kernel().decode()
+    kernel = sm._lib.last_fuse_kernel()
     oracle.set_accum_double(True)
     oagg = oracle.OracleAggregator(P, C, "mul", iew)
     for cam, p, w in zip(cams, probs, weights):

@@ -23,4 +23,4 @@ for label, p in (("dense (W,H,C) device tensor", dense), ("(H,W,C) tensor permut
             agg.add(idx, p)
         _lib.synchronize(0)
         dt = (time.perf_counter() - t0) / len(cams)
-    print("render + add, %-48s %.3f ms/view (%s, %s)" % (label, 1e3 * dt, _lib.lib().smesh_last_add_path().decode(), _lib.lib().smesh_last_fuse_kernel().decode()), flush=True)
+    print("render + add, %-48s %.3f ms/view (%s, %s)" % (label, 1e3 * dt, _lib.last_add_path(), _lib.last_fuse_kernel()), flush=True)

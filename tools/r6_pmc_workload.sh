@@ -14,12 +14,18 @@ run sq2 "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_S
 run tcc "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"
 run fetch "FETCH_SIZE"
 run write "WRITE_SIZE"
+if [ -n "$R6_PMC_MEMPIPE" ]; then   # the vector-memory pipeline of a CU: address (TA), cache (TCP) and data (TD) units
+run ta "TA_TA_BUSY_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum TA_FLAT_WRITE_WAVEFRONTS_sum TA_FLAT_ATOMIC_WAVEFRONTS_sum GRBM_GUI_ACTIVE"
+run tcp "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum"
+run tcp2 "TCP_TCC_ATOMIC_WITH_RET_REQ_sum TCP_TCC_WRITE_REQ_LATENCY_sum TCP_TCP_LATENCY_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_TCR_TCP_STALL_CYCLES_sum"
+run td "TD_TD_BUSY_sum TD_TC_STALL_sum TD_LOAD_WAVEFRONT_sum TD_STORE_WAVEFRONT_sum TD_ATOMIC_WAVEFRONT_sum TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum TCP_TOTAL_WRITE_sum"
+fi
 cd $root
 OUT=$out python - <<'PY'
 import csv, collections, glob, os
 out = os.environ['OUT']
 res = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ('sq', 'sq2', 'tcc', 'fetch', 'write'):
+for d in ('sq', 'sq2', 'tcc', 'fetch', 'write', 'ta', 'tcp', 'tcp2', 'td'):
     for f in glob.glob('%s/%s/**/*counter_collection.csv' % (out, d), recursive=True):
         for r in csv.DictReader(open(f)):
             n = r['Kernel_Name'].replace('(anonymous namespace)::', '').split('(')[0]
@@ -41,4 +47,8 @@ with open(out + '/summary.txt', 'w') as fo:
                     m.get('FETCH_SIZE', 0) * 1024 / 1e6, m.get('WRITE_SIZE', 0) * 1024 / 1e6,
                     (2 * m.get('FETCH_SIZE', 0) + m.get('WRITE_SIZE', 0)) * 1024 / 1e6))
         print(line); fo.write(line + '\n')
+        extra = {k: v for k, v in m.items() if k.startswith(('TA_', 'TCP_', 'TD_', 'GRBM'))}
+        if extra:
+            line = '      ' + '  '.join('%s=%.4g' % kv for kv in sorted(extra.items()))
+            print(line); fo.write(line + '\n')
 PY

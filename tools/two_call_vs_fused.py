@@ -23,4 +23,4 @@ for mode in ("fuse_view", "render + add", "render + add (index image exported fi
                 agg.add(idx, probs)
         _lib.synchronize(0)
         dt = (time.perf_counter() - t0) / len(cams)
-    print("%-70s %.3f ms/view (%s)" % (mode, 1e3 * dt, _lib.lib().smesh_last_fuse_kernel().decode()), flush=True)
+    print("%-70s %.3f ms/view (%s)" % (mode, 1e3 * dt, _lib.last_fuse_kernel()), flush=True)
