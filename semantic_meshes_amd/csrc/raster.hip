@@ -1515,9 +1515,11 @@ bool plane_optional_allowed(const smesh_renderer* r) {
 }
 
 // Consecutive triangle blocks per run of an XCD (xcd_block).  SMESH_RASTER_XCD=n sets it; 0: blocks take consecutive triangles in
-// dispatch order, as until round 5.
+// dispatch order, as until round 5.  cfg2, eight views per launch (profiles/r06_raster_experiments.txt): k_raster_frag_group fetches
+// 149.6 MB with 0, 79.1 MB with 8 (x 2: gfx950's FETCH_SIZE unit) -- 562 -> 422 MB of traffic per launch -- and takes 195 -> 191 us; runs of
+// 2 / 32 / 128: 195.5 / 201 / 211 us.
 uint32_t raster_xcd_run() {
-  static const uint32_t run = getenv("SMESH_RASTER_XCD") ? (uint32_t)std::max(0, atoi(getenv("SMESH_RASTER_XCD"))) : 16u;
+  static const uint32_t run = getenv("SMESH_RASTER_XCD") ? (uint32_t)std::max(0, atoi(getenv("SMESH_RASTER_XCD"))) : 8u;
   return run;
 }
 

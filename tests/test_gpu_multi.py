@@ -353,10 +353,10 @@ assert np.array_equal(agg.get(), ref.get())
 import semantic_meshes_amd
 r2 = semantic_meshes_amd.render.triangles(mesh)
 idx2, depth2 = r2.render(cams[0])
-assert type(idx2).__name__ == "DeviceArray" and np.asarray(idx2).shape == (160, 120)
+assert isinstance(idx2, semantic_meshes_amd.device.DeviceArray) and np.asarray(idx2).shape == (160, 120)
 assert semantic_meshes_amd.render.RETURN_CAPSULES is False
 idx3, _ = semantic_meshes.render.triangles(mesh, capsules=False).render(cams[0])
-assert type(idx3).__name__ == "DeviceArray"
+assert isinstance(idx3, semantic_meshes_amd.device.DeviceArray)
 print("capsules ok")
 """ % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k != "SMESH_RENDER_CAPSULES"}

@@ -181,7 +181,7 @@ int gather_main() {
                total / 1e12 / (tp * 1e-3), total * 640.0 / 600.0 / 1e12 / (tp * 1e-3));
       }
       printf("gather of 600-B rows, footprint %2llu GB, %s: 2 in flight %6.2f TB/s   4 in flight %6.2f TB/s   8 in flight %6.2f TB/s   (%.1f GB read)\n",
-             (unsigned long long)gb, stride == 0 ? "hashed positions      " : stride == 1 ? "consecutive rows      " : "rows 2160 apart (x+1) ",
+             (unsigned long long)gb, stride == 0 ? "hashed positions      " : stride == 1 ? "consecutive rows [CACHE: every wave re-reads what its neighbours just fetched -- L2 / Infinity Cache rate, not HBM]" : "rows 2160 apart (x+1) ",
              total / 1e12 / (t2 * 1e-3), total / 1e12 / (t4 * 1e-3), total / 1e12 / (t8 * 1e-3), total / 1e9);
     }
     CK(hipFree(buf));
@@ -189,7 +189,86 @@ int gather_main() {
   return 0;
 }
 
+// ---- replay of a REAL address stream (round 6): what k_fuse_tri_wide reads at cfg5, taken from renders of the scene
+// itself (tools/dump_pixel_stream.py): per view the pixels of every triangle in triangle order -- wave w of the kernel owns triangles
+// [64 w, 64 w + 64) and reads the 600-byte class vector of each of their visible pixels, view after view, INFLIGHT rows at a time; with
+// ACC it also reads and writes back the 64 accumulator rows of its triangles once (those of triangles seen in any view).
+//   file: uint32 magic 0x534D5253, nviews, pixels per image, waves; then per view: uint32 start[waves + 1], uint32 row[start[waves]]
+template <int INFLIGHT, bool ACC>
+__global__ __launch_bounds__(64) void k_replay(const float* __restrict__ img, uint64_t img_floats, const uint32_t* const* __restrict__ start,
+                                               const uint32_t* const* __restrict__ row, int nviews, float* __restrict__ acc, float* sink) {
+  const int l = threadIdx.x, c = 4 * l;
+  const uint32_t w = blockIdx.x;
+  float s = 0.f;
+  bool any = false;
+  for (int v = 0; v < nviews; v++) {
+    const uint32_t a = start[v][w], b = start[v][w + 1];
+    any = any || b > a;
+    const float* __restrict__ im = img + (uint64_t)v * img_floats;
+    for (uint32_t i = a; i < b; i += INFLIGHT) {
+      fvec4 x[INFLIGHT];
+#pragma unroll
+      for (int k = 0; k < INFLIGHT; k++) {
+        x[k] = fvec4{0.f, 0.f, 0.f, 0.f};
+        if (i + k < b && c + 4 <= 150) x[k] = *reinterpret_cast<const fvec4_a4*>(im + (uint64_t)row[v][i + k] * 150u + c);
+      }
+#pragma unroll
+      for (int k = 0; k < INFLIGHT; k++) s += x[k].x + x[k].y + x[k].z + x[k].w;
+    }
+  }
+  if (ACC && any) {
+    // the wave's 64 rows are one contiguous 38 400-byte block: 2 400 sixteen-byte pieces, 64 lanes
+    fvec4_a4* blk = reinterpret_cast<fvec4_a4*>(acc + (uint64_t)w * 64u * 150u);
+    for (int p = l; p < 2400; p += 64) { fvec4 v = blk[p]; v += s; blk[p] = v; }
+  }
+  if (s == 123.456f) *sink = s;
+}
+
+int replay_main(const char* path) {
+  FILE* f = fopen(path, "rb");
+  if (!f) { printf("cannot open %s\n", path); return 1; }
+  uint32_t head[4];
+  if (fread(head, 4, 4, f) != 4 || head[0] != 0x534D5253u) { printf("bad stream file\n"); return 1; }
+  const int nviews = (int)head[1];
+  const uint64_t N = head[2];
+  const uint32_t waves = head[3];
+  float* img; CK(hipMalloc(&img, (uint64_t)nviews * N * 600)); CK(hipMemset(img, 0, (uint64_t)nviews * N * 600));
+  float* acc; CK(hipMalloc(&acc, (uint64_t)waves * 64 * 600)); CK(hipMemset(acc, 0, (uint64_t)waves * 64 * 600));
+  float* sink; CK(hipMalloc(&sink, 4));
+  const uint32_t* h_start[8]; const uint32_t* h_row[8];
+  uint64_t total_rows = 0, seen_waves = 0;
+  uint32_t* any_seen = (uint32_t*)calloc(waves, 4);
+  for (int v = 0; v < nviews; v++) {
+    uint32_t* st = (uint32_t*)malloc((size_t)(waves + 1) * 4);
+    if (fread(st, 4, waves + 1, f) != waves + 1) { printf("short file\n"); return 1; }
+    const uint32_t n = st[waves];
+    uint32_t* rw = (uint32_t*)malloc((size_t)(n ? n : 1) * 4);
+    if (fread(rw, 4, n, f) != n) { printf("short file\n"); return 1; }
+    for (uint32_t w = 0; w < waves; w++) if (st[w + 1] > st[w]) any_seen[w] = 1;
+    uint32_t *d_st, *d_rw;
+    CK(hipMalloc(&d_st, (size_t)(waves + 1) * 4)); CK(hipMalloc(&d_rw, (size_t)(n ? n : 1) * 4));
+    CK(hipMemcpy(d_st, st, (size_t)(waves + 1) * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_rw, rw, (size_t)n * 4, hipMemcpyHostToDevice));
+    h_start[v] = d_st; h_row[v] = d_rw; total_rows += n;
+    free(st); free(rw);
+  }
+  fclose(f);
+  for (uint32_t w = 0; w < waves; w++) seen_waves += any_seen[w];
+  const uint32_t** d_start; const uint32_t** d_row;
+  CK(hipMalloc(&d_start, 8 * sizeof(void*))); CK(hipMalloc(&d_row, 8 * sizeof(void*)));
+  CK(hipMemcpy(d_start, h_start, nviews * sizeof(void*), hipMemcpyHostToDevice)); CK(hipMemcpy(d_row, h_row, nviews * sizeof(void*), hipMemcpyHostToDevice));
+  const double gath = (double)total_rows * 600.0, accb = (double)seen_waves * 64 * 600.0 * 2.0;
+  printf("replay of %s: %d views, %llu pixels per image, %u waves of 64 triangles (%llu with a visible triangle), %llu class-vector rows = %.2f GB; their accumulator blocks both ways %.2f GB\n",
+         path, nviews, (unsigned long long)N, waves, (unsigned long long)seen_waves, (unsigned long long)total_rows, gath / 1e9, accb / 1e9);
+#define REPLAY(B, A) timeit([&] { hipLaunchKernelGGL((k_replay<B, A>), dim3(waves), dim3(64), 0, 0, img, N * 150, d_start, d_row, nviews, acc, sink); }, 3)
+  const float g2 = REPLAY(2, false), g4 = REPLAY(4, false), a2 = REPLAY(2, true), a4 = REPLAY(4, true);
+  printf("  class vectors only        : 2 in flight %8.3f ms = %5.2f TB/s    4 in flight %8.3f ms = %5.2f TB/s\n", g2, gath / 1e12 / (g2 * 1e-3), g4, gath / 1e12 / (g4 * 1e-3));
+  printf("  + accumulator blocks (r+w): 2 in flight %8.3f ms = %5.2f TB/s    4 in flight %8.3f ms = %5.2f TB/s\n", a2, (gath + accb) / 1e12 / (a2 * 1e-3), a4,
+         (gath + accb) / 1e12 / (a4 * 1e-3));
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc > 2 && argv[1][0] == 'p') return replay_main(argv[2]);      // (rePlay)
   if (argc > 1 && argv[1][0] == 'g') return gather_main();
   if (argc > 1 && argv[1][0] == 'l') return lane_main();
   const uint64_t maxb = 12ull << 30;
