@@ -1039,6 +1039,9 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_any(TriFuseArgs a, TriViews<
 // does it replay the additions one class at a time (never for probability rows, whose sums are ~1 or 0).
 // ------------------------------------------------------------------------------------------------
 // One lane's share of a row: NCH chunks of four classes, chunk k covering classes 4 (l + 64 k) .. + 3.
+// (The row's tail -- C = 150 leaves two classes to lane 37 -- costs that lane two or three single-dword instructions.  Round 6 moved the
+// row's last four classes with ONE 16-byte instruction instead, the lane keeping / composing what is its own: k_fuse_tri_wide 1 654 ->
+// 1 872 us per cfg5 view.  Overlapping, unaligned pieces are worse than three instructions; not kept.)
 template <int NCH>
 __device__ __forceinline__ void load_wide(const float* __restrict__ src, uint32_t C, int l, fvec4 (&v)[NCH]) {
 #pragma unroll
@@ -1377,6 +1380,173 @@ __global__ __launch_bounds__(kWave) void k_fuse_tri_wide(TriFuseArgs a, TriViews
 #pragma unroll
     for (int b = 0; b < B; b++)
       if (t[b] >= 0 && !(SMESH_ABL(a.dbg) & 2)) store_wide<NCH>(a.acc + (uint64_t)rowid[b] * C, C, l, ac[b]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_fuse_tri_wide for Sum as a walk over a PIXEL LIST (round 6).  A replay of a cfg5 launch's REAL address stream with nothing around it
+// (tools/stream_bench p, profiles/r06_stream_replay_cfg5.txt: the class vectors triangle after triangle, every visible triangle's row
+// read and written once) takes 8.6 ms; the kernel above took 13.1, and its development build without any row or class-vector access
+// still 6.2: what it executes per pixel beside the two memory instructions -- finding the stream's next view with pixels of the
+// triangle, bit scans of 64-bit masks, the pixel's address, the view's pointers read back from LDS: ~80 scalar and ~70 vector
+// instructions per 600-byte row -- did not hide under the memory time.  Here the 64 lanes first write, lane = triangle and all at once,
+// the pixels of their triangles -- views in order, a view's pixels in image order: the order of the additions -- into a list in LDS; then
+// the wave walks the list with nothing left to decide, through a RING of K loads: entry i is consumed from slot i % K, which is
+// refilled with entry i + K at once, and a slot also carries the accumulator row of the triangle that starts at its entry.  K class
+// vectors (and the rows of the triangles ahead) are in flight at every moment, whatever triangle or view they belong to.
+// cfg5: 1 651 -> 1 125 us per view (replay: 1 075), 504 -> 681 views/s.  Per accumulator row the same float32 additions in the same
+// order as the kernel above: bit-equal raw accumulators (tests/test_gpu_parity.py).  Seven waves per SIMD (72 registers, 46 spilled
+// around the records phase): 6 / 7 / 8 waves 1 200 / 1 125 / 1 231 us.  A chunk of the list holds whole triangles (at most 8 x 64
+// entries each); a wave with more pixels than kWideCap walks several chunks, reloading its records for each.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWideCap = 512;      // entries of a chunk of the list (a triangle has at most 8 views x 64 pixels = 512)
+struct WideList {
+  TriView view[8];
+  float w0[64];            // iew / n + (1 - iew) for n = 1 .. 64 pixels of a triangle in a view (Mesh.h:90-93, 100-102)
+  uint32_t px[kWideCap];   // pixel (x * H + y, < 2^29: check_camera) | view << 29
+  uint16_t nl[kWideCap];   // n - 1 | the triangle's lane << 6
+};                         // (3.9 KB: the LDS must not be what limits the waves per SIMD)
+
+template <int KIND, int NCH>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_fuse_tri_wide_list(TriFuseArgs a, TriViews<8> vw, int nv) {
+  static_assert(KIND != SMESH_AGG_MUL, "Mul folds a view's terms once per view: k_fuse_tri_wide");
+  constexpr int K = NCH == 1 ? 4 : 2;      // class vectors in flight per wave: a ring of K slots, refilled as they are consumed
+  __shared__ WideList S;
+  const int l = threadIdx.x;
+  const uint32_t C = a.C;
+  uint32_t blk = blockIdx.x;
+  if (a.xcd_chunk) {
+    const uint32_t sq = blk >> 3, q = sq / a.xcd_chunk;
+    blk = (q * 8u + (blk & 7u)) * a.xcd_chunk + (sq - q * a.xcd_chunk);
+    if (blk >= a.tri_blocks) return;   // block-uniform
+  }
+  const uint64_t f0 = ((uint64_t)a.blk_first + blk) * kWave;
+  const uint64_t f = f0 + l;
+  const uint32_t pid = (a.prim_id && f < a.F) ? a.prim_id[f] : (uint32_t)f;
+  if (l == 0) {
+#pragma unroll
+    for (int v = 0; v < 8; v++) S.view[v] = vw.v[v];
+  }
+  S.w0[l] = a.iew * (1.0f / ((float)(l + 1))) + (1 - a.iew) * 1.0f;              // Mesh.h:100-102 for l + 1 pixels
+  uint32_t cnt = 0u, inc = 0u, exc = 0u;   // this triangle's entries (its visible pixels over the launch's views), and their running sums over the lanes
+  unsigned long long vis = 0ull;
+  uint32_t base = 0u;                // entries of the chunks before this one
+  int s = 0;                         // first lane (triangle) of this chunk
+  for (bool first = true;; first = false) {
+    // The triangles' records of every view -> the masks of their visible pixels.  Per CHUNK (a wave almost always has one): kept across the
+    // walk below, the eight masks and origins would cost the kernel a wave per SIMD.
+    unsigned long long win[8];
+    uint32_t org[8];
+    bool big = false;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+      win[v] = 0ull;
+      org[v] = 0u;
+      if (v < nv) {
+        TriFrag rec;
+        rec.x0 = 0; rec.y0 = 0; rec.kind = 0; rec.pad = 0; rec.mask = 0ull;
+        if (f < a.F) rec = vw.v[v].frags[f];
+        org[v] = (uint32_t)rec.x0 | ((uint32_t)rec.y0 << 16);
+        big = big || rec.kind == 2;
+        unsigned long long m = rec.kind == 1 ? rec.mask : 0ull;
+        // pass 1, lane = triangle, normally skipped: the tile resolve has cleared the losers out of the masks (k_fuse_tri)
+        if (!a.prim_id && vw.v[v].big_len[1] == 0u) { win[v] = m; m = 0ull; }
+        const uint32_t* __restrict__ idx = vw.v[v].idx;
+        const uint32_t Hv = vw.v[v].H;
+        while (__ballot(m != 0ull) != 0ull) {
+          int k[4];
+          uint32_t got[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            k[j] = -1;
+            if (m) { k[j] = __ffsll((long long)m) - 1; m &= m - 1ull; }
+            got[j] = idx[k[j] >= 0 ? (uint64_t)(rec.x0 + (k[j] >> 3)) * Hv + rec.y0 + (k[j] & 7) : 0];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (k[j] >= 0 && got[j] == pid) win[v] |= 1ull << k[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int v = 0; v < 8; v++)
+      if (big) win[v] = 0ull;          // (a triangle that is big in any of the views belongs to k_fuse_big_any for all of them)
+    if (first) {
+#pragma unroll
+      for (int v = 0; v < 8; v++) cnt += (uint32_t)__popcll(win[v]);
+      vis = __ballot(cnt != 0u);
+      if (vis == 0ull || (SMESH_ABL(a.dbg) & 1)) return;
+      inc = wave_scan_incl_u(cnt);
+      exc = inc - cnt;
+      wave_sync();                     // (S.view is in LDS)
+    }
+    // the chunk: the longest run of lanes from s on whose entries fit the list (inc is monotone: the lanes that fit are a run)
+    const unsigned long long fit = __ballot(l >= s && inc - base <= (uint32_t)kWideCap);
+    const int e1 = s + (int)__popcll(fit);     // one past the chunk's last lane (>= s + 1: a triangle has at most 512 entries)
+    if (l >= s && l < e1 && cnt != 0u) {
+      uint32_t pos = exc - base;
+#pragma unroll
+      for (int v = 0; v < 8; v++) {
+        if (win[v] == 0ull) continue;
+        const uint32_t nt = (uint32_t)__popcll(win[v]);                                   // this primitive's pixels in this view (Mesh.h:90-93)
+        const uint32_t Hv = S.view[v].H, ox = org[v] & 0xFFFFu, oy = org[v] >> 16;
+        for (unsigned long long m = win[v]; m; m &= m - 1ull) {                          // ascending bits = image order (x, then y)
+          const int k = __ffsll((long long)m) - 1;
+          S.px[pos] = ((ox + (uint32_t)(k >> 3)) * Hv + oy + (uint32_t)(k & 7)) | ((uint32_t)v << 29);
+          S.nl[pos] = (uint16_t)((nt - 1u) | ((uint32_t)l << 6));
+          pos++;
+        }
+      }
+    }
+    wave_sync();
+    // ---- the walk: entry i of the chunk is consumed from ring slot i % K, which is refilled with entry i + K at once.  A slot also
+    // carries the accumulator row of the triangle that STARTS at its entry, requested together with the entry's class vector, so the
+    // row is there when the walk arrives.  Everything about an entry is wave-uniform (scalar registers).
+    const uint32_t n = (e1 >= 64 ? (uint32_t)__builtin_amdgcn_readlane((int)inc, 63) : (uint32_t)__builtin_amdgcn_readlane((int)inc, e1 - 1)) - base;
+    fvec4 p[K][NCH], rw[K][NCH], ac[NCH];
+    float w[K];
+    uint32_t rid[K];
+    bool start[K];
+    uint32_t prev_issued = 0xFFFFFFFFu;      // row of the entry issued last
+    auto issue = [&](const int k, const uint32_t j) {
+      const uint32_t ex = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.px[j]);
+      const uint32_t en = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.nl[j]);
+      const uint32_t ew = (uint32_t)__builtin_amdgcn_readfirstlane(__float_as_int(S.w0[en & 63u]));
+      rid[k] = (uint32_t)__builtin_amdgcn_readlane((int)pid, (int)(en >> 6));
+      const uint32_t v = ex >> 29;
+      const uint64_t pix = ex & 0x1FFFFFFFu;
+      const float* probs = uniform_ptr(S.view[v].probs);
+      const float* weights = uniform_ptr(S.view[v].weights);
+      if (!(SMESH_ABL(a.dbg) & 8)) load_wide<NCH>(probs + pix * C, C, l, p[k]);
+      w[k] = __uint_as_float(ew) * (weights ? weights[pix] : 1.0f);
+      start[k] = rid[k] != prev_issued;
+      if (start[k] && !(SMESH_ABL(a.dbg) & 4)) load_wide<NCH>(a.acc + (uint64_t)rid[k] * C, C, l, rw[k]);
+      prev_issued = rid[k];
+    };
+#pragma unroll
+    for (int k = 0; k < K; k++) { w[k] = 0.0f; rid[k] = 0u; start[k] = false; if ((uint32_t)k < n) issue(k, (uint32_t)k); }
+    uint32_t cur = 0xFFFFFFFFu;
+    for (uint32_t i0 = 0; i0 < n; i0 += K) {
+#pragma unroll
+      for (int k = 0; k < K; k++) {
+        const uint32_t i = i0 + (uint32_t)k;
+        if (i < n) {
+          if (start[k]) {
+            if (cur != 0xFFFFFFFFu && !(SMESH_ABL(a.dbg) & 2)) store_wide<NCH>(a.acc + (uint64_t)cur * C, C, l, ac);
+            cur = rid[k];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) ac[c] = rw[k][c];
+          }
+          fuse_pixel_wide<KIND, NCH>(ac, p[k], C, l, w[k]);            // Mesh.h:103
+          if (i + K < n) issue(k, i + K);
+        }
+      }
+    }
+    if (cur != 0xFFFFFFFFu && !(SMESH_ABL(a.dbg) & 2)) store_wide<NCH>(a.acc + (uint64_t)cur * C, C, l, ac);
+    if (e1 >= 64 || (vis >> e1) == 0ull) break;
+    base += n;
+    s = e1;
+    wave_sync();                     // (the list is rewritten)
   }
 }
 
@@ -2315,6 +2485,22 @@ void smesh_fuse_part_rows(uint64_t F, int part, int nparts, uint64_t* f_lo, uint
 // `nviews` = 1, 2, 4 or 8 (smesh_aggregator_max_fused_views): views[0], views[1] ... of the same renderer in one launch.
 // `part` / `nparts`: only the triangles of smesh_fuse_part_rows(F, part, nparts) -- the queued medium triangles (fuse_mid_entries, float
 // atomics) all go with part 0, the queued big ones with the part their position falls into.
+// Sum rows of 128 .. 255 classes: the pixel-list kernel (k_fuse_tri_wide_list; SMESH_WIDE_LIST=0: k_fuse_tri_wide as until round 5).
+// false: not launched.  Where it is used and where not is measured (cfg2's mesh and resolution, eight views per call, ms per view, old /
+// list kernel; profiles/r06_wide_rows_sweep.txt): Sum C = 128 0.405 / 0.381, 150 0.467 / 0.406, 192 0.438 / 0.407, 240 0.454 / 0.439 --
+// 256 (rows of whole aligned lines) 0.371 / 0.454, 300 0.528 / 0.558, 1024 1.361 / 1.441; Summax (its arg-max needs registers the ring
+// has taken: spills) 150 0.638 / 0.694.  cfg5 (20 M sub-pixel triangles, C = 150): 1 651 / 1 125 us per view.
+template <int KIND>
+static bool launch_fuse_wide_list(int wide_chunks, uint32_t C, dim3 wgrid, hipStream_t st, const TriFuseArgs& t, const TriViews<8>& tv, int nviews) {
+  static const bool off = getenv("SMESH_WIDE_LIST") && atoi(getenv("SMESH_WIDE_LIST")) == 0;
+  if constexpr (KIND != SMESH_AGG_SUM) return false;
+  else {
+    if (off || wide_chunks != 1 || C >= 256u) return false;
+    hipLaunchKernelGGL((k_fuse_tri_wide_list<KIND, 1>), wgrid, dim3(kWave), 0, st, t, tv, nviews);
+    return true;
+  }
+}
+
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews, int part, int nparts) {
   DeviceCtx* ctx = a->ctx;
@@ -2468,7 +2654,9 @@ int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint3
       case 41: hipLaunchKernelGGL((k_fuse_tri<40, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
       case 48: hipLaunchKernelGGL((k_fuse_tri<48, K, false, 1>), grid, block, 0, st, t, tv1); break;   \
       default:                                                                                \
-        if (!t.tri_blocks) { } else if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }   \
+        if (!t.tri_blocks) { }                                                                \
+        else if (wide_chunks && launch_fuse_wide_list<K>(wide_chunks, a->C, wgrid, st, t, tv, nviews)) { }   \
+        else if (wide_chunks) { SMESH_FW(K); } else { SMESH_FA(K); }                          \
         if (!no_big) hipLaunchKernelGGL((k_fuse_big_any<K>), bgrid, block, 0, st, t, tv, nviews, pw, amax, scratch_stride); \
         break;                                                                                \
     }

@@ -27,10 +27,13 @@ DEFER_VIEWS = os.environ.get("SMESH_DEFER_VIEWS", "1") != "0"       # default of
 
 import weakref                                                       # noqa: E402
 _aggregators = weakref.WeakSet()
+_aggregators_lock = threading.Lock()      # (aggregators are created and flushed from different threads in the harness)
 
 
 def _flush_device(device=None):
-    for a in list(_aggregators):
+    with _aggregators_lock:
+        live = list(_aggregators)
+    for a in live:
         if (device is None or a.device == device) and a._pending:
             a.flush()
 
@@ -58,7 +61,8 @@ class _MeshAggregator:
         self._pending = []      # [(renderer, CameraPOD, W, H, probs array, weights array or None)]
         self._pending_lock = threading.RLock()
         self.defer = DEFER_VIEWS
-        _aggregators.add(self)
+        with _aggregators_lock:
+            _aggregators.add(self)
 
     @property
     def _h(self):

@@ -1529,3 +1529,51 @@ def test_huge_stage_is_left_out_only_where_it_is_provably_empty(sm, oracle):
     mesh2, cams2, _ = synth.scene("cfg2")
     r2 = sm.render.triangles(mesh2)
     assert not any(r2.render_stats(c, queues=False)[0] for c in cams2[::17])
+
+
+WIDE_LIST_SCRIPT = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["SMESH_ROOT"]); sys.path.insert(0, os.path.join(os.environ["SMESH_ROOT"], "tests"))
+import semantic_meshes_amd as sm
+from semantic_meshes_amd import synth, _lib
+from helpers import small_scene
+out = {}
+for name, (ga, gb) in (("fine", (170, 81)), ("six_pixel_boxes", (50, 25))):
+    mesh, cams = small_scene(ga, gb, 320, 240, views=11)
+    P = len(mesh.faces)
+    r = sm.render.triangles(mesh)
+    for C in (150, 131):
+        probs = [synth.device_probs(320, 240, C, synth.probs_seed(9, k), 0.05, 0) for k in range(len(cams))]
+        agg = sm.fusion.MeshAggregator(P, C)
+        agg.fuse_views(r, cams[:8], probs[:8])
+        agg.fuse_views(r, cams[8:], probs[8:])
+        agg.defer = False
+        agg.fuse_view(r, cams[0], probs[0])
+        assert _lib.last_fuse_kernel() == "k_fuse_tri_wide"
+        out["%s_%d" % (name, C)] = agg.get_raw()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def test_wide_rows_pixel_list_kernel_equals_the_stream_kernel_bit_for_bit(tmp_path, sm):
+    """k_fuse_tri_wide_list (round 6: Sum, 128 <= C < 256 -- the wave's pixels written to a list in LDS first, then walked through a ring of loads)
+    against k_fuse_tri_wide (SMESH_WIDE_LIST=0): per accumulator row the same float32 additions in the same order, so the raw accumulators are
+    bit-equal -- on a fine mesh (a few entries per triangle) and on one of six-pixel boxes seen in eight views (thousands of entries per wave:
+    the list is walked in several chunks), C = 150 (a row tail of two classes) and 131 (of three)."""
+    import os
+    import subprocess
+    import sys
+    script = os.path.join(tmp_path, "wide.py")
+    open(script, "w").write(WIDE_LIST_SCRIPT)
+    got = {}
+    for knob in ("0", "1"):
+        path = os.path.join(tmp_path, "raw%s.npz" % knob)
+        env = dict(os.environ, SMESH_WIDE_LIST=knob, SMESH_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        res = subprocess.run([sys.executable, script, path], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+        got[knob] = np.load(path)
+    for key in got["0"].files:
+        a, b = got["0"][key], got["1"][key]
+        assert (a != 0).sum() > a.size // 8, key
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), key

@@ -17,6 +17,7 @@ mesh = synth.grid_mesh(cfg["a"], cfg["b"])
 F = len(mesh.faces)
 waves = (F + 63) // 64
 r = render.triangles(mesh)
+merged_tri, merged_ent = [], []
 with open(out, "wb") as f:
     np.array([0x534D5253, views, W * H, waves], np.uint32).tofile(f)
     for k in range(views):
@@ -28,4 +29,17 @@ with open(out, "wb") as f:
         start = np.searchsorted(tri[:n], np.arange(0, waves + 1, dtype=np.uint64) * 64).astype(np.uint32)
         start.tofile(f)
         order[:n].tofile(f)
+        merged_tri.append(tri[:n].astype(np.uint32))
+        merged_ent.append(order[:n] | np.uint32(k << 29))
         print("view %d: %d visible pixels of %d, %d of %d triangles seen" % (k, n, W * H, len(np.unique(tri[:n])), F), flush=True)
+    # ... and the same rows in the order the KERNEL walks them: triangle after triangle, a triangle's views in order (stable sort by triangle of
+    # the views' lists laid end to end) -- uint32 start[waves + 1], uint32 entry[n] (pixel | view << 29), uint32 triangle[n]
+    tri_all = np.concatenate(merged_tri)
+    ent_all = np.concatenate(merged_ent)
+    o = np.argsort(tri_all, kind="stable")
+    tri_all, ent_all = tri_all[o], ent_all[o]
+    start = np.searchsorted(tri_all, np.arange(0, waves + 1, dtype=np.uint64) * 64).astype(np.uint32)
+    start.tofile(f)
+    ent_all.tofile(f)
+    tri_all.tofile(f)
+    print("merged: %d rows of %d triangles" % (len(tri_all), len(np.unique(tri_all))), flush=True)

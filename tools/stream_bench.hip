@@ -224,6 +224,50 @@ __global__ __launch_bounds__(64) void k_replay(const float* __restrict__ img, ui
   if (s == 123.456f) *sink = s;
 }
 
+// The same rows in the KERNEL's order: triangle after triangle (a triangle's views in order), INFLIGHT class vectors at a time whatever
+// triangle they belong to.  ROWS: 0 = class vectors only; 1 = + the wave's 64-row accumulator block once at the end (as k_replay);
+// 2 = + each visible triangle's own 600-byte row read before its first pixel and written after its last (what the kernels do).
+template <int INFLIGHT, int ROWS>
+__global__ __launch_bounds__(64) void k_replay_merged(const float* __restrict__ img, uint64_t img_floats, const uint32_t* __restrict__ start,
+                                                      const uint32_t* __restrict__ ent, const uint32_t* __restrict__ tri, float* __restrict__ acc, float* sink) {
+  const int l = threadIdx.x, c = 4 * l;
+  const uint32_t w = blockIdx.x;
+  const uint32_t a = start[w], b = start[w + 1];
+  float s = 0.f;
+  uint32_t cur = 0xFFFFFFFFu;
+  fvec4 row = fvec4{0.f, 0.f, 0.f, 0.f};
+  for (uint32_t i = a; i < b; i += INFLIGHT) {
+    fvec4 x[INFLIGHT];
+    uint32_t t[INFLIGHT];
+#pragma unroll
+    for (int k = 0; k < INFLIGHT; k++) {
+      x[k] = fvec4{0.f, 0.f, 0.f, 0.f};
+      t[k] = 0xFFFFFFFFu;
+      if (i + k < b) {
+        const uint32_t e = ent[i + k];
+        t[k] = tri[i + k];
+        if (c + 4 <= 150) x[k] = *reinterpret_cast<const fvec4_a4*>(img + (uint64_t)(e >> 29) * img_floats + (uint64_t)(e & 0x1FFFFFFFu) * 150u + c);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < INFLIGHT; k++) {
+      if (ROWS == 2 && t[k] != 0xFFFFFFFFu && t[k] != cur) {
+        if (cur != 0xFFFFFFFFu && c + 4 <= 150) *reinterpret_cast<fvec4_a4*>(acc + (uint64_t)cur * 150u + c) = row;
+        cur = t[k];
+        if (c + 4 <= 150) row = *reinterpret_cast<const fvec4_a4*>(acc + (uint64_t)cur * 150u + c);
+      }
+      row += x[k];
+      s += x[k].x + x[k].y + x[k].z + x[k].w;
+    }
+  }
+  if (ROWS == 2 && cur != 0xFFFFFFFFu && c + 4 <= 150) *reinterpret_cast<fvec4_a4*>(acc + (uint64_t)cur * 150u + c) = row;
+  if (ROWS == 1 && b > a) {
+    fvec4_a4* blk = reinterpret_cast<fvec4_a4*>(acc + (uint64_t)w * 64u * 150u);
+    for (int p = l; p < 2400; p += 64) { fvec4 v = blk[p]; v += s; blk[p] = v; }
+  }
+  if (s == 123.456f) *sink = s;
+}
+
 int replay_main(const char* path) {
   FILE* f = fopen(path, "rb");
   if (!f) { printf("cannot open %s\n", path); return 1; }
@@ -251,6 +295,26 @@ int replay_main(const char* path) {
     h_start[v] = d_st; h_row[v] = d_rw; total_rows += n;
     free(st); free(rw);
   }
+  // the merged (triangle-major) section, if the file has one
+  uint32_t *d_mstart = nullptr, *d_ment = nullptr, *d_mtri = nullptr;
+  uint64_t merged_rows = 0, merged_tris = 0;
+  {
+    uint32_t* st = (uint32_t*)malloc((size_t)(waves + 1) * 4);
+    if (fread(st, 4, waves + 1, f) == waves + 1) {
+      const uint32_t n = st[waves];
+      uint32_t* en = (uint32_t*)malloc((size_t)(n ? n : 1) * 4);
+      uint32_t* tr = (uint32_t*)malloc((size_t)(n ? n : 1) * 4);
+      if (fread(en, 4, n, f) == n && fread(tr, 4, n, f) == n) {
+        CK(hipMalloc(&d_mstart, (size_t)(waves + 1) * 4)); CK(hipMalloc(&d_ment, (size_t)(n ? n : 1) * 4)); CK(hipMalloc(&d_mtri, (size_t)(n ? n : 1) * 4));
+        CK(hipMemcpy(d_mstart, st, (size_t)(waves + 1) * 4, hipMemcpyHostToDevice));
+        CK(hipMemcpy(d_ment, en, (size_t)n * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(d_mtri, tr, (size_t)n * 4, hipMemcpyHostToDevice));
+        merged_rows = n;
+        for (uint32_t i = 0; i < n; i++) merged_tris += (i == 0 || tr[i] != tr[i - 1]) ? 1 : 0;
+      }
+      free(en); free(tr);
+    }
+    free(st);
+  }
   fclose(f);
   for (uint32_t w = 0; w < waves; w++) seen_waves += any_seen[w];
   const uint32_t** d_start; const uint32_t** d_row;
@@ -264,6 +328,19 @@ int replay_main(const char* path) {
   printf("  class vectors only        : 2 in flight %8.3f ms = %5.2f TB/s    4 in flight %8.3f ms = %5.2f TB/s\n", g2, gath / 1e12 / (g2 * 1e-3), g4, gath / 1e12 / (g4 * 1e-3));
   printf("  + accumulator blocks (r+w): 2 in flight %8.3f ms = %5.2f TB/s    4 in flight %8.3f ms = %5.2f TB/s\n", a2, (gath + accb) / 1e12 / (a2 * 1e-3), a4,
          (gath + accb) / 1e12 / (a4 * 1e-3));
+  if (d_mstart) {
+    const double rowb = (double)merged_tris * 600.0 * 2.0;
+    printf("the same %llu rows triangle-major (the kernels' order: a triangle's views one after the other), %llu visible triangles (their rows both ways: %.2f GB)\n",
+           (unsigned long long)merged_rows, (unsigned long long)merged_tris, rowb / 1e9);
+#define REPLAYM(B, R) timeit([&] { hipLaunchKernelGGL((k_replay_merged<B, R>), dim3(waves), dim3(64), 0, 0, img, N * 150, d_mstart, d_ment, d_mtri, acc, sink); }, 3)
+    const float m2 = REPLAYM(2, 0), m4 = REPLAYM(4, 0), m8 = REPLAYM(8, 0), b2 = REPLAYM(2, 1), b4 = REPLAYM(4, 1), r2 = REPLAYM(2, 2), r4 = REPLAYM(4, 2), r8 = REPLAYM(8, 2);
+    printf("  class vectors only             : 2 in flight %8.3f ms = %5.2f TB/s    4 in flight %8.3f ms = %5.2f TB/s    8 in flight %8.3f ms = %5.2f TB/s\n",
+           m2, gath / 1e12 / (m2 * 1e-3), m4, gath / 1e12 / (m4 * 1e-3), m8, gath / 1e12 / (m8 * 1e-3));
+    printf("  + accumulator blocks (r+w)     : 2 in flight %8.3f ms = %5.2f TB/s    4 in flight %8.3f ms = %5.2f TB/s\n", b2, (gath + accb) / 1e12 / (b2 * 1e-3), b4,
+           (gath + accb) / 1e12 / (b4 * 1e-3));
+    printf("  + each triangle's own row (r+w): 2 in flight %8.3f ms = %5.2f TB/s    4 in flight %8.3f ms = %5.2f TB/s    8 in flight %8.3f ms = %5.2f TB/s\n",
+           r2, (gath + rowb) / 1e12 / (r2 * 1e-3), r4, (gath + rowb) / 1e12 / (r4 * 1e-3), r8, (gath + rowb) / 1e12 / (r8 * 1e-3));
+  }
   return 0;
 }
 
