@@ -70,7 +70,7 @@ def pmc_traffic(workload, kernel_prefix, steps, warmup):
             cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "bench", "--", sys.executable,
                    os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", str(steps), "--warmup", str(warmup), "--repeats", "1",
                    "--no-cpu-baseline", "--no-host-path", "--no-pmc", "--no-group-pipeline"]
-            env = dict(os.environ, TMPDIR="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp", SMESH_BENCH_PROBS_GB="40")
             env.pop("RANK", None)
             try:
                 subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
@@ -95,10 +95,12 @@ def pmc_traffic(workload, kernel_prefix, steps, warmup):
     # k_fuse_tri<C, kind, exact, NV>: one instance per view count; the run-time-view kernels (k_fuse_tri_any / _wide / k_fuse_texel_multi) have one
     cands = [n for n in per["FETCH_SIZE"] if kernel_prefix in n and n in per["WRITE_SIZE"] and "_big" not in n]
     if not cands:
-        return None, "no launch of %s in the counter files" % kernel_prefix
+        return None, "no launch of %s in both counter files (FETCH_SIZE pass: %s; WRITE_SIZE pass: %s)" % (
+            kernel_prefix, sorted(n for n in per["FETCH_SIZE"] if "fuse" in n)[:4], sorted(n for n in per["WRITE_SIZE"] if "fuse" in n)[:4])
     by_nv, names = {}, {}
     for n in cands:
-        tail = n.rstrip(">").rsplit(",", 1)[-1].strip() if n.endswith(">") else ""
+        # (only k_fuse_tri<C, kind, exact, NV> carries its views per launch as its last template argument; k_fuse_tri_wide_list<kind, chunks> does not)
+        tail = n.rstrip(">").rsplit(",", 1)[-1].strip() if (n.endswith(">") and "k_fuse_tri<" in n) else ""
         nv = int(tail) if tail.isdigit() and int(tail) in (1, 2, 4, 8) else 0
         t = int((2.0 * per["FETCH_SIZE"][n] + per["WRITE_SIZE"][n]) * 1024)
         if nv not in by_nv or t > by_nv[nv]:
@@ -469,7 +471,10 @@ def main():
 
     # ---- inputs resident in HBM before the timed region: one distinct probs image per view -------------
     # (cfg2: 210 x 157.6 MB = 33 GB.  Larger workloads cycle through as many images as fit in ~120 GB of HBM.)
-    nbuf = max(1, min(total_views, int(120e9 // (4.0 * W * H * C))))
+    # (SMESH_BENCH_PROBS_GB: the counter passes of `--pmc` run as child processes BESIDE this one, whose images stay resident -- they cycle
+    # through 40 GB of images instead of 120, or cfg5's two processes would not fit the 288 GB together)
+    probs_budget = 1e9 * float(os.environ.get("SMESH_BENCH_PROBS_GB", "120"))
+    nbuf = max(1, min(total_views, int(probs_budget // (4.0 * W * H * C))))
     bufs = [synth.device_probs(W, H, C, synth.probs_seed(1, k), 0.0, device) for k in view_ids[:nbuf]]
     probs = [bufs[i % nbuf] for i in range(total_views)]
     _lib.synchronize(device)
@@ -763,7 +768,8 @@ def main():
                         traffic = entry.get("hbm_bytes_per_launch")
                         vpl_entry = 8 if tkey.endswith("_x8") else 2 if tkey.endswith("_pair") else 1
                         traffic_timed = traffic / vpl_entry * k_views
-                        traffic_source = "profiles/fusion_traffic.json [%s] (committed PMC passes of an EARLIER round; `--pmc` measures it in the run)" % tkey
+                        traffic_source = ("profiles/fusion_traffic.json [%s] (committed PMC passes of an EARLIER round; `--pmc` measures it in the run%s)"
+                                          % (tkey, "; this run's passes: " + note if note else ""))
                 except Exception:
                     traffic = None
             if traffic is None and note:
