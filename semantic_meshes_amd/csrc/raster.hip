@@ -812,7 +812,10 @@ __device__ __forceinline__ void coop_walk(const RasterArgs& a, const Tri& t, con
 
 // MODE (an instance of the kernels per mode: the code of the other modes costs the small-triangle instance registers it does not
 // have -- k_raster_frag_group is held to 96 for five waves per SIMD): bit 0 = RasterArgs::wg_push, bit 1 = RasterArgs::spread,
-// bit 2 = texel primitives (RasterArgs::tex_res != nullptr; emit_cover).  (Round 6 also built instances whose lanes project their
+// bit 2 = texel primitives (RasterArgs::tex_res != nullptr; emit_cover).  (Round 6 also built a bit 3: an 8-byte PIXEL CELL per vertex -- first / last
+// sample column and row a box ending / beginning there can reach -- read first, so that the seven in eight sub-pixel triangles of cfg4 that hold no
+// sample centre are dropped on 24 bytes instead of 72: k_raster_frag_group 667 -> 728 us per eight cfg4 views, 2 342 -> 2 579 at cfg5, the vertex stage
+// 97 -> 125: a second dependent round trip for every wave costs more than the bytes.  Not kept.)  (Round 6 also built instances whose lanes project their
 // triangles' vertices themselves -- no vertex stage, no 24-byte record per vertex and view: k_raster_frag_group 195 -> 242 us per eight
 // cfg2 views for 24 us of vertex stage saved, cfg4 668 -> 814 for 106; not kept.)
 template <int MODE>
@@ -1183,8 +1186,11 @@ __global__ __launch_bounds__(256) void k_raster_huge(RasterArgs a, uint32_t ntil
 // One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
 // > 8 x 8: the workgroup scans their queue, keeps those whose box overlaps the tile and shades the overlap, 256
 // samples at a time), then the output planes are written once.  "Big" here means larger than kMedium x kMedium.
+// `planes_wanted()`: false = nobody will read this view's planes (RasterArgs::idx_optional; decided by the kernel for the whole launch, asked
+// only where the planes would be written: its loads are not on the block's way in).
+template <typename PlanesWanted>
 __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out,
-                                                   const uint32_t tile) {
+                                                   const uint32_t tile, PlanesWanted planes_wanted) {
   __shared__ unsigned long long skeys[kQPixels];
   const FragQueues& q = a.q;
   const int t = threadIdx.x;
@@ -1251,9 +1257,7 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
       for (uint32_t i = sq_lane + kSpec * kGroup; i < n; i += kGroup) lost(q.key[qbase + i], q.pix[qbase + i]);
     }
   }
-  // (both counters are final: every queue push and every overflow happened in the launches before this one)
-  const bool want_planes = !a.idx_optional || a.big_count[0] != 0u || a.big_count[1] != 0u;
-  if (want_planes)
+  if (planes_wanted())
   for (int p = t; p < kQPixels; p += 256) {
     const uint32_t gx = x0 + (uint32_t)(p >> 6), gy = y0 + (uint32_t)(p & 63);
     if (gx < W && gy < H) {
@@ -1267,8 +1271,17 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
   if (t == 0) q.flag[tile] = 0u;
 }
 
+// Is the index plane of a view read by anybody?  Always, unless the launch's caller is fuse_view(s) with the triangle-order kernels
+// (idx_optional) -- and then only if a view FUSED TOGETHER with this one has queued triangles (big_count[0]: their waves scan the plane,
+// and for a triangle that is big in one view of a launch they scan the planes of the views in which it is small as well) or masks that
+// need checking (big_count[1]).  Both counters are final: every push and every overflow happened in the launches before the resolve.
+__device__ __forceinline__ bool view_needs_planes(const RasterArgs& a) { return !a.idx_optional || a.big_count[0] != 0u || a.big_count[1] != 0u; }
+// (A per-VIEW decision -- the fusion's big-triangle waves reading a triangle's small views from their records' masks instead of the planes -- was
+// built too and is not kept: 2 of 9 000 random soups still found a plane it had not written being read; k_tile_resolve_group 41.6 against 51 us
+// per eight cfg2 views, where a view or two of a group usually has a handful of queued triangles.)
+
 __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out) {
-  tile_resolve_block(a, idx_out, depth_out, blockIdx.x);
+  tile_resolve_block(a, idx_out, depth_out, blockIdx.x, [&] { return view_needs_planes(a); });     // (idx_optional here: a view that is fused alone, smesh_fuse_view)
 }
 
 __global__ __launch_bounds__(256) void k_raster_huge_group(RasterGroup g) {
@@ -1287,7 +1300,14 @@ __global__ __launch_bounds__(256) void k_raster_huge_group(RasterGroup g) {
 __global__ __launch_bounds__(256) void k_tile_resolve_group(RasterGroup g) {
   uint32_t v = 0;
   while (v + 1 < g.n && blockIdx.x >= g.tile_end[v]) v++;   // block-uniform, n <= kMaxGroup
-  tile_resolve_block(g.view[v], g.idx[v], nullptr, blockIdx.x - (v ? g.tile_end[v - 1] : 0u));
+  // the views of a raster launch are fused together (in launches of 8 / 4 / 2 / 1 of them): one decision for all of them -- a view without
+  // queued triangles of its own is still scanned for the triangles that are big in ANOTHER view of the launch (round 6: 2 of 7 500
+  // random soups caught the per-view decision, profiles/r06_differential_sweeps.txt)
+  tile_resolve_block(g.view[v], g.idx[v], nullptr, blockIdx.x - (v ? g.tile_end[v - 1] : 0u), [&] {
+    bool planes = false;
+    for (uint32_t u = 0; u < g.n; u++) planes = planes || view_needs_planes(g.view[u]);
+    return planes;
+  });
 }
 
 // Split the key image into the two output planes and re-arm the keys for the next render.
@@ -1514,6 +1534,12 @@ bool plane_optional_allowed(const smesh_renderer* r) {
   return !off && !r->texels && !r->prim_id && raster_path() == RasterPath::Frag;
 }
 
+// RasterArgs::idx_optional for a fuse_view(s) call of this renderer into this aggregator: 0 = the planes are read (not the triangle-order
+// kernels), 1 = they are read only for queued triangles and masks that need checking -- one decision per raster launch (view_needs_planes).
+int plane_optional_level(smesh_renderer* r, smesh_aggregator* a) {
+  return (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) ? 1 : 0;
+}
+
 // Consecutive triangle blocks per run of an XCD (xcd_block).  SMESH_RASTER_XCD=n sets it; 0: blocks take consecutive triangles in
 // dispatch order, as until round 5.  cfg2, eight views per launch (profiles/r06_raster_experiments.txt): k_raster_frag_group fetches
 // 149.6 MB with 0, 79.1 MB with 8 (x 2: gfx950's FETCH_SIZE unit) -- 562 -> 422 MB of traffic per launch -- and takes 195 -> 191 us; runs of
@@ -1661,7 +1687,7 @@ uint32_t frag_groups(uint64_t F, int views, uint32_t tpw) {
 }
 
 int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, float* d_depth, hipStream_t st = nullptr,
-                int side = 0, bool idx_optional = false) {
+                int side = 0, int idx_optional = 0) {
   DeviceCtx* ctx = r->ctx;
   r->last_render_side = side;
   if (!st) {
@@ -1685,7 +1711,7 @@ int render_into(smesh_renderer* r, const smesh_camera_t* cam, uint32_t* d_idx, f
     SMESH_HIP(hipMemsetAsync(r->side[side].big_count, 0, 32, st));
   }
   if (r->F) {
-    a.idx_optional = idx_optional && plane_optional_allowed(r) ? 1u : 0u;
+    a.idx_optional = (idx_optional && plane_optional_allowed(r)) ? (uint32_t)idx_optional : 0u;
     const uint32_t big_grid = (uint32_t)std::min<uint64_t>(r->F, (uint64_t)ctx->num_cus);
     int qs = SMESH_OK;
     if (raster_path() == RasterPath::Frag && ensure_queues(r, vs, W, H, st, &qs)) {
@@ -1778,9 +1804,9 @@ int prepare_group_slots(smesh_renderer* r, const smesh_camera_t* cams, int n, hi
 // `side_base`: where the records and index planes go (side[side_base + v], fused[side_base + v]) when that is not the view slots'
 // own set (held views: the rasteriser scratch of slots base .. base + n - 1 is free again after the launches, the records stay).
 int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipStream_t st, int base = 0, int side_base = -1,
-                      bool idx_optional = false) {
+                      int idx_optional = 0) {
   if (side_base < 0) side_base = base;
-  idx_optional = idx_optional && plane_optional_allowed(r);
+  if (!plane_optional_allowed(r)) idx_optional = 0;
   DeviceCtx* ctx = r->ctx;
   ProjectGroup pg;
   RasterGroup rg;
@@ -1808,7 +1834,7 @@ int render_group_into(smesh_renderer* r, const smesh_camera_t* cams, int n, hipS
     { const RasterArgs own = raster_args(r, vs, side_base + v, W, H, 1, &cams[v]); rg.view[v].wg_push = own.wg_push; rg.view[v].balance = own.balance; }
     rg.view[v].cam = pg.cam[v];
     rg.view[v].q = vs.fq;
-    rg.view[v].idx_optional = idx_optional ? 1u : 0u;
+    rg.view[v].idx_optional = (uint32_t)idx_optional;
     rg.idx[v] = static_cast<uint32_t*>(r->fused[side_base + v].ptr);
     tiles += (uint32_t)(div_up(W, kQW) * div_up(H, kQH));
     rg.tile_end[v] = tiles;
@@ -2379,7 +2405,7 @@ int smesh_fuse_view(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_came
   uint32_t* d_idx = static_cast<uint32_t*>(r->fused[slot].ptr);
   r->last_idx[slot] = nullptr; r->rec_valid[slot] = false;   // the records of a render_device() on this side are being overwritten
   // (the fusion only consumes the index plane -- and the triangle-order kernels not even that, where the view has no queued triangles)
-  const bool tri_path = !r->texels && smesh_aggregator_can_fuse_triangles(a, r->F);
+  const int tri_path = plane_optional_level(r, a);
   SMESH_TRY(render_into(r, cam, d_idx, /*d_depth=*/nullptr, ctx->stream, slot, tri_path));
   SMESH_TRY(fuse_rendered(r, a, slot, d_idx, probs, weights, memkind, W, H));
   r->fused_seq++;
@@ -2400,10 +2426,11 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
   DeviceCtx* ctx = r->ctx;
   if (smesh_aggregator_ctx(a) != ctx) return fail(SMESH_ERR_INVALID, "renderer and aggregator live on different devices");
   static const bool pairs_off = getenv("SMESH_FUSE_PAIRS") && atoi(getenv("SMESH_FUSE_PAIRS")) == 0;
-  bool pairable, tri_path;
+  bool pairable;
+  int tri_path;
   {
     std::lock_guard<std::mutex> g2(smesh_aggregator_mutex(a));
-    tri_path = !r->texels && smesh_aggregator_can_fuse_triangles(a, r->F);   // (fuse_rendered / the group's fusion take k_fuse_tri*: RasterArgs::idx_optional)
+    tri_path = plane_optional_level(r, a);   // (fuse_rendered / the group's fusion take k_fuse_tri*: RasterArgs::idx_optional)
     pairable = !pairs_off && memkind == SMESH_MEM_DEVICE && !r->texels && r->F != 0 && smesh_aggregator_can_fuse_triangles(a, r->F) &&
                smesh_aggregator_can_fuse_pair(a);
   }
@@ -2474,7 +2501,7 @@ int smesh_fuse_views(smesh_renderer_t* r, smesh_aggregator_t* a, const smesh_cam
           SMESH_TRY(r->fused[v].reserve(N * 8));
         }
         r->last_idx[v] = nullptr; r->rec_valid[v] = false;   // the records of a render_device() on this side are being overwritten
-        SMESH_TRY(render_into(r, &cams[i + v], static_cast<uint32_t*>(r->fused[v].ptr), /*d_depth=*/nullptr, ctx->stream, v, tri_path));
+        SMESH_TRY(render_into(r, &cams[i + v], static_cast<uint32_t*>(r->fused[v].ptr), /*d_depth=*/nullptr, ctx->stream, v));   // (fused as a PAIR below: each needs the other's plane decision -- always written)
       }
     }
     // texel renderers: the views of the group in ONE fusion launch (a triangle's texel rows make one round trip for all of them)
@@ -2608,7 +2635,7 @@ int smesh_fuse_views_begin(smesh_renderer_t* r, smesh_aggregator_t* a, const sme
   }
   static const int group_max = getenv("SMESH_RASTER_GROUP") ? std::min(kMaxGroup, std::max(2, atoi(getenv("SMESH_RASTER_GROUP")))) : kMaxGroup;
   for (int i = 0; i < h.n; i += group_max)
-    SMESH_TRY(render_group_into(r, &cams[i], std::min(group_max, h.n - i), ctx->stream, 0, kSlots + i, /*idx_optional: ranged => k_fuse_tri* */ true));
+    SMESH_TRY(render_group_into(r, &cams[i], std::min(group_max, h.n - i), ctx->stream, 0, kSlots + i, /*idx_optional: ranged => k_fuse_tri* */ plane_optional_level(r, a)));
   SMESH_TRY(fuse_held_part(r, a, 0));
   smesh_note_fuse(smesh_aggregator_fuse_kernel_name(a, false), "render-records");
   r->fused_seq += n;

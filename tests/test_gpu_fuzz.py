@@ -175,6 +175,15 @@ def test_random_soup_fuse_views_against_oracle(sm, oracle, seed):
         oracle.set_accum_double(False)
 
 
+@pytest.mark.parametrize("seed", [252362, 253169, 553071])
+def test_soup_fuse_views_seeds_that_caught_the_per_view_plane_decision(sm, oracle, seed):
+    """Round 6 let a view of fuse_views skip its index plane when it had no queued triangles OF ITS OWN -- but a triangle that is big in
+    one view of a launch has its small views scanned in THEIR planes too (fuse_tri.inc.hpp, the tail waves).  Two of 7 500 random soups of the
+    round's differential sweep (fifty triangles of a few pixels, several views) showed it: 20 of 150 elements 1 % off.  The decision is
+    now one per raster launch (raster.hip: view_needs_planes).  Seed 553071 caught a second attempt at a per-view decision."""
+    test_random_soup_fuse_views_against_oracle(sm, oracle, seed)
+
+
 @pytest.mark.parametrize("seed", range(14))
 def test_random_texel_soup_mul_against_the_float64_oracle(sm, oracle, seed):
     """Mul on texel renderers, triangles of every size: small ones fold each term into the (hi, lo) row in double (k_fuse_texel /
