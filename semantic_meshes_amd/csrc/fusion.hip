@@ -2482,9 +2482,6 @@ void smesh_fuse_part_rows(uint64_t F, int part, int nparts, uint64_t* f_lo, uint
   *f_hi = std::min(F, 64 * (B * (uint64_t)(part + 1) / (uint64_t)nparts));
 }
 
-// `nviews` = 1, 2, 4 or 8 (smesh_aggregator_max_fused_views): views[0], views[1] ... of the same renderer in one launch.
-// `part` / `nparts`: only the triangles of smesh_fuse_part_rows(F, part, nparts) -- the queued medium triangles (fuse_mid_entries, float
-// atomics) all go with part 0, the queued big ones with the part their position falls into.
 // Sum rows of 128 .. 255 classes: the pixel-list kernel (k_fuse_tri_wide_list; SMESH_WIDE_LIST=0: k_fuse_tri_wide as until round 5).
 // false: not launched.  Where it is used and where not is measured (cfg2's mesh and resolution, eight views per call, ms per view, old /
 // list kernel; profiles/r06_wide_rows_sweep.txt): Sum C = 128 0.405 / 0.381, 150 0.467 / 0.406, 192 0.438 / 0.407, 240 0.454 / 0.439 --
@@ -2501,6 +2498,9 @@ static bool launch_fuse_wide_list(int wide_chunks, uint32_t C, dim3 wgrid, hipSt
   }
 }
 
+// `nviews` = 1, 2, 4 or 8 (smesh_aggregator_max_fused_views): views[0], views[1] ... of the same renderer in one launch.
+// `part` / `nparts`: only the triangles of smesh_fuse_part_rows(F, part, nparts) -- the queued medium triangles (fuse_mid_entries, float
+// atomics) all go with part 0, the queued big ones with the part their position falls into.
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews, int part, int nparts) {
   DeviceCtx* ctx = a->ctx;
