@@ -191,9 +191,12 @@ __device__ __forceinline__ void load_row(const float* __restrict__ pr, int C, fl
 
 // One triangle of one view, its pixels found by scanning the box [x0, x1] x [y0, y1] of the index image: one WAVE, lanes
 // over the box; per-lane partial sums are combined by a butterfly over the wave and lane c owns class c of the row.
+// `by_mask`: the box is the (at most) 8 x 8 box of a view in which the triangle is SMALL, and `mask` (bit dx * 8 + dy) already names its
+// visible pixels there -- the record's mask after the tile resolve: the same pixels the scan would find, without the view's index plane
+// (which a view without queued triangles of its own then need not write at all: raster.hip, RasterArgs::idx_optional == 2).
 template <int CT, int KIND, bool EXACT>
 __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f, const int x0, const int y0, const int x1, const int y1,
-                                         uint32_t* __restrict__ lds_list) {
+                                         uint32_t* __restrict__ lds_list, const bool by_mask = false, const unsigned long long mask = 0ull) {
   const int C = EXACT ? CT : (int)a.C;   // run-time class count, C <= CT
   const int l = threadIdx.x;
   const int bh = y1 - y0 + 1;
@@ -221,8 +224,12 @@ __device__ __forceinline__ void fuse_box(const TriFuseArgs& a, const uint32_t f,
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const long long i = base + (long long)u * kWave + l;
-      v[u] = a.idx[i < npx ? pix_of(i) : pix_of(0)];
-      if (!(i < npx)) v[u] = ~f;
+      if (by_mask) {      // (wave-uniform; such a box is one round: one_step, n <= 64)
+        v[u] = (i < npx && ((mask >> ((int)(i / bh) * 8 + (int)(i % bh))) & 1ull)) ? f : ~f;
+      } else {
+        v[u] = a.idx[i < npx ? pix_of(i) : pix_of(0)];
+        if (!(i < npx)) v[u] = ~f;
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; u++) if (v[u] == f) { mine_n++; hits |= 1u << u; }
@@ -416,7 +423,9 @@ __device__ __forceinline__ void fuse_big_triangles(const TriFuseArgs& a, const T
         int x1, y1;
         if (rec.kind == 2) { x1 = (int)(rec.mask & 0xFFFFu); y1 = (int)((rec.mask >> 16) & 0xFFFFu); }
         else { x1 = min((int)rec.x0 + 7, (int)x.W - 1); y1 = min((int)rec.y0 + 7, (int)x.H - 1); }
-        fuse_box<CT, KIND, EXACT>(x, f, rec.x0, rec.y0, x1, y1, lds_list);
+        // (a view in which the triangle is small: its record's mask names the visible pixels, unless the render says its masks need checking)
+        const bool by_mask = rec.kind == 1 && !a.prim_id && vw.v[j].big_len[1] == 0u;
+        fuse_box<CT, KIND, EXACT>(x, f, rec.x0, rec.y0, x1, y1, lds_list, by_mask, rec.mask);
       }
     }
   }
@@ -499,6 +508,9 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(fuse_tri_
   if (verify) {
 #pragma unroll
     for (int v = 0; v < NV; v++) {
+      // (only the views whose OWN masks need checking: a view without the flag may not even have written its plane -- raster.hip,
+      // RasterArgs::idx_optional; round 6's sweep caught the all-views loop on a scene where one view of the launch overflowed its queues)
+      if (!scattered && vw.v[v].big_len[1] == 0u) continue;
       const uint32_t* __restrict__ idx = vw.v[v].idx;
       unsigned long long m = msk[v], win = 0ull;
       while (__ballot(m != 0ull) != 0ull) {

@@ -2447,6 +2447,7 @@ const char* smesh_aggregator_fuse_kernel_name(smesh_aggregator* a, bool reordere
 }
 
 int smesh_aggregator_max_fused_views(smesh_aggregator* a);
+bool smesh_aggregator_fuses_small_views_by_mask(smesh_aggregator* a);
 bool smesh_aggregator_takes_strided_probs(smesh_aggregator* a, int64_t ps0, int64_t ps1, int nviews);
 bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a) { return smesh_aggregator_max_fused_views(a) >= 2; }
 
@@ -2461,6 +2462,14 @@ int smesh_aggregator_max_fused_views(smesh_aggregator* a) {
   // through the 48-slot k_fuse_tri; Mul stays there (the Mul instances of k_fuse_tri_any carry a view's partial sums in double: 220 VGPRs)
   if (a->C > 40u && a->C <= (uint32_t)kFuseTriMaxC && a->kind != SMESH_AGG_MUL) m = 8;
   return std::min(m, cap);
+}
+
+// Is EVERY triangle-order launch of this aggregator k_fuse_tri -- whose waves never read the index plane of a view that has neither queued
+// triangles nor masks to check (fuse_box by_mask, the per-view verify pass)?  Up to 40 classes yes, whatever the number of views; 41 .. 48 only
+// for Mul (two views at most); Sum / Summax there take k_fuse_tri_any + k_fuse_big_any for more than two views, and those scan the planes.
+// raster.hip asks before it lets each view of a group decide on its own plane (plane_optional_level).
+bool smesh_aggregator_fuses_small_views_by_mask(smesh_aggregator* a) {
+  return a->C <= 40u || (a->C <= (uint32_t)kFuseTriMaxC && a->kind == SMESH_AGG_MUL && smesh_aggregator_max_fused_views(a) <= 2);
 }
 
 // Can the triangle-order fusion of this aggregator read class vectors in place at element strides (ps0, ps1, 1) -- the (H,W,C)

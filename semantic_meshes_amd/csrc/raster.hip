@@ -42,6 +42,7 @@ bool smesh_aggregator_can_fuse_pair(smesh_aggregator* a);
 int smesh_aggregator_max_fused_views(smesh_aggregator* a);
 bool smesh_aggregator_takes_strided_probs(smesh_aggregator* a, int64_t ps0, int64_t ps1, int nviews);
 int smesh_aggregator_dense_probs(smesh_aggregator* a, const float* d_probs, const int64_t ps[3], uint64_t W, uint64_t H, const float** out);
+bool smesh_aggregator_fuses_small_views_by_mask(smesh_aggregator* a);
 int smesh_aggregator_fuse_triangles(smesh_aggregator* a, uint64_t F, const uint32_t* prim_id, uint32_t big_capacity,
                                     const RenderedView* views, int nviews, int part = 0, int nparts = 1);
 void smesh_fuse_part_rows(uint64_t F, int part, int nparts, uint64_t* f_lo, uint64_t* f_hi);
@@ -1276,9 +1277,10 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
 // and for a triangle that is big in one view of a launch they scan the planes of the views in which it is small as well) or masks that
 // need checking (big_count[1]).  Both counters are final: every push and every overflow happened in the launches before the resolve.
 __device__ __forceinline__ bool view_needs_planes(const RasterArgs& a) { return !a.idx_optional || a.big_count[0] != 0u || a.big_count[1] != 0u; }
-// (A per-VIEW decision -- the fusion's big-triangle waves reading a triangle's small views from their records' masks instead of the planes -- was
-// built too and is not kept: 2 of 9 000 random soups still found a plane it had not written being read; k_tile_resolve_group 41.6 against 51 us
-// per eight cfg2 views, where a view or two of a group usually has a handful of queued triangles.)
+// idx_optional == 2: every fusion launch of these views is k_fuse_tri, whose big-triangle waves read a triangle's SMALL views from their
+// records' masks (fuse_box by_mask) and whose main waves check only the views that ask for it: the decision is each view's own
+// (k_tile_resolve_group 41.6 against 51 us per eight cfg2 views, where a view or two of a group usually has a handful of queued triangles).
+// == 1: k_fuse_tri_any / _wide, whose k_fuse_big_any scans the planes of such views: one decision for the raster launch.
 
 __global__ __launch_bounds__(256) void k_tile_resolve(RasterArgs a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out) {
   tile_resolve_block(a, idx_out, depth_out, blockIdx.x, [&] { return view_needs_planes(a); });     // (idx_optional here: a view that is fused alone, smesh_fuse_view)
@@ -1300,10 +1302,11 @@ __global__ __launch_bounds__(256) void k_raster_huge_group(RasterGroup g) {
 __global__ __launch_bounds__(256) void k_tile_resolve_group(RasterGroup g) {
   uint32_t v = 0;
   while (v + 1 < g.n && blockIdx.x >= g.tile_end[v]) v++;   // block-uniform, n <= kMaxGroup
-  // the views of a raster launch are fused together (in launches of 8 / 4 / 2 / 1 of them): one decision for all of them -- a view without
-  // queued triangles of its own is still scanned for the triangles that are big in ANOTHER view of the launch (round 6: 2 of 7 500
-  // random soups caught the per-view decision, profiles/r06_differential_sweeps.txt)
+  // the views of a raster launch are fused together (in launches of 8 / 4 / 2 / 1 of them): one decision for all of them (level 1) -- a view
+  // without queued triangles of its own is still scanned for the triangles that are big in ANOTHER view of the launch (round 6: 2 of 7 500
+  // random soups caught a per-view decision there, profiles/r06_differential_sweeps.txt) -- unless the fusion kernel does not do that (level 2)
   tile_resolve_block(g.view[v], g.idx[v], nullptr, blockIdx.x - (v ? g.tile_end[v - 1] : 0u), [&] {
+    if (g.view[v].idx_optional == 2u) return view_needs_planes(g.view[v]);
     bool planes = false;
     for (uint32_t u = 0; u < g.n; u++) planes = planes || view_needs_planes(g.view[u]);
     return planes;
@@ -1535,9 +1538,15 @@ bool plane_optional_allowed(const smesh_renderer* r) {
 }
 
 // RasterArgs::idx_optional for a fuse_view(s) call of this renderer into this aggregator: 0 = the planes are read (not the triangle-order
-// kernels), 1 = they are read only for queued triangles and masks that need checking -- one decision per raster launch (view_needs_planes).
+// kernels), 1 = they are read only for queued triangles and masks that need checking -- one decision per raster launch (view_needs_planes),
+// 2 = the same, each view for itself: aggregators whose EVERY triangle-order launch is k_fuse_tri (smesh_aggregator_fuses_small_views_by_mask:
+// not the name of the kernel -- 41 .. 48 classes go to k_fuse_tri_any when a launch holds more than two views, which is what the first
+// attempt at level 2 tripped over: seeds 553071 / 702926 of tools/soup_sweep.py, C = 47 / 48).  SMESH_PLANE_LEVEL=1 forces level 1.
 int plane_optional_level(smesh_renderer* r, smesh_aggregator* a) {
-  return (!r->texels && smesh_aggregator_can_fuse_triangles(a, r->F)) ? 1 : 0;
+  if (r->texels || !smesh_aggregator_can_fuse_triangles(a, r->F)) return 0;
+  static const int forced = getenv("SMESH_PLANE_LEVEL") ? atoi(getenv("SMESH_PLANE_LEVEL")) : 0;
+  if (forced == 1) return 1;
+  return smesh_aggregator_fuses_small_views_by_mask(a) ? 2 : 1;
 }
 
 // Consecutive triangle blocks per run of an XCD (xcd_block).  SMESH_RASTER_XCD=n sets it; 0: blocks take consecutive triangles in

@@ -175,12 +175,14 @@ def test_random_soup_fuse_views_against_oracle(sm, oracle, seed):
         oracle.set_accum_double(False)
 
 
-@pytest.mark.parametrize("seed", [252362, 253169, 553071])
+@pytest.mark.parametrize("seed", [252362, 253169, 553071, 702926])
 def test_soup_fuse_views_seeds_that_caught_the_per_view_plane_decision(sm, oracle, seed):
     """Round 6 let a view of fuse_views skip its index plane when it had no queued triangles OF ITS OWN -- but a triangle that is big in
     one view of a launch has its small views scanned in THEIR planes too (fuse_tri.inc.hpp, the tail waves).  Two of 7 500 random soups of the
     round's differential sweep (fifty triangles of a few pixels, several views) showed it: 20 of 150 elements 1 % off.  The decision is
-    now one per raster launch (raster.hip: view_needs_planes).  Seed 553071 caught a second attempt at a per-view decision."""
+    now one per raster launch wherever a fusion kernel does that (raster.hip: view_needs_planes, level 1), and each view's own where every
+    launch is k_fuse_tri, which reads such views from their records' masks (level 2; fuse_box by_mask).  Seeds 553071 and 702926 (47 / 48
+    classes, eight / nine views: k_fuse_tri_any, not k_fuse_tri as the kernel's NAME for that class count says) caught the first level 2."""
     test_random_soup_fuse_views_against_oracle(sm, oracle, seed)
 
 
