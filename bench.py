@@ -389,9 +389,9 @@ def main():
                          "measured in a short SERIALISED leg of the same run (roofline.note)")
     ap.add_argument("--no-group-pipeline", dest="group_pipeline", action="store_false",
                     help="one kernel at a time on the GPU throughout (what rounds 1-4 timed); the roofline comes from the timed region itself")
-    ap.add_argument("--repeats", type=int, default=int(os.environ.get("SMESH_BENCH_REPEATS", "7")),
+    ap.add_argument("--repeats", type=int, default=int(os.environ["SMESH_BENCH_REPEATS"]) if os.environ.get("SMESH_BENCH_REPEATS") else None,
                     help="the K-step timed region (barrier, K steps, exchange, barrier) is run this many times; `value` is the MEDIAN region, "
-                         "config.repeats / value_min / value_max say how far the others were")
+                         "config.repeats / value_min / value_max / region_ms say how far the others were.  Default: 7, and 25 for K <= 40")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench: --gpus must be at least 1")
@@ -405,9 +405,14 @@ def main():
     gp = ctypes.c_int64(0)
     _lib.check(_lib.lib().smesh_get_option(b"group_pipeline", ctypes.byref(gp)))
     pipelined = bool(gp.value)
-    args.repeats = max(1, args.repeats)
     if args.steps is None:
         args.steps = {"cfg5": 24}.get(args.workload, 200)
+    if args.repeats is None:
+        # A region of twenty cfg2 views is 1.3 ms of device time, and the first eight or so such regions of a process run 4 - 6 % slower than the
+        # rest (1.37 -> 1.305 ms; profiles/r06_steps20_regions.txt): with seven regions the median sat on that ramp.  Short regions are repeated more
+        # often -- every region is still K timed steps between two barriers, all of them are listed in config.region_ms, the value is their median.
+        args.repeats = 7 if args.steps > 40 else 25
+    args.repeats = max(1, args.repeats)
     if args.warmup is None:
         args.warmup = {"cfg5": 4}.get(args.workload, 10)
 
