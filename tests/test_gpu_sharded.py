@@ -243,7 +243,7 @@ def test_bench_line_of_a_two_rank_run(tmp_path, sm, exchange):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--workload", "cfg1"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--workload", "cfg1", "--repeats", "7"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -275,7 +275,7 @@ def test_bench_gpus_two_without_a_launcher_spawns_two_ranks(tmp_path, sm):
     env = dict(os.environ, SMESH_BENCH_BACKEND="gloo", OMP_NUM_THREADS="1")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "SMESH_EXCHANGE"):
         env.pop(k, None)
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--workload", "cfg1"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "4", "--workload", "cfg1", "--repeats", "7"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=str(tmp_path))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
@@ -405,7 +405,7 @@ def test_cfg3_geometry_eight_ranks_on_one_gpu(tmp_path, sm):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "SMESH_EXCHANGE"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "2", "--workload", "cfg2"]
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "8", "--warmup", "2", "--workload", "cfg2", "--repeats", "7"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500, cwd=str(tmp_path))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith('{"metric"')]
