@@ -1193,6 +1193,7 @@ template <typename PlanesWanted>
 __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out,
                                                    const uint32_t tile, PlanesWanted planes_wanted) {
   __shared__ unsigned long long skeys[kQPixels];
+  __shared__ uint32_t scount[kQSub];
   const FragQueues& q = a.q;
   const int t = threadIdx.x;
   const uint32_t W = a.W, H = a.H;
@@ -1213,6 +1214,7 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
     spec_pix[k] = q.pix[qbase + i];
   }
   const uint32_t n = min(q.count[tile * kQSub + sq], q.cap);
+  if (sq_lane == 0u) scount[sq] = n;
   // bit 0: fragments of small triangles that did not fit the queue went through the global key image; bit 1: k_raster_huge left the
   // fragments of triangles larger than kMedium x kMedium (and of triangles clipped at the near plane) there
   const uint32_t tile_flag = q.flag[tile];
@@ -1232,7 +1234,34 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
   for (uint32_t k = 0; k < kSpec; k++)
     if (sq_lane + k * kGroup < n) atomicMin(&skeys[spec_pix[k]], spec_key[k]);
   // (skipping the null keys of the cooperative loop's sub-rectangles here was measured slower: 10 000 triangles 0.083 -> 0.090 ms per view)
-  for (uint32_t i = sq_lane + kSpec * kGroup; i < n; i += kGroup) atomicMin(&skeys[q.pix[qbase + i]], q.key[qbase + i]);
+  // What the speculative loads did not cover -- entries kHead ... of every sub-queue -- is ONE list for all 256 threads (sub-queue after
+  // sub-queue), four entries of a thread in flight: the sub-queues of a tile fill evenly only where many waves reach it.  A medium
+  // triangle's whole sub-rectangle sits in its wave's sub-queue, and a tile of a coarse mesh hears from three or four waves: a quarter
+  // of the threads then walked most of the tile's entries (round 6: profiles/r06_coarse_and_inside_traces.txt).
+  constexpr uint32_t kHead = kSpec * kGroup;
+  uint32_t rest[kQSub], total = 0u;
+#pragma unroll
+  for (int s = 0; s < kQSub; s++) { rest[s] = scount[s] > kHead ? scount[s] - kHead : 0u; total += rest[s]; }
+  auto entry_of = [&](uint32_t j) -> uint64_t {      // j < total: the j-th of those entries
+    uint32_t sub = 0u;
+#pragma unroll
+    for (int s = 0; s < kQSub - 1; s++) if (sub == (uint32_t)s && j >= rest[s]) { j -= rest[s]; sub = (uint32_t)s + 1u; }
+    return ((uint64_t)tile * kQSub + sub) * q.cap + kHead + j;
+  };
+  for (uint32_t j0 = (uint32_t)t; j0 < total; j0 += 4u * 256u) {
+    unsigned long long k4[4];
+    uint16_t p4[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++) {
+      const uint32_t j = j0 + u * 256u;
+      const uint64_t e = j < total ? entry_of(j) : qbase;
+      k4[u] = q.key[e];
+      p4[u] = q.pix[e];
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4u; u++)
+      if (j0 + u * 256u < total) atomicMin(&skeys[p4[u]], k4[u]);
+  }
   __syncthreads();
   // The depth test is decided: tell the triangle-order fusion which fragments of the small triangles LOST it, by clearing their
   // bit in the triangle's record (about one fragment in twenty at cfg2; the winners need no memory traffic at all).  The record
@@ -1255,7 +1284,20 @@ __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t
 #pragma unroll
       for (uint32_t k = 0; k < kSpec; k++)
         if (sq_lane + k * kGroup < n) lost(spec_key[k], spec_pix[k]);
-      for (uint32_t i = sq_lane + kSpec * kGroup; i < n; i += kGroup) lost(q.key[qbase + i], q.pix[qbase + i]);
+      for (uint32_t j0 = (uint32_t)t; j0 < total; j0 += 4u * 256u) {
+        unsigned long long k4[4];
+        uint16_t p4[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++) {
+          const uint32_t j = j0 + u * 256u;
+          const uint64_t e = j < total ? entry_of(j) : qbase;
+          k4[u] = q.key[e];
+          p4[u] = q.pix[e];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; u++)
+          if (j0 + u * 256u < total) lost(k4[u], p4[u]);
+      }
     }
   }
   if (planes_wanted())
