@@ -556,6 +556,7 @@ def main():
         return ms.value
 
     B = max(1, args.views_per_call)
+    call_sizes = [max(1, int(v)) for v in os.environ.get("SMESH_BENCH_CALL_SIZES", "").split(",") if v.strip()]
 
     def fuse_range(first, last):
         """views [first, last) in order: one fuse_view call per view, or fuse_views on batches of B (the library then
@@ -563,6 +564,12 @@ def main():
         if B == 1:
             for i in range(first, last):
                 agg.fuse_view(renderer, cams[i], probs[i])
+        elif call_sizes:
+            i, k = first, 0
+            while i < last:      # (experiment: SMESH_BENCH_CALL_SIZES=4,8,4,4 -- calls of these sizes in turn; profiles/r06_steps20_regions.txt)
+                j = min(i + call_sizes[k % len(call_sizes)], last)
+                agg.fuse_views(renderer, cams[i:j], probs[i:j])
+                i, k = j, k + 1
         else:
             for i in range(first, last, B):
                 j = min(i + B, last)
