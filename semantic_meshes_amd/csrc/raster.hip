@@ -302,7 +302,8 @@ struct RasterArgs {
                               // kLaneBox x kLaneBox) box; tpw = 64 / kSpread (raster_frag_wave)
   uint32_t idx_optional;      // k_tile_resolve: nonzero = the index plane is wanted only by the fusion's fallback paths (smesh_fuse_view(s) of a
                               // triangle renderer in its own face order: k_fuse_tri* read the plane for queued triangles -- big_count[0] -- and
-                              // when the masks need checking -- big_count[1]): a view with neither does not write it (8.3 MB per 1080p view)
+                              // when the masks need checking -- big_count[1]): a view with neither does not write it (8.3 MB per 1080p view).
+                              // 2 = each view of a group for itself, 1 = one decision for the group's launch (plane_optional_level)
   int dbg;                    // development ablation (SMESH_RDBG) of k_raster_frag: 1 = no stores, 2 = setup only, 4 = + coverage,
                               // 8 = + slot reservation, 16 = grouping without the reservation atomics
 };
@@ -1187,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_raster_huge(RasterArgs a, uint32_t ntil
 // One workgroup per tile: depth test in LDS over the tile's fragment queue, then the big triangles (bounding box
 // > 8 x 8: the workgroup scans their queue, keeps those whose box overlaps the tile and shades the overlap, 256
 // samples at a time), then the output planes are written once.  "Big" here means larger than kMedium x kMedium.
-// `planes_wanted()`: false = nobody will read this view's planes (RasterArgs::idx_optional; decided by the kernel for the whole launch, asked
+// `planes_wanted()`: false = nobody will read this view's planes (RasterArgs::idx_optional; decided by the kernel per view or for the whole launch, asked
 // only where the planes would be written: its loads are not on the block's way in).
 template <typename PlanesWanted>
 __device__ __forceinline__ void tile_resolve_block(const RasterArgs& a, uint32_t* __restrict__ idx_out, float* __restrict__ depth_out,
